@@ -1,0 +1,162 @@
+/*
+ * mclstexp_hip.h -- C ABI of libmclstexp_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * contrastive training hot path of mclSTExp.
+ *
+ * The reference (ZhicengShi/mclSTExp) has no native code and no FFI: every entry point below
+ * replaces the ATen dispatch behind one call site of /root/reference/model.py or train.py, cited
+ * per function.  Conventions:
+ *   - plain pointers + sizes only; every buffer is caller-owned DEVICE memory (the Python host
+ *     passes torch tensors' data_ptr()); the library never allocates, frees or retains pointers;
+ *   - every call only ENQUEUES work on the caller's stream (hipStream_t passed as void*); no host
+ *     synchronisation, no global mutable state; safe from one host thread per device;
+ *   - return 0 on success, a positive hipError_t if a launch failed, a negative MCL_E* code for a
+ *     rejected argument.  No exceptions cross the ABI.
+ *   - all matrices are fp32 row-major with explicit leading dimensions (elements, not bytes);
+ *     G (genes) need not be a multiple of anything: tails are masked in-kernel.
+ */
+#ifndef MCLSTEXP_HIP_H
+#define MCLSTEXP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCL_ABI_VERSION 1
+
+#define MCL_OK 0
+#define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
+#define MCL_EUNSUPPORTED (-2) /* valid but not implemented (e.g. head_dim != 64) */
+#define MCL_EWORKSPACE (-3)   /* workspace too small (see the *_workspace_bytes query) */
+
+typedef void* mcl_stream_t; /* hipStream_t */
+
+int mcl_abi_version(void);
+const char* mcl_error_string(int code);
+
+/* ---------------------------------------------------------------- GEMM (K3, K5, K6, K7, K8 contractions)
+ * C[b] = epilogue( alpha * A[b] (M x K) * B[b] (K x N) ), fp32 in HBM.
+ * Element (m,k) of A is A[b*sAb + m*sAm + k*sAk]; element (k,n) of B is B[b*sBb + k*sBk + n*sBn];
+ * exactly one of (sAm,sAk) and one of (sBk,sBn) must be 1.  This single strided form covers
+ *   y = x W^T      nn.Linear forward      model.py:23,27,43,45,155,157   (A k-contig, B k-contig)
+ *   dx = dy W      nn.Linear backward-data                              (A k-contig, B n-contig)
+ *   dW = dy^T x    nn.Linear backward-weight                            (A m-contig, B n-contig)
+ *   q k^T, attn v  einsum model.py:53,55 batched over heads (b = head, strided views of qkv)
+ *   S = E_spot E_img^T / T                model.py:242
+ * Epilogue, in order:  v = alpha*acc ; v += bias[n] ; if pre_out: pre_out[m,n] = v ;
+ *   GELU: v = gelu_erf(v) (nn.GELU, model.py:25,156) ; GELU_BWD: v *= gelu_erf'(aux[m,n]) ;
+ *   v += resid[m,n] (residual, model.py:67,68,165) ; ACCUM: v += C[m,n] ; C[m,n] = v.
+ * compute: MCL_COMPUTE_F32 = v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate);
+ *          MCL_COMPUTE_BF16 = operands rounded to bf16 at LDS staging, v_mfma_f32_32x32x16_bf16.
+ */
+#define MCL_EPI_GELU 1
+#define MCL_EPI_GELU_BWD 2
+#define MCL_EPI_ACCUM 4
+#define MCL_COMPUTE_F32 0
+#define MCL_COMPUTE_BF16 1
+
+typedef struct mcl_gemm_args {
+  int32_t M, N, K, batch;
+  const float* A; int64_t sAm, sAk, sAb;
+  const float* B; int64_t sBk, sBn, sBb;
+  float* C; int64_t ldc, sCb;
+  float alpha;
+  int32_t flags;         /* MCL_EPI_* */
+  const float* bias;     /* [N] or NULL */
+  const float* resid; int64_t ldr, sRb;  /* NULL or (M,N) per batch */
+  float* pre_out; int64_t ldp;           /* NULL or (M,N): pre-activation store (batch must be 1) */
+  const float* aux; int64_t ldaux;       /* (M,N) for MCL_EPI_GELU_BWD (batch must be 1) */
+  int32_t compute;       /* MCL_COMPUTE_* */
+  int32_t reserved;
+} mcl_gemm_args;
+
+int mcl_gemm(const mcl_gemm_args* args, mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- K1 position-embedding add
+ * model.py:230-235:  out[b,:] = expr[b,:] + X[(long)pos[b,0],:] + Y[(long)pos[b,1],:]
+ * (tables model.py:204-205, 65536 rows).  (long) truncates toward zero.  ix/iy (int32, B) receive
+ * the indices for the backward.  Indices outside [0,n_rows) are clamped and *err_flag (device int,
+ * may be NULL) is set to 1 -- nn.Embedding would raise.                                        */
+int mcl_pos_embed_add_fwd(const float* expr, int64_t ld_expr, const float* pos /*(B,2)*/,
+                          const float* x_table, const float* y_table, int64_t ld_table, int32_t n_rows,
+                          float* out, int64_t ld_out, int32_t* ix, int32_t* iy, int32_t* err_flag,
+                          int32_t B, int32_t G, mcl_stream_t stream);
+
+/* Backward of the gather (autograd of nn.Embedding, dense in the reference: two (65536,G) grads).
+ * Row-sparse, deterministic: slot b is "owner" iff no b' < b has idx[b'] == idx[b]; then
+ * row_grad[b,:] = sum_{b'>=b, idx[b']==idx[b]} d_out[b',:] (ascending b') and owner_idx[b] = idx[b];
+ * otherwise owner_idx[b] = -1 and row_grad[b,:] is untouched.                                   */
+int mcl_embed_rowgrad(const float* d_out, int64_t ld_dout, const int32_t* idx, int32_t* owner_idx,
+                      float* row_grad, int64_t ld_rg, int32_t B, int32_t G, mcl_stream_t stream);
+
+/* Dense scatter of owner rows: table_grad[owner_idx[b],:] (+)= row_grad[b,:] for owners
+ * (accumulate != 0 adds, else overwrites).  For drop-in use with a stock dense optimizer.      */
+int mcl_embed_scatter_rows(const int32_t* owner_idx, const float* row_grad, int64_t ld_rg, float* table_grad,
+                           int64_t ld_table, int32_t B, int32_t G, int32_t accumulate, mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- K2 LayerNorm (model.py:13,17,158,166)
+ * y = (x-mean)*rstd*gamma + beta over the last dim (biased variance, eps inside the sqrt).
+ * mean/rstd (rows) are saved for the backward.                                                */
+int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                      float* mean, float* rstd, int32_t rows, int32_t cols, float eps, mcl_stream_t stream);
+/* dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ dx_add if non-NULL: the residual branch's gradient,
+ * may alias dx), g = dy*gamma.  dgamma/dbeta (cols) are OVERWRITTEN with the column sums over rows. */
+int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, const float* dx_add, int64_t ldadd, float* dx,
+                      int64_t lddx, float* dgamma, float* dbeta, int32_t rows, int32_t cols, mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- K4 attention softmax (model.py:53-54)
+ * In place over n_rows rows of length cols (row stride ld):  p = softmax(scale * s).           */
+int mcl_softmax_rows_fwd(float* s, int64_t ld, int32_t n_rows, int32_t cols, float scale, mcl_stream_t stream);
+/* In place on dp:  ds = scale * p * (dp - sum_j dp_j p_j).                                     */
+int mcl_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int32_t n_rows, int32_t cols, float scale,
+                         mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- bias gradient
+ * out[n] = sum_m x[m,n]  (nn.Linear bias backward).                                           */
+int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- K8 symmetric InfoNCE (model.py:242-247)
+ * Works on a logits strip S (R x C, already divided by T): this rank's rows are global rows
+ * [row0,row0+R) and its columns are global columns [col0,col0+C); the target (identity) entry of
+ * local (i,j) is at row0+i == col0+j.
+ *
+ * mcl_infonce_lse: row_lse[i] = LSE_j S_ij (if row_lse != NULL) and col_lse[j] = LSE_i S_ij (if
+ * col_lse != NULL), max-subtracted.                                                            */
+int mcl_infonce_lse(const float* S, int64_t ldS, int32_t R, int32_t C, float* row_lse, float* col_lse,
+                    mcl_stream_t stream);
+/* loss_sum[0] (+)= sum_i (row_lse[i] - S_ii)  and  loss_sum[1] (+)= sum_j (col_lse[j] - S_jj) over
+ * the target entries present in this strip; n_diag = how many to visit starting at local
+ * (di0, dj0).  The reference's loss is (loss_sum[0]+loss_sum[1]) / (2*B_glob).                 */
+int mcl_infonce_loss(const float* S, int64_t ldS, const float* row_lse, const float* col_lse,
+                     int32_t di0, int32_t dj0, int32_t n_diag, int32_t use_rows, int32_t use_cols,
+                     float* loss_sum, mcl_stream_t stream);
+/* dS_ij = coef * (exp(S_ij-row_lse[i]) + exp(S_ij-col_lse[j]) - 2*[row0+i == col0+j]), written to
+ * dS (may alias S).  coef = 1/(2*B_glob*T) folds the temperature of model.py:242.              */
+int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const float* col_lse, int32_t R,
+                        int32_t C, int32_t row0, int32_t col0, float coef, float* dS, int64_t lddS,
+                        mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- K9 Adam with L2 weight decay
+ * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
+ *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+ *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),   bc1 = 1-b1^t, bc2 = 1-b2^t (host-computed).
+ * Flat fp32 buffers of n elements (28 B/element of HBM traffic).                               */
+int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float bc1, float bc2, mcl_stream_t stream);
+/* Same update for an embedding table (n_rows x cols, contiguous) whose data gradient is row-sparse:
+ * g = wd*p + (row_slot[r] >= 0 ? row_grad[row_slot[r],:] : 0).  24 B/element: the dense zero
+ * gradient of the reference (model.py:204-205 under autograd) is never materialised.
+ * row_slot (n_rows int32) maps table row -> slot in row_grad or -1.                            */
+int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
+                        const float* row_grad, int64_t ld_rg, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float bc1, float bc2, mcl_stream_t stream);
+/* row_slot maintenance: set row_slot[owner_idx[b]] = b for owners (fill != 0) or back to -1.    */
+int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill, mcl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCLSTEXP_HIP_H */

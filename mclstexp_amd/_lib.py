@@ -1,0 +1,97 @@
+"""ctypes binding of libmclstexp_hip.so (the C ABI in include/mclstexp_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  ``lib()`` loads lazily so that host-side code (argument parsing, module construction,
+state-dict handling) can be imported on a machine without the library built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmclstexp_hip.so")
+ABI_VERSION = 1
+
+_lib: Optional[C.CDLL] = None
+
+c_f = C.c_float
+c_i = C.c_int32
+c_l = C.c_int64
+c_p = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    """struct mcl_gemm_args (include/mclstexp_hip.h)."""
+    _fields_ = [
+        ("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i),
+        ("A", c_p), ("sAm", c_l), ("sAk", c_l), ("sAb", c_l),
+        ("B", c_p), ("sBk", c_l), ("sBn", c_l), ("sBb", c_l),
+        ("C", c_p), ("ldc", c_l), ("sCb", c_l),
+        ("alpha", c_f), ("flags", c_i),
+        ("bias", c_p),
+        ("resid", c_p), ("ldr", c_l), ("sRb", c_l),
+        ("pre_out", c_p), ("ldp", c_l),
+        ("aux", c_p), ("ldaux", c_l),
+        ("compute", c_i), ("reserved", c_i),
+    ]
+
+
+EPI_GELU, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+PROTOTYPES = {
+    "mcl_abi_version": [],
+    "mcl_error_string": [c_i],
+    "mcl_gemm": [C.POINTER(GemmArgs), c_p],
+    "mcl_pos_embed_add_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p],
+    "mcl_embed_rowgrad": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
+    "mcl_embed_scatter_rows": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
+    "mcl_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_p],
+    "mcl_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p],
+    "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
+    "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
+    "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mcl_infonce_lse": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
+    "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+    "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
+    "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
+    "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
+}
+_RESTYPES = {"mcl_error_string": C.c_char_p}
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the library and attach prototypes.  Raises RuntimeError if absent or ABI-mismatched."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built.  Run `python -m mclstexp_amd.build` "
+            "(hipcc --offload-arch=gfx950).  mclstexp_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{path} does not export {name}; rebuild the library") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    v = lib.mcl_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"{path} has ABI version {v}, host expects {ABI_VERSION}; rebuild")
+    return lib
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = lib().mcl_error_string(code)
+        raise RuntimeError(f"mclstexp_hip {what} failed: [{code}] {msg.decode() if msg else '?'}")

@@ -1,0 +1,131 @@
+// K9: torch.optim.Adam(lr, betas, eps, weight_decay) (L2-coupled), train.py:118-120, as one fused
+// streaming pass.  Pure HBM traffic: 28 B/element (read p,g,m,v; write p,m,v); the embedding-table
+// form reads no dense gradient (24 B/element) and adds the row-sparse data gradient through a
+// row->slot map.  16-byte accesses per lane, grid-stride, ~8 workgroups per CU.
+#include "common.h"
+
+namespace {
+
+struct AdamC {
+  float lr_over_bc1, beta1, beta2, eps, wd, rsqrt_bc2;
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamC& c) {
+  g = fmaf(c.wd, p, g);                         // grad.add(param, alpha=wd)
+  m = fmaf(1.0f - c.beta1, g - m, m);           // exp_avg.lerp_(grad, 1-beta1)
+  v = fmaf(c.beta2, v, (1.0f - c.beta2) * g * g);
+  const float denom = sqrtf(v) * c.rsqrt_bc2 + c.eps;
+  p -= c.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   AdamC c) {
+  const long long n4 = n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    adam1(pp.x, gg.x, mm.x, vv.x, c);
+    adam1(pp.y, gg.y, mm.y, vv.y, c);
+    adam1(pp.z, gg.z, mm.z, vv.z, c);
+    adam1(pp.w, gg.w, mm.w, vv.w, c);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  const long long tail0 = n4 << 2;
+  for (long long i = tail0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    adam1(p[i], g[i], m[i], v[i], c);
+}
+
+// unaligned fallback (base pointers not 16-byte aligned)
+__global__ __launch_bounds__(256) void adam_kernel_scalar(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, long long n,
+                                                          AdamC c) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    adam1(p[i], g[i], m[i], v[i], c);
+}
+
+// One workgroup walks whole rows (grid-stride over rows); the row's slot is wave-uniform.
+template <bool VEC>
+__global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, float* __restrict__ m,
+                                                         float* __restrict__ v, int n_rows, int cols,
+                                                         const int* __restrict__ row_slot,
+                                                         const float* __restrict__ rg, long long ldrg, AdamC c) {
+  for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    const int slot = row_slot[r];
+    const long long base = (long long)r * cols;
+    const float* g = slot >= 0 ? rg + (long long)slot * ldrg : nullptr;
+    if (VEC) {
+      float4* p4 = reinterpret_cast<float4*>(p + base);
+      float4* m4 = reinterpret_cast<float4*>(m + base);
+      float4* v4 = reinterpret_cast<float4*>(v + base);
+      const float4* g4 = reinterpret_cast<const float4*>(g);
+      for (int i = threadIdx.x; i < (cols >> 2); i += 256) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        float4 gg = g ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        adam1(pp.x, gg.x, mm.x, vv.x, c);
+        adam1(pp.y, gg.y, mm.y, vv.y, c);
+        adam1(pp.z, gg.z, mm.z, vv.z, c);
+        adam1(pp.w, gg.w, mm.w, vv.w, c);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+      }
+    } else {
+      for (int i = threadIdx.x; i < cols; i += 256) adam1(p[base + i], g ? g[i] : 0.0f, m[base + i], v[base + i], c);
+    }
+  }
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+
+inline AdamC make_consts(float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+  AdamC c;
+  c.lr_over_bc1 = lr / bc1;
+  c.beta1 = b1;
+  c.beta2 = b2;
+  c.eps = eps;
+  c.wd = wd;
+  c.rsqrt_bc2 = 1.0f / sqrtf(bc2);
+  return c;
+}
+
+}  // namespace
+
+extern "C" int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float bc1, float bc2, mcl_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) return MCL_EINVAL;
+  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (al16(p) && al16(g) && al16(m) && al16(v))
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), p, g, m, v,
+                       (long long)n, c);
+  else
+    hipLaunchKernelGGL(adam_kernel_scalar, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), p, g, m, v,
+                       (long long)n, c);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t cols,
+                                   const int32_t* row_slot, const float* row_grad, int64_t ld_rg, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+                                   mcl_stream_t stream) {
+  if (!p || !m || !v || !row_slot || !row_grad || n_rows <= 0 || cols <= 0 || bc1 <= 0.f || bc2 <= 0.f)
+    return MCL_EINVAL;
+  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+  const int blocks = n_rows < 4096 ? n_rows : 4096;
+  const bool vec = (cols % 4 == 0) && (ld_rg % 4 == 0) && al16(p) && al16(m) && al16(v) && al16(row_grad);
+  if (vec)
+    hipLaunchKernelGGL((adam_table_kernel<true>), dim3(blocks), dim3(256), 0, mcl_stream(stream), p, m, v, n_rows,
+                       cols, row_slot, row_grad, (long long)ld_rg, c);
+  else
+    hipLaunchKernelGGL((adam_table_kernel<false>), dim3(blocks), dim3(256), 0, mcl_stream(stream), p, m, v, n_rows,
+                       cols, row_slot, row_grad, (long long)ld_rg, c);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

@@ -1,0 +1,227 @@
+// Strided batched fp32 GEMM on the gfx950 matrix cores with a fused epilogue.
+//   C = epi(alpha * A(MxK) * B(KxN));  see include/mclstexp_hip.h for the contract.
+//
+// MI355X mapping: 256-thread workgroup = 4 waves in a 2x2 arrangement over a BM x BN = 64 x 64
+// output tile; each wave owns a 32x32 block computed with v_mfma_f32_32x32x2_f32 (exact fp32
+// products and accumulation: bit-identical to an fmaf chain, which is what lets the path meet the
+// reference's fp32 numerics) or, in bf16 mode, v_mfma_f32_32x32x16_bf16 on operands rounded at
+// staging time.  K is walked in BK = 32 slices staged through LDS in [k][m] / [k][n] layout
+// (row stride 65 words: conflict-free both for the scalar transposing stores and for the
+// 32-lane MFMA operand reads); the next slice is prefetched into registers while the current one
+// is multiplied.  All four operand layouts are handled by two staging variants per operand
+// (contiguous along K, or along M/N), vectorised to 16-byte loads when base and leading dimension
+// allow and falling back to dword loads for the odd gene counts (785, 171, 685, 3467).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 65, NT = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmP {
+  int M, N, K;
+  const float* A; long long sAm, sAk, sAb;
+  const float* B; long long sBk, sBn, sBb;
+  float* C; long long ldc, sCb;
+  float alpha; int flags;
+  const float* bias;
+  const float* resid; long long ldr, sRb;
+  float* pre_out; long long ldp;
+  const float* aux; long long ldaux;
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// Stage one (rows x BK) operand slice into regs: the operand is addressed as X[r*sr + k*sk] with
+// r in [r0, r0+64) and k in [k0, k0+BK).  KC: contiguous along k (sk == 1) else along r (sr == 1).
+// Each thread carries 8 floats.  VEC: 16-byte loads allowed.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void load_slice(float (&reg)[8], const float* __restrict__ X, long long sr, long long sk,
+                                           int r0, int k0, int R, int K, int tid) {
+  if (KC) {
+    // 64 rows x 32 k: 8 float4 per row -> thread t: row = t/8 + 32*h, kq = (t%8)*4
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = r0 + (tid >> 3) + 32 * h;
+      const int k = k0 + (tid & 7) * 4;
+      const float* p = X + (long long)r * sr + k;
+      if (VEC && r < R && k + 3 < K) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        reg[h * 4 + 0] = v.x; reg[h * 4 + 1] = v.y; reg[h * 4 + 2] = v.z; reg[h * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[h * 4 + i] = (r < R && k + i < K) ? p[i] : 0.0f;
+      }
+    }
+  } else {
+    // contiguous along r: 32 k-rows x 64 r: 16 float4 per k -> thread t: k = t/16 + 16*h, rq = (t%16)*4
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + (tid >> 4) + 16 * h;
+      const int r = r0 + (tid & 15) * 4;
+      const float* p = X + (long long)k * sk + r;
+      if (VEC && k < K && r + 3 < R) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        reg[h * 4 + 0] = v.x; reg[h * 4 + 1] = v.y; reg[h * 4 + 2] = v.z; reg[h * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[h * 4 + i] = (k < K && r + i < R) ? p[i] : 0.0f;
+      }
+    }
+  }
+}
+
+// Write the staged registers into the LDS slice T[k][r] (row stride LDT words).
+template <bool KC>
+__device__ __forceinline__ void store_slice(const float (&reg)[8], float* __restrict__ T, int tid) {
+  if (KC) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = (tid >> 3) + 32 * h, k = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T[(k + i) * LDT + r] = reg[h * 4 + i];
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = (tid >> 4) + 16 * h, r = (tid & 15) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T[k * LDT + r + i] = reg[h * 4 + i];
+    }
+  }
+}
+
+template <bool AKC, bool BKC, bool VEC, bool BF16>
+__global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
+  __shared__ float As[BK * LDT];
+  __shared__ float Bs[BK * LDT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int bz = blockIdx.z;
+  const float* __restrict__ A = p.A + (long long)bz * p.sAb;
+  const float* __restrict__ B = p.B + (long long)bz * p.sBb;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+  float ra[8], rb[8];
+  const int nk = (p.K + BK - 1) / BK;
+  load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, 0, p.M, p.K, tid);
+  load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, 0, p.N, p.K, tid);
+
+  const int arow = wm * 32 + (lane & 31);
+  const int brow = wn * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    store_slice<AKC>(ra, As, tid);
+    store_slice<BKC>(rb, Bs, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, (kt + 1) * BK, p.M, p.K, tid);
+      load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, (kt + 1) * BK, p.N, p.K, tid);
+    }
+    if (!BF16) {
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 2) {
+        const float a = As[(ks + khalf) * LDT + arow];
+        const float b = Bs[(ks + khalf) * LDT + brow];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    } else {
+      // 32x32x16 bf16: lane l holds A[i = l&31][k = 8*(l>>5) .. +7] (8 consecutive k)
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 16) {
+        bf16x8 a, b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          a[i] = (short)f2bf(As[(ks + khalf * 8 + i) * LDT + arow]);
+          b[i] = (short)f2bf(Bs[(ks + khalf * 8 + i) * LDT + brow]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc[r] -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the wave's 32x32 block
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col >= p.N) return;
+  float* __restrict__ C = p.C + (long long)bz * p.sCb;
+  const float* __restrict__ R = p.resid ? p.resid + (long long)bz * p.sRb : nullptr;
+  const float bias = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row >= p.M) continue;
+    float v = p.alpha * acc[r] + bias;
+    if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
+    if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
+    if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
+    if (R) v += R[(long long)row * p.ldr + col];
+    if (p.flags & MCL_EPI_ACCUM) v += C[(long long)row * p.ldc + col];
+    C[(long long)row * p.ldc + col] = v;
+  }
+}
+
+template <bool AKC, bool BKC, bool VEC>
+void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch), block(NT);
+  if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true>), grid, block, 0, st, p);
+  else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false>), grid, block, 0, st, p);
+}
+
+template <bool AKC, bool BKC>
+void launch1(const GemmP& p, int batch, bool vec, bool bf16, hipStream_t st) {
+  if (vec) launch2<AKC, BKC, true>(p, batch, bf16, st);
+  else     launch2<AKC, BKC, false>(p, batch, bf16, st);
+}
+
+inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
+  if (!a || !a->A || !a->B || !a->C) return MCL_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return MCL_EINVAL;
+  const bool akc = (a->sAk == 1), amc = (a->sAm == 1);
+  const bool bkc = (a->sBk == 1), bnc = (a->sBn == 1);
+  if (!(akc || amc) || !(bkc || bnc)) return MCL_EINVAL;
+  if ((a->pre_out || (a->flags & MCL_EPI_GELU_BWD)) && a->batch != 1) return MCL_EINVAL;
+  if ((a->flags & MCL_EPI_GELU_BWD) && !a->aux) return MCL_EINVAL;
+  if (a->compute != MCL_COMPUTE_F32 && a->compute != MCL_COMPUTE_BF16) return MCL_EUNSUPPORTED;
+  if (a->batch > 65535) return MCL_EUNSUPPORTED;
+
+  GemmP p;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.A = a->A; p.sAm = a->sAm; p.sAk = a->sAk; p.sAb = a->sAb;
+  p.B = a->B; p.sBk = a->sBk; p.sBn = a->sBn; p.sBb = a->sBb;
+  p.C = a->C; p.ldc = a->ldc; p.sCb = a->sCb;
+  p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias;
+  p.resid = a->resid; p.ldr = a->ldr; p.sRb = a->sRb;
+  p.pre_out = a->pre_out; p.ldp = a->ldp; p.aux = a->aux; p.ldaux = a->ldaux;
+
+  // prefer the k-contiguous reading when a dimension of extent-1 stride is ambiguous
+  const bool AKC = akc, BKC = bkc;
+  const long long lda = AKC ? a->sAm : a->sAk, ldb = BKC ? a->sBn : a->sBk;
+  const bool vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                   (a->sAb % 4 == 0) && (a->sBb % 4 == 0);
+  hipStream_t st = mcl_stream(stream);
+  const bool bf16 = a->compute == MCL_COMPUTE_BF16;
+  if (AKC && BKC) launch1<true, true>(p, a->batch, vec, bf16, st);
+  else if (AKC && !BKC) launch1<true, false>(p, a->batch, vec, bf16, st);
+  else if (!AKC && BKC) launch1<false, true>(p, a->batch, vec, bf16, st);
+  else launch1<false, false>(p, a->batch, vec, bf16, st);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

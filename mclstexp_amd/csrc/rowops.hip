@@ -1,0 +1,189 @@
+// Row-wise HBM-bound kernels: LayerNorm fwd/bwd (K2), attention softmax fwd/bwd (part of K4),
+// column sums (bias gradients).  One 64-lane wave owns one row; reductions are wave shuffles
+// (no LDS, no barriers); a 256-thread workgroup processes 4 rows.  Column reductions run one
+// thread per column so that consecutive lanes read consecutive addresses of each row.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            long long ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int rows, int cols,
+                                                            float eps) {
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (long long)row * ldx;
+  float s = 0.0f;
+  for (int c = lane; c < cols; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.0f;
+  for (int c = lane; c < cols; c += 64) {
+    const float d = xr[c] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  float* yr = y + (long long)row * ldy;
+  for (int c = lane; c < cols; c += 64) yr[c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, long long lddy,
+                                                               const float* __restrict__ x, long long ldx,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* dx_add,
+                                                               long long ldadd, float* dx, long long lddx, int rows,
+                                                               int cols) {
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* dyr = dy + (long long)row * lddy;
+  const float* xr = x + (long long)row * ldx;
+  const float mu = mean[row], rs = rstd[row];
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int c = lane; c < cols; c += 64) {
+    const float g = dyr[c] * gamma[c];
+    s1 += g;
+    s2 += g * (xr[c] - mu) * rs;
+  }
+  s1 = wave_sum(s1) / (float)cols;
+  s2 = wave_sum(s2) / (float)cols;
+  float* dxr = dx + (long long)row * lddx;
+  const float* addr = dx_add ? dx_add + (long long)row * ldadd : nullptr;
+  for (int c = lane; c < cols; c += 64) {
+    const float xh = (xr[c] - mu) * rs;
+    const float v = rs * (dyr[c] * gamma[c] - s1 - xh * s2);
+    dxr[c] = addr ? addr[c] + v : v;
+  }
+}
+
+// dgamma[c] = sum_r dy[r,c]*xhat[r,c]; dbeta[c] = sum_r dy[r,c].  Block = 64 columns x 4 row-groups.
+__global__ __launch_bounds__(256) void layernorm_bwd_dgb_kernel(const float* __restrict__ dy, long long lddy,
+                                                                const float* __restrict__ x, long long ldx,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                int rows, int cols) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float ag = 0.0f, ab = 0.0f;
+  if (c < cols) {
+    for (int r = grp; r < rows; r += 4) {
+      const float d = dy[(long long)r * lddy + c];
+      ag += d * (x[(long long)r * ldx + c] - mean[r]) * rstd[r];
+      ab += d;
+    }
+  }
+  sg[grp][lane] = ag;
+  sb[grp][lane] = ab;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+    dgamma[c] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    dbeta[c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx,
+                                                     float* __restrict__ out, int rows, int cols) {
+  __shared__ float sm[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a = 0.0f;
+  if (c < cols)
+    for (int r = grp; r < rows; r += 4) a += x[(long long)r * ldx + c];
+  sm[grp][lane] = a;
+  __syncthreads();
+  if (grp == 0 && c < cols) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ s, long long ld, int n_rows,
+                                                               int cols, float scale) {
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  float* r = s + (long long)row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, r[c] * scale);
+  mx = wave_max(mx);
+  float sum = 0.0f;
+  for (int c = lane; c < cols; c += 64) {
+    const float e = expf(r[c] * scale - mx);
+    r[c] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / wave_sum(sum);
+  for (int c = lane; c < cols; c += 64) r[c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp,
+                                                               long long ld, int n_rows, int cols, float scale) {
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* pr = p + (long long)row * ld;
+  float* dr = dp + (long long)row * ld;
+  float dot = 0.0f;
+  for (int c = lane; c < cols; c += 64) dot += pr[c] * dr[c];
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64) dr[c] = scale * pr[c] * (dr[c] - dot);
+}
+
+}  // namespace
+
+extern "C" int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
+                                 int64_t ldy, float* mean, float* rstd, int32_t rows, int32_t cols, float eps,
+                                 mcl_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || cols <= 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0,
+                     mcl_stream(stream), x, ldx, gamma, beta, y, ldy, mean, rstd, rows, cols, eps);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, const float* dx_add, int64_t ldadd,
+                                 float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t rows, int32_t cols,
+                                 mcl_stream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || cols <= 0) return MCL_EINVAL;
+  hipStream_t st = mcl_stream(stream);
+  hipLaunchKernelGGL(layernorm_bwd_dgb_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd,
+                     dgamma, dbeta, rows, cols);
+  hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st, dy,
+                     lddy, x, ldx, gamma, mean, rstd, dx_add, ldadd, dx, lddx, rows, cols);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, mcl_stream_t stream) {
+  if (!x || !out || rows <= 0 || cols <= 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, mcl_stream(stream), x, ldx, out, rows, cols);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_softmax_rows_fwd(float* s, int64_t ld, int32_t n_rows, int32_t cols, float scale,
+                                    mcl_stream_t stream) {
+  if (!s || n_rows <= 0 || cols <= 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0,
+                     mcl_stream(stream), s, ld, n_rows, cols, scale);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int32_t n_rows, int32_t cols, float scale,
+                                    mcl_stream_t stream) {
+  if (!p || !dp || n_rows <= 0 || cols <= 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0,
+                     mcl_stream(stream), p, dp, ld, n_rows, cols, scale);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

@@ -1,0 +1,203 @@
+"""Data parallelism for the contrastive step: one process per GPU, torch.distributed over RCCL/xGMI
+(backend "nccl" on ROCm), gloo for CPU logic tests.
+
+New capability relative to the reference (single ``cuda:0``, train.py:107).  Rank r owns
+pairs [r*B_loc, (r+1)*B_loc).  Everything up to the (B_loc, P) embeddings is rank-local (so the spot
+encoder attends over the LOCAL spots and BatchNorm uses LOCAL statistics -- SURVEY R2); the loss is
+the reference's symmetric InfoNCE over the GLOBAL batch:
+
+  1. ONE all-gather of [E_spot | E_img] (B_loc x 2P per rank; 256 KiB at B_loc=128 fp32);
+  2. each rank forms its row strip  S_r = E_spot_loc E_img_all^T / T  (complete row LSEs) and its
+     column strip  S_c = E_spot_all E_img_loc^T / T  (complete column LSEs): no partial-LSE merge;
+  3. ONE all-gather of [row_lse | col_lse | diag] (3*B_loc floats) -> global loss on every rank and the
+     LSE vectors the closed-form gradient needs;
+  4. dE_spot_loc = dS_r E_img_all and dE_img_loc = dS_c^T E_spot_all are purely local: no reduce-scatter.
+
+xGMI is point-to-point and both collectives are latency-bound (KBs), so the design minimises their
+COUNT (two) rather than their bytes.  Parameter gradients are then summed (not averaged: dE already
+carries the 1/(2*B_glob) of the global mean) with one all-reduce over FusedAdam's flat gradient
+buffer; the two position tables exchange only the upstream gradient rows (B_glob x G) instead of a
+dense 2 x 65536 x G all-reduce.
+
+The collective plumbing is device-agnostic; the arithmetic goes through a small primitive set that
+defaults to the HIP kernels (``HipPrims``).  CPU tests inject oracle-backed primitives.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as td
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- process group
+def init_from_env() -> Tuple[Optional[td.ProcessGroup], int, int]:
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (group, rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world <= 1:
+        return None, 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not td.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        td.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return td.group.WORLD, rank, world
+
+
+def shutdown() -> None:
+    if td.is_available() and td.is_initialized():
+        td.destroy_process_group()
+
+
+def _all_gather_cat(x: Tensor, pg) -> Tensor:
+    """Concatenation over ranks along dim 0 (equal shapes on every rank)."""
+    x = x.contiguous()
+    world = td.get_world_size(pg)
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    td.all_gather_into_tensor(out, x, group=pg)
+    return out
+
+
+# --------------------------------------------------------------------------- arithmetic primitives
+class HipPrims:
+    """The gfx950 kernels (ops.py) behind the five primitives the DP InfoNCE needs."""
+
+    @staticmethod
+    def logits(a: Tensor, b: Tensor, inv_t: float) -> Tensor:
+        from . import ops
+        R, P = a.shape
+        Cn = b.shape[0]
+        S = torch.empty((R, Cn), device=a.device, dtype=torch.float32)
+        ops.gemm_raw(R, Cn, P, 1, a, a.stride(0), 1, 0, b, 1, b.stride(0), 0, S, Cn, 0, alpha=inv_t)
+        return S
+
+    @staticmethod
+    def row_lse(S: Tensor) -> Tensor:
+        from . import _lib, ops
+        out = torch.empty((S.shape[0],), device=S.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mcl_infonce_lse(S.data_ptr(), S.stride(0), S.shape[0], S.shape[1], out.data_ptr(), None,
+                                              ops._stream()), "mcl_infonce_lse")
+        return out
+
+    @staticmethod
+    def col_lse(S: Tensor) -> Tensor:
+        from . import _lib, ops
+        out = torch.empty((S.shape[1],), device=S.device, dtype=torch.float32)
+        _lib.check(_lib.lib().mcl_infonce_lse(S.data_ptr(), S.stride(0), S.shape[0], S.shape[1], None, out.data_ptr(),
+                                              ops._stream()), "mcl_infonce_lse")
+        return out
+
+    @staticmethod
+    def dlogits(S: Tensor, row_lse: Tensor, col_lse: Tensor, row0: int, col0: int, coef: float) -> Tensor:
+        from . import _lib, ops
+        dS = torch.empty_like(S)
+        _lib.check(_lib.lib().mcl_infonce_dlogits(S.data_ptr(), S.stride(0), row_lse.data_ptr(), col_lse.data_ptr(),
+                                                  S.shape[0], S.shape[1], row0, col0, coef, dS.data_ptr(),
+                                                  dS.stride(0), ops._stream()), "mcl_infonce_dlogits")
+        return dS
+
+    @staticmethod
+    def mm_nn(dS: Tensor, e: Tensor) -> Tensor:
+        from . import ops
+        R, Cn = dS.shape
+        P = e.shape[1]
+        out = torch.empty((R, P), device=dS.device, dtype=torch.float32)
+        ops.gemm_raw(R, P, Cn, 1, dS, dS.stride(0), 1, 0, e, e.stride(0), 1, 0, out, P, 0)
+        return out
+
+    @staticmethod
+    def mm_tn(dS: Tensor, e: Tensor) -> Tensor:
+        from . import ops
+        R, Cn = dS.shape
+        P = e.shape[1]
+        out = torch.empty((Cn, P), device=dS.device, dtype=torch.float32)
+        ops.gemm_raw(Cn, P, R, 1, dS, 1, dS.stride(0), 0, e, e.stride(0), 1, 0, out, P, 0)
+        return out
+
+
+def dist_infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipPrims
+                         ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """Global symmetric InfoNCE from per-rank embeddings.  Returns (loss [identical on every rank],
+    dE_spot_loc, dE_img_loc, S_row_strip)."""
+    world, rank = td.get_world_size(pg), td.get_rank(pg)
+    b_loc, P = e_spot.shape
+    b_glob = world * b_loc
+    row0 = rank * b_loc
+    all_e = _all_gather_cat(torch.cat([e_spot, e_img], dim=1), pg)          # collective 1: (B_glob, 2P)
+    es_all, ei_all = all_e[:, :P], all_e[:, P:]
+    inv_t = 1.0 / temperature
+    s_rows = prims.logits(e_spot.contiguous(), ei_all, inv_t)                # (B_loc, B_glob)
+    s_cols = prims.logits(es_all, e_img.contiguous(), inv_t)                 # (B_glob, B_loc)
+    rl = prims.row_lse(s_rows)
+    cl = prims.col_lse(s_cols)
+    idx = torch.arange(b_loc, device=e_spot.device)
+    diag = s_rows[idx, row0 + idx]
+    packed = _all_gather_cat(torch.stack([rl, cl, diag]).unsqueeze(0), pg)   # collective 2: (W, 3, B_loc)
+    rl_all = packed[:, 0].reshape(-1)
+    cl_all = packed[:, 1].reshape(-1)
+    diag_all = packed[:, 2].reshape(-1)
+    loss = ((rl_all - diag_all).sum() + (cl_all - diag_all).sum()) / (2.0 * b_glob)
+    coef = 1.0 / (2.0 * b_glob * temperature)
+    ds_rows = prims.dlogits(s_rows, rl, cl_all, row0, 0, coef)
+    ds_cols = prims.dlogits(s_cols, rl_all, cl, 0, row0, coef)
+    d_es = prims.mm_nn(ds_rows, ei_all)
+    d_ei = prims.mm_tn(ds_cols, es_all)
+    return loss, d_es, d_ei, s_rows
+
+
+class DistInfoNCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e_spot, e_img, temperature, pg, stash):
+        loss, d_es, d_ei, s_rows = dist_infonce_fwd_bwd(e_spot, e_img, temperature, pg)
+        if stash is not None:
+            stash["logits"] = s_rows
+        ctx.save_for_backward(d_es, d_ei)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        d_es, d_ei = ctx.saved_tensors
+        return d_es * gl, d_ei * gl, None, None, None
+
+
+# --------------------------------------------------------------------------- gradient exchange
+def gather_rows(dout: Tensor, ix: Tensor, iy: Tensor, pg) -> Tuple[Tensor, Tensor, Tensor]:
+    """Sparse exchange for the two position tables: both share one upstream gradient (B_loc, G), so a
+    single all-gather of it (+ the two index vectors) replaces a dense 2 x (65536, G) all-reduce
+    (4 MB vs 524 MB at B_glob=1024, G=1000).  Every rank then reduces the identical global rows."""
+    g_dout = _all_gather_cat(dout, pg)
+    g_idx = _all_gather_cat(torch.stack([ix, iy], dim=1), pg)
+    return g_dout, g_idx[:, 0].contiguous(), g_idx[:, 1].contiguous()
+
+
+class GradReducer:
+    """Sum parameter gradients over ranks: one all-reduce per flat FusedAdam bucket (the gradients
+    already live contiguously there), plus stragglers that are not in a flat bucket."""
+
+    def __init__(self, pg):
+        self.pg = pg
+
+    def reduce(self, optimizer) -> None:
+        if hasattr(optimizer, "ensure_flat"):
+            optimizer.ensure_flat()
+        flat_ids = set()
+        if hasattr(optimizer, "flat_grads"):
+            for g in optimizer.flat_grads():
+                td.all_reduce(g, op=td.ReduceOp.SUM, group=self.pg)
+            flat_ids = optimizer.flat_param_ids()
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                if id(p) in flat_ids or p.grad is None:
+                    continue
+                td.all_reduce(p.grad, op=td.ReduceOp.SUM, group=self.pg)

@@ -1,0 +1,301 @@
+"""Drop-in model classes for mclSTExp's contrastive hot path (mirrors /root/reference/model.py).
+
+Same class names, constructor signatures, attribute names and ``state_dict`` keys as the reference,
+so ``train.py``-style loops and the ``evel_*.py`` sub-module calls (evel_her2st.py:48-69) work
+unchanged; underneath, every operation outside the image backbone is a hand-written gfx950 kernel
+reached through the C ABI (``ops.py``).  Inputs must live on the GPU -- there is no CPU path.
+
+Differences from the reference, all deliberate:
+  * an unknown ``encoder_name`` raises (the reference silently builds a model without
+    ``image_encoder``, model.py:206-215); ``"identity"`` is an extension meaning ``batch["image"]``
+    already holds (B, image_dim) features;
+  * ``torch.eye(B).cuda()`` (model.py:243) is never built: the closed-form InfoNCE kernel uses the
+    diagonal directly;
+  * keyword-only extras: ``compute`` ("f32" exact / "bf16" MFMA), ``backbone_dtype`` (autocast dtype
+    for the delegated backbone), ``embedding_grad`` ("dense" = stock-optimizer compatible,
+    "rowsparse" = hand the 2 x (65536, G) tables' gradients to FusedAdam as touched rows only),
+    ``process_group`` (data-parallel global InfoNCE).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import backbones, ops
+from .backbones import (ENCODERS, ImageEncdoer_res18, ImageEncdoer_res101, ImageEncoder,  # noqa: F401
+                        ImageEncoder_Resnet, ImageEncoder_VIT)
+
+Tensor = torch.Tensor
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) [gelu] through mcl_gemm, with hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gelu):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y, pre = ops.linear_fwd(x2, W, b, gelu=gelu, save_pre=gelu)
+        ctx.save_for_backward(x2, W, pre if gelu else None)
+        ctx.has_bias, ctx.shp = b is not None, shp
+        return y.view(*shp[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, pre = ctx.saved_tensors
+        dy2 = dy.reshape(-1, W.shape[0])
+        if pre is not None:
+            dy2 = dy2 * _gelu_grad(pre)
+        dW = ops.linear_bwd_weight(dy2, x2)
+        db = ops.colsum(dy2) if ctx.has_bias else None
+        dx = ops.linear_bwd_data(dy2, W).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        return dx, dW, db, None
+
+
+def _gelu_grad(x: Tensor) -> Tensor:
+    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads, dim_head):
+        out, P = ops.attention_core_fwd(qkv, heads, dim_head)
+        ctx.save_for_backward(qkv, P)
+        ctx.hd = (heads, dim_head)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, P = ctx.saved_tensors
+        return ops.attention_core_bwd(dout, qkv, P, *ctx.hd), None, None
+
+
+def _linear(m: nn.Linear, x: Tensor, gelu: bool = False) -> Tensor:
+    return _LinearFn.apply(x, m.weight, m.bias, gelu)
+
+
+def _layer_norm(m: nn.LayerNorm, x: Tensor) -> Tensor:
+    return ops.LayerNormFn.apply(x, m.weight, m.bias, m.eps)
+
+
+class PreNorm(nn.Module):
+    """model.py:10-17."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        return self.fn(_layer_norm(self.norm, x), **kwargs)
+
+
+class FeedForward(nn.Module):
+    """model.py:20-32."""
+
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+    def forward(self, x):
+        h = self.net[2](_linear(self.net[0], x, gelu=True))
+        return self.net[4](_linear(self.net[3], h))
+
+
+class Attention(nn.Module):
+    """model.py:35-57 (batch-as-sequence: x is (1, B, G) or (B, G))."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        project_out = not (heads == 1 and dim_head == dim)
+        self.heads = heads
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.attend = nn.Softmax(dim=-1)
+        self.to_qkv = nn.Linear(dim, inner_dim * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
+
+    def forward(self, x):
+        shp = x.shape
+        if x.dim() == 3 and shp[0] != 1:
+            return torch.cat([self.forward(xi.unsqueeze(0)) for xi in x], 0)
+        x2 = x.reshape(-1, shp[-1])
+        qkv = _linear(self.to_qkv, x2)
+        out = _AttnCoreFn.apply(qkv, self.heads, self.dim_head)
+        if isinstance(self.to_out, nn.Identity):
+            return out.view(*shp[:-1], -1)
+        out = self.to_out[1](_linear(self.to_out[0], out))
+        return out.view(*shp[:-1], -1)
+
+
+class attn_block(nn.Module):
+    """model.py:60-69.  ``forward`` runs the whole layer as one hand-scheduled forward/backward
+    (ops.AttnBlockFn) when its dropouts are inactive -- which is always the case in the reference
+    (model.py:217 hard-codes dropout=0.)."""
+
+    def __init__(self, dim, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.attn = PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout))
+        self.ff = PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))
+        self._p = dropout
+
+    def forward(self, x):
+        a, f = self.attn.fn, self.ff.fn
+        fused_ok = (not (self.training and self._p > 0)) and not isinstance(a.to_out, nn.Identity)
+        if not fused_ok:
+            x = self.attn(x) + x
+            return self.ff(x) + x
+        shp = x.shape
+        if x.dim() == 3 and shp[0] != 1:
+            return torch.cat([self.forward(xi.unsqueeze(0)) for xi in x], 0)
+        y = ops.AttnBlockFn.apply(x.reshape(-1, shp[-1]), self.attn.norm.weight, self.attn.norm.bias,
+                                  a.to_qkv.weight, a.to_out[0].weight, a.to_out[0].bias,
+                                  self.ff.norm.weight, self.ff.norm.bias,
+                                  f.net[0].weight, f.net[0].bias, f.net[3].weight, f.net[3].bias,
+                                  a.heads, a.dim_head)
+        return y.view(shp)
+
+
+class ProjectionHead(nn.Module):
+    """model.py:151-168."""
+
+    def __init__(self, embedding_dim, projection_dim, dropout=0.):
+        super().__init__()
+        self.projection = nn.Linear(embedding_dim, projection_dim)
+        self.gelu = nn.GELU()
+        self.fc = nn.Linear(projection_dim, projection_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(projection_dim)
+
+    def forward(self, x):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if self.training and self.dropout.p > 0:
+            projected = _linear(self.projection, x2)
+            y = self.dropout(_linear(self.fc, ops_gelu(projected))) + projected
+            y = _layer_norm(self.layer_norm, y)
+        else:
+            y = ops.ProjectionHeadFn.apply(x2, self.projection.weight, self.projection.bias, self.fc.weight,
+                                           self.fc.bias, self.layer_norm.weight, self.layer_norm.bias)
+        return y.view(*shp[:-1], -1)
+
+
+def ops_gelu(x: Tensor) -> Tensor:
+    return F.gelu(x)  # only on the dropout>0 path, which the reference never takes
+
+
+class _ContrastiveBase(nn.Module):
+    """Shared forward tail of mclSTExp_Attention / mclSTExp_MLP (model.py:187-198, 225-247)."""
+
+    def _init_common(self, temperature, compute, backbone_dtype, embedding_grad, process_group):
+        self.temperature = temperature
+        if embedding_grad not in ("dense", "rowsparse"):
+            raise ValueError("embedding_grad must be 'dense' or 'rowsparse'")
+        self.compute = compute
+        self.backbone_dtype = backbone_dtype
+        self.embedding_grad = embedding_grad
+        self.process_group = process_group
+        self.capture = False
+        self.last: Dict[str, Tensor] = {}
+        self.sparse_grads: Dict[str, ops.RowSparseGrad] = {}
+
+    def _encode_image(self, encoder: nn.Module, image: Tensor) -> Tensor:
+        if isinstance(encoder, nn.Identity):
+            return image
+        if self.backbone_dtype is not None and self.backbone_dtype != torch.float32:
+            if image.dim() == 4:
+                image = image.contiguous(memory_format=torch.channels_last)
+            with torch.autocast("cuda", dtype=self.backbone_dtype):
+                feats = encoder(image)
+            return feats.float()
+        return encoder(image)
+
+    def _spot_features(self, batch) -> Tensor:
+        sink = self.sparse_grads if (self.embedding_grad == "rowsparse" and torch.is_grad_enabled()) else None
+        return ops.PosEmbedAddFn.apply(batch["expression"], batch["position"], self.x_embed.weight,
+                                       self.y_embed.weight, sink)
+
+    def _loss(self, spot_embeddings: Tensor, image_embeddings: Tensor) -> Tensor:
+        stash = self.last if self.capture else None
+        if self.capture:
+            self.last["spot_embeddings"] = spot_embeddings.detach()
+            self.last["image_embeddings"] = image_embeddings.detach()
+        if self.process_group is not None:
+            from . import dist as mdist
+            return mdist.DistInfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature),
+                                             self.process_group, stash)
+        return ops.InfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature), stash)
+
+
+class mclSTExp_MLP(_ContrastiveBase):
+    """model.py:171-198 (ablation without the spot encoder; attribute name ``image_ecode`` kept)."""
+
+    def __init__(self, temperature, image_embedding, spot_embedding, projection_dim, dropout=0., *,
+                 encoder_name="densenet121", compute="f32", backbone_dtype=None, embedding_grad="dense",
+                 process_group=None):
+        super().__init__()
+        self.x_embed = nn.Embedding(65536, spot_embedding)
+        self.y_embed = nn.Embedding(65536, spot_embedding)
+        self.image_ecode = _make_encoder(encoder_name)
+        self.image_projection = ProjectionHead(embedding_dim=image_embedding, projection_dim=projection_dim)
+        self.spot_projection = ProjectionHead(embedding_dim=spot_embedding, projection_dim=projection_dim)
+        self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group)
+
+    def forward(self, batch):
+        ops.set_compute(self.compute)
+        image_features = self._encode_image(self.image_ecode, batch["image"])
+        image_embeddings = self.image_projection(image_features)
+        spot_embeddings = self.spot_projection(self._spot_features(batch))
+        return self._loss(spot_embeddings, image_embeddings)
+
+
+class mclSTExp_Attention(_ContrastiveBase):
+    """model.py:201-247."""
+
+    def __init__(self, encoder_name, temperature, image_dim, spot_dim, projection_dim, heads_num, heads_dim,
+                 head_layers, dropout=0., *, compute="f32", backbone_dtype=None, embedding_grad="dense",
+                 process_group=None):
+        super().__init__()
+        self.x_embed = nn.Embedding(65536, spot_dim)
+        self.y_embed = nn.Embedding(65536, spot_dim)
+        self.image_encoder = _make_encoder(encoder_name)
+        # model.py:216-218: mlp_dim = spot_dim, dropout hard-coded to 0.
+        self.spot_encoder = nn.Sequential(
+            *[attn_block(spot_dim, heads=heads_num, dim_head=heads_dim, mlp_dim=spot_dim, dropout=0.)
+              for _ in range(head_layers)])
+        self.image_projection = ProjectionHead(embedding_dim=image_dim, projection_dim=projection_dim)
+        self.spot_projection = ProjectionHead(embedding_dim=spot_dim, projection_dim=projection_dim)
+        self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group)
+
+    def forward(self, batch):
+        ops.set_compute(self.compute)
+        image_features = self._encode_image(self.image_encoder, batch["image"])
+        image_embeddings = self.image_projection(image_features)
+        spot_features = self._spot_features(batch).unsqueeze(dim=0)        # (1, B, G): batch is the sequence
+        spot_embeddings = self.spot_encoder(spot_features)
+        spot_embeddings = self.spot_projection(spot_embeddings).squeeze(dim=0)
+        return self._loss(spot_embeddings, image_embeddings)
+
+
+def _make_encoder(encoder_name: str) -> nn.Module:
+    if encoder_name == "identity":
+        return nn.Identity()
+    if encoder_name not in ENCODERS:
+        raise ValueError(f"unknown encoder_name '{encoder_name}' (reference accepts {sorted(ENCODERS)}; "
+                         "'identity' = precomputed features)")
+    return ENCODERS[encoder_name]()
+
+
+def load_reference_state_dict(model: nn.Module, state: Dict[str, Tensor], strict: bool = True):
+    """Checkpoint loader with the reference's key rewrites (evel_her2st.py:33-37): strips a DataParallel
+    'module.' prefix and renames 'well' -> 'spot'."""
+    new = {}
+    for k, v in state.items():
+        k = k.replace("module.", "").replace("well", "spot")
+        new[k] = v
+    return model.load_state_dict(new, strict=strict)

@@ -1,0 +1,407 @@
+"""Host-side launch wrappers and hand-derived autograd for the HIP kernels (C ABI via ctypes).
+
+Every function here takes fp32 tensors resident on the GPU and enqueues kernels on torch's current
+stream.  CPU tensors are rejected: there is no fallback path.  The backward passes are written out
+kernel by kernel (the reference obtains them from autograd, train.py:38).
+
+Reference call sites are cited per function (paths relative to /root/reference/).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (COMPUTE_BF16, COMPUTE_F32, EPI_ACCUM, EPI_GELU, EPI_GELU_BWD, GemmArgs, check)
+
+Tensor = torch.Tensor
+LN_EPS = 1e-5
+
+_compute_mode = COMPUTE_F32
+
+
+def set_compute(mode: str) -> None:
+    """'f32' (exact fp32 MFMA, reference numerics) or 'bf16' (bf16 MFMA operands, fp32 accumulate)."""
+    global _compute_mode
+    _compute_mode = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16}[mode]
+
+
+def get_compute() -> str:
+    return "bf16" if _compute_mode == COMPUTE_BF16 else "f32"
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: Tensor, name: str = "tensor") -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"mclstexp_amd: {name} is on {t.device}; the hot path runs only on the GPU "
+                           "(HIP kernels, no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"mclstexp_amd: {name} must be float32, got {t.dtype}")
+    return t
+
+
+def _rowmajor(t: Tensor, name: str = "tensor") -> Tensor:
+    """2-D view with unit stride along the last dim (makes a copy only if needed)."""
+    _chk(t, name)
+    if t.dim() != 2:
+        raise RuntimeError(f"{name}: expected 2-D, got shape {tuple(t.shape)}")
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        t = t.contiguous()
+    if t.shape[1] == 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, sAb: int, B: Tensor, sBk: int,
+             sBn: int, sBb: int, Cmat: Tensor, ldc: int, sCb: int, alpha: float = 1.0, flags: int = 0,
+             bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0, sRb: int = 0,
+             pre_out: Optional[Tensor] = None, ldp: int = 0, aux: Optional[Tensor] = None, ldaux: int = 0,
+             a_off: int = 0, b_off: int = 0, c_off: int = 0, compute: Optional[int] = None) -> None:
+    """mcl_gemm with explicit strides; *_off are element offsets into A/B/C's storage views."""
+    a = GemmArgs()
+    a.M, a.N, a.K, a.batch = M, N, K, batch
+    a.A, a.sAm, a.sAk, a.sAb = A.data_ptr() + 4 * a_off, sAm, sAk, sAb
+    a.B, a.sBk, a.sBn, a.sBb = B.data_ptr() + 4 * b_off, sBk, sBn, sBb
+    a.C, a.ldc, a.sCb = Cmat.data_ptr() + 4 * c_off, ldc, sCb
+    a.alpha, a.flags = alpha, flags
+    a.bias = _p(bias)
+    a.resid, a.ldr, a.sRb = _p(resid), ldr, sRb
+    a.pre_out, a.ldp = _p(pre_out), ldp
+    a.aux, a.ldaux = _p(aux), ldaux
+    a.compute = _compute_mode if compute is None else compute
+    check(_lib.lib().mcl_gemm(C.byref(a), _stream()), "mcl_gemm")
+
+
+def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor] = None, gelu: bool = False,
+               resid: Optional[Tensor] = None, save_pre: bool = False, alpha: float = 1.0
+               ) -> Tuple[Tensor, Optional[Tensor]]:
+    """y = epi(alpha * x W^T + b): nn.Linear forward (model.py:23,27,43,45,155,157) with the fused epilogue."""
+    x, W = _rowmajor(x, "x"), _rowmajor(W, "W")
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K, (x.shape, W.shape)
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    pre = torch.empty((M, N), device=x.device, dtype=torch.float32) if save_pre else None
+    if resid is not None:
+        resid = _rowmajor(resid, "resid")
+    gemm_raw(M, N, K, 1, x, x.stride(0), 1, 0, W, 1, W.stride(0), 0, y, N, 0, alpha, EPI_GELU if gelu else 0,
+             bias, resid, resid.stride(0) if resid is not None else 0, 0, pre, N)
+    return y, pre
+
+
+def linear_bwd_data(dy: Tensor, W: Tensor, gelu_bwd_aux: Optional[Tensor] = None,
+                    resid: Optional[Tensor] = None) -> Tensor:
+    """dx = (dy W) [* gelu'(aux)] [+ resid]."""
+    dy, W = _rowmajor(dy, "dy"), _rowmajor(W, "W")
+    M, N = dy.shape
+    K = W.shape[1]
+    assert W.shape[0] == N
+    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    flags = EPI_GELU_BWD if gelu_bwd_aux is not None else 0
+    if resid is not None:
+        resid = _rowmajor(resid, "resid")
+    gemm_raw(M, K, N, 1, dy, dy.stride(0), 1, 0, W, W.stride(0), 1, 0, dx, K, 0, 1.0, flags, None, resid,
+             resid.stride(0) if resid is not None else 0, 0, None, 0, gelu_bwd_aux,
+             gelu_bwd_aux.stride(0) if gelu_bwd_aux is not None else 0)
+    return dx
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor) -> Tensor:
+    """dW = dy^T x  (N, K)."""
+    dy, x = _rowmajor(dy, "dy"), _rowmajor(x, "x")
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M
+    dW = torch.empty((N, K), device=dy.device, dtype=torch.float32)
+    gemm_raw(N, K, M, 1, dy, 1, dy.stride(0), 0, x, x.stride(0), 1, 0, dW, K, 0)
+    return dW
+
+
+def colsum(x: Tensor) -> Tensor:
+    x = _rowmajor(x, "x")
+    out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+    check(_lib.lib().mcl_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], _stream()),
+          "mcl_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = LN_EPS) -> Tuple[Tensor, Tensor, Tensor]:
+    x = _rowmajor(x, "x")
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), device=x.device, dtype=torch.float32)
+    mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    check(_lib.lib().mcl_layernorm_fwd(x.data_ptr(), x.stride(0), _chk(gamma).data_ptr(), _chk(beta).data_ptr(),
+                                       y.data_ptr(), cols, mean.data_ptr(), rstd.data_ptr(), rows, cols, eps,
+                                       _stream()), "mcl_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
+                  dx_add: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    dy, x = _rowmajor(dy, "dy"), _rowmajor(x, "x")
+    rows, cols = x.shape
+    dx = torch.empty((rows, cols), device=x.device, dtype=torch.float32)
+    dg = torch.empty((cols,), device=x.device, dtype=torch.float32)
+    db = torch.empty((cols,), device=x.device, dtype=torch.float32)
+    if dx_add is not None:
+        dx_add = _rowmajor(dx_add, "dx_add")
+    check(_lib.lib().mcl_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
+                                       mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+                                       dx_add.stride(0) if dx_add is not None else 0, dx.data_ptr(), cols,
+                                       dg.data_ptr(), db.data_ptr(), rows, cols, _stream()), "mcl_layernorm_bwd")
+    return dx, dg, db
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim (model.py:13,158)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y, mean, rstd = layernorm_fwd(x2, gamma, beta, eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd(dy.reshape(x2.shape), x2, gamma, mean, rstd)
+        return dx.view(ctx.shp), dg, db, None
+
+
+# --------------------------------------------------------------------------- attention core (v1: materialised P)
+def attention_core_fwd(qkv: Tensor, heads: int, dim_head: int) -> Tuple[Tensor, Tensor]:
+    """model.py:52-56 on the (B, 3*h*d) to_qkv output: returns (out (B, h*d), P (h, B, B))."""
+    B = qkv.shape[0]
+    inner = heads * dim_head
+    ld = qkv.stride(0)
+    P = torch.empty((heads, B, B), device=qkv.device, dtype=torch.float32)
+    # scores_h = q_h k_h^T
+    gemm_raw(B, B, dim_head, heads, qkv, ld, 1, dim_head, qkv, 1, ld, dim_head, P, B, B * B, b_off=inner)
+    check(_lib.lib().mcl_softmax_rows_fwd(P.data_ptr(), B, heads * B, B, dim_head ** -0.5, _stream()),
+          "mcl_softmax_rows_fwd")
+    out = torch.empty((B, inner), device=qkv.device, dtype=torch.float32)
+    # out_h = P_h v_h
+    gemm_raw(B, dim_head, B, heads, P, B, 1, B * B, qkv, ld, 1, dim_head, out, inner, dim_head, b_off=2 * inner)
+    return out, P
+
+
+def attention_core_bwd(dout: Tensor, qkv: Tensor, P: Tensor, heads: int, dim_head: int) -> Tensor:
+    """Returns dqkv (B, 3*h*d)."""
+    B = qkv.shape[0]
+    inner = heads * dim_head
+    ld = qkv.stride(0)
+    dout = _rowmajor(dout, "dout")
+    ldo = dout.stride(0)
+    dqkv = torch.empty((B, 3 * inner), device=qkv.device, dtype=torch.float32)
+    ldq = 3 * inner
+    # dV_h = P_h^T dO_h
+    gemm_raw(B, dim_head, B, heads, P, 1, B, B * B, dout, ldo, 1, dim_head, dqkv, ldq, dim_head, c_off=2 * inner)
+    # dP_h = dO_h v_h^T
+    dP = torch.empty_like(P)
+    gemm_raw(B, B, dim_head, heads, dout, ldo, 1, dim_head, qkv, 1, ld, dim_head, dP, B, B * B, b_off=2 * inner)
+    check(_lib.lib().mcl_softmax_rows_bwd(P.data_ptr(), dP.data_ptr(), B, heads * B, B, dim_head ** -0.5, _stream()),
+          "mcl_softmax_rows_bwd")
+    # dq_h = dS_h k_h ; dk_h = dS_h^T q_h
+    gemm_raw(B, dim_head, B, heads, dP, B, 1, B * B, qkv, ld, 1, dim_head, dqkv, ldq, dim_head, b_off=inner)
+    gemm_raw(B, dim_head, B, heads, dP, 1, B, B * B, qkv, ld, 1, dim_head, dqkv, ldq, dim_head, c_off=inner)
+    return dqkv
+
+
+# --------------------------------------------------------------------------- attn_block (model.py:60-69)
+class AttnBlockFn(torch.autograd.Function):
+    """One spot-Transformer layer over the batch-as-sequence:
+        x1 = to_out(attn(LN1(x))) + x ;  x2 = W2 gelu(W1 LN2(x1) + b1) + b2 + x1
+    model.py:66-69 (PreNorm 17, Attention 49-57, FeedForward 31-32; both dropouts p=0)."""
+
+    @staticmethod
+    def forward(ctx, x, g1, be1, wqkv, wo, bo, g2, be2, w1, b1, w2, b2, heads, dim_head):
+        x = _rowmajor(x, "x")
+        u1, mean1, rstd1 = layernorm_fwd(x, g1, be1)
+        qkv, _ = linear_fwd(u1, wqkv)
+        o, P = attention_core_fwd(qkv, heads, dim_head)
+        x1, _ = linear_fwd(o, wo, bo, resid=x)
+        u2, mean2, rstd2 = layernorm_fwd(x1, g2, be2)
+        h, pre = linear_fwd(u2, w1, b1, gelu=True, save_pre=True)
+        x2, _ = linear_fwd(h, w2, b2, resid=x1)
+        ctx.save_for_backward(x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h)
+        ctx.heads, ctx.dim_head = heads, dim_head
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h) = ctx.saved_tensors
+        dx2 = _rowmajor(dx2, "dx2")
+        # ff: x2 = h W2^T + b2 + x1
+        dw2 = linear_bwd_weight(dx2, h)
+        db2 = colsum(dx2)
+        dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
+        dw1 = linear_bwd_weight(dpre, u2)
+        db1 = colsum(dpre)
+        du2 = linear_bwd_data(dpre, w1)
+        dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2)
+        # attn: x1 = o Wo^T + bo + x
+        dwo = linear_bwd_weight(dx1, o)
+        dbo = colsum(dx1)
+        do = linear_bwd_data(dx1, wo)
+        dqkv = attention_core_bwd(do, qkv, P, ctx.heads, ctx.dim_head)
+        dwqkv = linear_bwd_weight(dqkv, u1)
+        du1 = linear_bwd_data(dqkv, wqkv)
+        dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1)
+        return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None
+
+
+# --------------------------------------------------------------------------- ProjectionHead (model.py:151-168)
+class ProjectionHeadFn(torch.autograd.Function):
+    """p = x Wp^T + bp ; E = LN(gelu(p) Wf^T + bf + p)   (dropout p=0, model.py:164)."""
+
+    @staticmethod
+    def forward(ctx, x, wp, bp, wf, bf, g, be):
+        x = _rowmajor(x, "x")
+        a, p = linear_fwd(x, wp, bp, gelu=True, save_pre=True)
+        z, _ = linear_fwd(a, wf, bf, resid=p)
+        e, mean, rstd = layernorm_fwd(z, g, be)
+        ctx.save_for_backward(x, wp, wf, g, p, a, z, mean, rstd)
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        x, wp, wf, g, p, a, z, mean, rstd = ctx.saved_tensors
+        dz, dg, dbe = layernorm_bwd(_rowmajor(de, "de"), z, g, mean, rstd)
+        dwf = linear_bwd_weight(dz, a)
+        dbf = colsum(dz)
+        dp = linear_bwd_data(dz, wf, gelu_bwd_aux=p, resid=dz)
+        dwp = linear_bwd_weight(dp, x)
+        dbp = colsum(dp)
+        dx = linear_bwd_data(dp, wp) if ctx.needs_input_grad[0] else None
+        return dx, dwp, dbp, dwf, dbf, dg, dbe
+
+
+# --------------------------------------------------------------------------- position embedding (model.py:230-235)
+class RowSparseGrad:
+    """Row-sparse gradient of an embedding table: ``rows[b]`` (B, G) is the summed gradient of table row
+    ``owner_idx[b]`` where owner_idx[b] >= 0 (each touched table row appears exactly once)."""
+    __slots__ = ("owner_idx", "rows")
+
+    def __init__(self, owner_idx: Tensor, rows: Tensor):
+        self.owner_idx, self.rows = owner_idx, rows
+
+    def to_dense(self, n_rows: int) -> Tensor:
+        G = self.rows.shape[1]
+        dense = torch.zeros((n_rows, G), device=self.rows.device, dtype=torch.float32)
+        check(_lib.lib().mcl_embed_scatter_rows(self.owner_idx.data_ptr(), self.rows.data_ptr(), self.rows.stride(0),
+                                                dense.data_ptr(), G, self.rows.shape[0], G, 0, _stream()),
+              "mcl_embed_scatter_rows")
+        return dense
+
+
+def embed_rowgrad(d_out: Tensor, idx: Tensor) -> RowSparseGrad:
+    d_out = _rowmajor(d_out, "d_out")
+    B, G = d_out.shape
+    owner = torch.empty((B,), device=d_out.device, dtype=torch.int32)
+    rows = torch.empty((B, G), device=d_out.device, dtype=torch.float32)
+    check(_lib.lib().mcl_embed_rowgrad(d_out.data_ptr(), d_out.stride(0), idx.data_ptr(), owner.data_ptr(),
+                                       rows.data_ptr(), G, B, G, _stream()), "mcl_embed_rowgrad")
+    return RowSparseGrad(owner, rows)
+
+
+class PosEmbedAddFn(torch.autograd.Function):
+    """out = expr + x_table[pos[:,0].long()] + y_table[pos[:,1].long()].
+
+    Backward never builds the reference's dense (65536, G) gradients unless asked: with
+    ``sparse_sink`` (a dict) the upstream gradient and the two index vectors are handed over as
+    ``sink['dout'|'ix'|'iy']`` for the fused table optimizer (which reduces them to touched rows) and
+    the tables receive no ``.grad``; without it dense gradients are returned (stock-optimizer
+    compatible)."""
+
+    @staticmethod
+    def forward(ctx, expr, pos, x_table, y_table, sparse_sink):
+        expr = _rowmajor(expr, "expression")
+        B, G = expr.shape
+        pos = _chk(pos, "position").contiguous()
+        if pos.shape != (B, 2):
+            raise RuntimeError(f"position must be ({B}, 2), got {tuple(pos.shape)}")
+        xt, yt = _chk(x_table, "x_embed.weight"), _chk(y_table, "y_embed.weight")
+        assert xt.is_contiguous() and yt.is_contiguous() and xt.shape == yt.shape and xt.shape[1] == G
+        out = torch.empty((B, G), device=expr.device, dtype=torch.float32)
+        ix = torch.empty((B,), device=expr.device, dtype=torch.int32)
+        iy = torch.empty((B,), device=expr.device, dtype=torch.int32)
+        check(_lib.lib().mcl_pos_embed_add_fwd(expr.data_ptr(), expr.stride(0), pos.data_ptr(), xt.data_ptr(),
+                                               yt.data_ptr(), G, xt.shape[0], out.data_ptr(), G, ix.data_ptr(),
+                                               iy.data_ptr(), None, B, G, _stream()), "mcl_pos_embed_add_fwd")
+        ctx.save_for_backward(ix, iy)
+        ctx.n_rows = xt.shape[0]
+        ctx.sink = sparse_sink
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ix, iy = ctx.saved_tensors
+        d_expr = dout if ctx.needs_input_grad[0] else None
+        if ctx.sink is not None:
+            # both tables share the same upstream gradient; the optimizer (or its data-parallel
+            # exchange) reduces it to touched rows
+            ctx.sink["dout"], ctx.sink["ix"], ctx.sink["iy"] = _rowmajor(dout, "dout"), ix, iy
+            return d_expr, None, None, None, None
+        gx = embed_rowgrad(dout, ix)
+        gy = embed_rowgrad(dout, iy)
+        return d_expr, None, gx.to_dense(ctx.n_rows), gy.to_dense(ctx.n_rows), None
+
+
+# --------------------------------------------------------------------------- InfoNCE (model.py:242-247)
+def infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, want_logits: bool = True
+                    ) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """Single-device symmetric InfoNCE: returns (loss 0-d, dE_spot, dE_img, logits)."""
+    es, ei = _rowmajor(e_spot, "spot_embeddings"), _rowmajor(e_img, "image_embeddings")
+    B, P = es.shape
+    assert ei.shape == (B, P)
+    dev = es.device
+    L = _lib.lib()
+    S = torch.empty((B, B), device=dev, dtype=torch.float32)
+    gemm_raw(B, B, P, 1, es, es.stride(0), 1, 0, ei, 1, ei.stride(0), 0, S, B, 0, alpha=1.0 / temperature)
+    lse = torch.empty((2, B), device=dev, dtype=torch.float32)
+    check(L.mcl_infonce_lse(S.data_ptr(), B, B, B, lse[0].data_ptr(), lse[1].data_ptr(), _stream()), "mcl_infonce_lse")
+    sums = torch.zeros((2,), device=dev, dtype=torch.float32)
+    check(L.mcl_infonce_loss(S.data_ptr(), B, lse[0].data_ptr(), lse[1].data_ptr(), 0, 0, B, 1, 1, sums.data_ptr(),
+                             _stream()), "mcl_infonce_loss")
+    loss = (sums[0] + sums[1]) / (2.0 * B)
+    dS = torch.empty_like(S)
+    check(L.mcl_infonce_dlogits(S.data_ptr(), B, lse[0].data_ptr(), lse[1].data_ptr(), B, B, 0, 0,
+                                1.0 / (2.0 * B * temperature), dS.data_ptr(), B, _stream()), "mcl_infonce_dlogits")
+    d_es = torch.empty_like(es)
+    d_ei = torch.empty_like(ei)
+    gemm_raw(B, P, B, 1, dS, B, 1, 0, ei, ei.stride(0), 1, 0, d_es, P, 0)          # dE_s = dS E_i
+    gemm_raw(B, P, B, 1, dS, 1, B, 0, es, es.stride(0), 1, 0, d_ei, P, 0)          # dE_i = dS^T E_s
+    return loss, d_es, d_ei, (S if want_logits else None)
+
+
+class InfoNCEFn(torch.autograd.Function):
+    """loss = 0.5*[CE(S, I) + CE(S^T, I)], S = E_spot E_img^T / T.  Forward and backward are computed
+    together (closed-form dS from the two LSE vectors); autograd's backward only scales by grad_output."""
+
+    @staticmethod
+    def forward(ctx, e_spot, e_img, temperature, stash):
+        loss, d_es, d_ei, S = infonce_fwd_bwd(e_spot, e_img, temperature, want_logits=stash is not None)
+        if stash is not None:
+            stash["logits"] = S
+        ctx.save_for_backward(d_es, d_ei)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        d_es, d_ei = ctx.saved_tensors
+        return d_es * gl, d_ei * gl, None, None

@@ -1,0 +1,177 @@
+"""FusedAdam: torch.optim.Adam(lr, betas, eps, weight_decay) semantics (train.py:118-120) on the HIP
+kernels of csrc/adam.hip.
+
+MI355X-first layout: all dense parameters of a group are re-homed into ONE flat fp32 buffer (their
+``.data`` / ``.grad`` become views), with flat exp_avg / exp_avg_sq beside it, so the whole update is a
+single HBM-streaming launch (28 B/element) and, under data parallelism, the flat gradient buffer is
+the all-reduce bucket (no packing copies).  The two (65536, G) position tables are updated by a
+second kernel that reads no dense gradient: untouched rows see g = wd*p exactly as in the reference
+(whose dense autograd gradient is zero there), touched rows add the row-sparse data gradient.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+
+Tensor = torch.Tensor
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-3, process_group=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.process_group = process_group
+        self._step_count = 0
+        self._flat: Dict[int, dict] = {}          # group index -> flat buffers
+        self._tables: Dict[int, dict] = {}        # id(param) -> table state
+        self._sink: Optional[dict] = None
+
+    # ------------------------------------------------------------------ wiring
+    def attach_model(self, model) -> "FusedAdam":
+        """Registers the model's position tables for the row-sparse update (model.embedding_grad ==
+        'rowsparse') and inherits its process group."""
+        if getattr(model, "embedding_grad", "dense") == "rowsparse":
+            self._sink = model.sparse_grads
+            for key, emb in (("ix", model.x_embed), ("iy", model.y_embed)):
+                self._tables[id(emb.weight)] = {"key": key, "param": emb.weight}
+        if self.process_group is None:
+            self.process_group = getattr(model, "process_group", None)
+        return self
+
+    # ------------------------------------------------------------------ flat buffers
+    def _build_flat(self, gi: int, group) -> None:
+        ps = [p for p in group["params"] if p.grad is not None and id(p) not in self._tables
+              and p.dtype == torch.float32 and p.is_cuda and not p.grad.is_sparse]
+        if not ps:
+            self._flat[gi] = {"params": [], "n": 0}
+            return
+        dev = ps[0].device
+        offs, n = [], 0
+        for p in ps:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every segment 16-byte aligned
+        flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
+        flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(ps, offs):
+            strides = p.stride()
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            if not dense:
+                p.data = p.data.contiguous()
+                p.grad = p.grad.contiguous()
+                strides = p.stride()
+            vp = flat_p.as_strided(p.shape, strides, o)
+            vg = flat_g.as_strided(p.shape, strides, o)
+            vp.copy_(p.data)
+            vg.copy_(p.grad)        # copy_ is layout-aware: logical element (i,j,..) -> same logical slot
+            p.data = vp
+            p.grad = vg
+        self._flat[gi] = {"params": ps, "n": n, "p": flat_p, "g": flat_g,
+                          "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p)}
+
+    def ensure_flat(self) -> None:
+        for gi, group in enumerate(self.param_groups):
+            if gi not in self._flat:
+                self._build_flat(gi, group)
+
+    def flat_param_ids(self) -> set:
+        return {id(p) for f in self._flat.values() for p in f["params"]}
+
+    def flat_grads(self) -> List[Tensor]:
+        """Flat gradient buffers (the data-parallel all-reduce buckets)."""
+        return [f["g"] for f in self._flat.values() if f.get("n", 0) > 0]
+
+    # ------------------------------------------------------------------ API
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        flat_ids = set()
+        for f in self._flat.values():
+            if f.get("n", 0) > 0:
+                f["g"].zero_()
+                flat_ids.update(id(p) for p in f["params"])
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) in flat_ids or p.grad is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._step_count += 1
+        t = self._step_count
+        L = _lib.lib()
+        st = ops._stream()
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
+            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+            if gi not in self._flat:
+                self._build_flat(gi, group)
+            f = self._flat[gi]
+            flat_ids = {id(p) for p in f["params"]}
+            if f["n"] > 0:
+                check(L.mcl_adam_step(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
+                                      f["n"], lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_step")
+            for p in group["params"]:
+                if id(p) in flat_ids:
+                    continue
+                tab = self._tables.get(id(p))
+                if tab is not None and self._sink is not None and "dout" in self._sink:
+                    self._table_step(L, st, p, tab, lr, b1, b2, eps, wd, bc1, bc2)
+                    continue
+                if p.grad is None:
+                    continue                        # torch.optim.Adam skips parameters without a gradient
+                state = self.state[p]
+                if not state:
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                g = p.grad
+                if g.stride() != p.stride():
+                    g = torch.empty_like(p).copy_(g)   # same memory order as p (the update is elementwise)
+                check(L.mcl_adam_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
+                                      state["exp_avg_sq"].data_ptr(), p.numel(), lr, b1, b2, eps, wd, bc1, bc2, st),
+                      "mcl_adam_step")
+        if self._sink is not None:
+            self._sink.clear()
+        return loss
+
+    # ------------------------------------------------------------------ tables
+    def _gathered(self):
+        """(dout, ix, iy) over the global batch (identical on every rank) -- cached per step."""
+        s = self._sink
+        if "g_dout" in s:
+            return s["g_dout"], s["g_ix"], s["g_iy"]
+        dout, ix, iy = s["dout"], s["ix"], s["iy"]
+        pg = self.process_group
+        if pg is not None and torch.distributed.get_world_size(pg) > 1:
+            from . import dist as mdist
+            dout, ix, iy = mdist.gather_rows(dout, ix, iy, pg)
+        s["g_dout"], s["g_ix"], s["g_iy"] = dout, ix, iy
+        return dout, ix, iy
+
+    def _table_step(self, L, st, p, tab, lr, b1, b2, eps, wd, bc1, bc2) -> None:
+        state = self.state[p]
+        if not state:
+            state["exp_avg"] = torch.zeros_like(p)
+            state["exp_avg_sq"] = torch.zeros_like(p)
+            state["row_slot"] = torch.full((p.shape[0],), -1, device=p.device, dtype=torch.int32)
+        dout, ix, iy = self._gathered()
+        rs = ops.embed_rowgrad(dout, ix if tab["key"] == "ix" else iy)
+        B = rs.rows.shape[0]
+        slot = state["row_slot"]
+        check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 1, st), "mcl_row_slot_update")
+        check(L.mcl_adam_table_step(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                    p.shape[0], p.shape[1], slot.data_ptr(), rs.rows.data_ptr(), rs.rows.stride(0),
+                                    lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_table_step")
+        check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 0, st), "mcl_row_slot_update")

@@ -1,0 +1,283 @@
+"""Per-kernel parity: each C-ABI entry point (through ops.py) against the CPU oracle / fp64 torch on
+the same seeded inputs.  Run on the MI355X box:  pytest -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mclstexp_amd import _lib, ops as _ops
+    _lib.lib()  # must load: no fallback
+    _ops.set_compute("f32")
+    return _ops
+
+
+# ------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 1000, 1000), (33, 171, 785), (8, 256, 1024), (1, 64, 64), (65, 129, 33), (128, 1536, 785)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_linear_fwd_and_bwd_layouts(ops, M, N, K):
+    x, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3)
+    dy = _rand(M, N, seed=4)
+    xd, Wd, bd, dyd = x.to(DEV), W.to(DEV), b.to(DEV), dy.to(DEV)
+    y, _ = ops.linear_fwd(xd, Wd, bd)
+    ref = x.double() @ W.double().t() + b.double()
+    assert_close_scaled(y.cpu(), ref, 2e-6, what="y = x W^T + b")
+    dx = ops.linear_bwd_data(dyd, Wd)
+    assert_close_scaled(dx.cpu(), dy.double() @ W.double(), 2e-6, what="dx = dy W")
+    dW = ops.linear_bwd_weight(dyd, xd)
+    assert_close_scaled(dW.cpu(), dy.double().t() @ x.double(), 2e-6, what="dW = dy^T x")
+    db = ops.colsum(dyd)
+    assert_close_scaled(db.cpu(), dy.double().sum(0), 2e-6, what="db")
+
+
+def test_gemm_epilogues(ops):
+    from oracle import ref_cpu
+    M, N, K = 37, 171, 300
+    x, W, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(N, seed=3), _rand(M, N, seed=5)
+    xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), r.to(DEV)
+    pre_ref = x.double() @ W.double().t() + b.double()
+    y, pre = ops.linear_fwd(xd, Wd, bd, gelu=True, save_pre=True, resid=rd)
+    assert_close_scaled(pre.cpu(), pre_ref, 2e-6, what="pre-activation")
+    assert_close_scaled(y.cpu(), ref_cpu.gelu_erf(pre_ref) + r.double(), 2e-6, what="gelu + resid")
+    dy = _rand(M, N, seed=7)
+    aux = _rand(M, K, seed=8, scale=2.0)
+    dx = ops.linear_bwd_data(dy.to(DEV), Wd, gelu_bwd_aux=aux.to(DEV), resid=xd)
+    ref = (dy.double() @ W.double()) * ref_cpu.gelu_erf_grad(aux.double()) + x.double()
+    assert_close_scaled(dx.cpu(), ref, 2e-6, what="gelu-bwd epilogue")
+    y2, _ = ops.linear_fwd(xd, Wd, None, alpha=0.25)
+    assert_close_scaled(y2.cpu(), 0.25 * (x.double() @ W.double().t()), 2e-6, what="alpha, no bias")
+
+
+def test_gemm_unaligned_views(ops):
+    """Operands that are strided views (q/k/v slices of qkv) and 4-byte-aligned-only bases."""
+    B, H, d = 19, 3, 64
+    qkv = _rand(B, 3 * H * d, seed=3).to(DEV)
+    out, P = ops.attention_core_fwd(qkv, H, d)
+    q, k, v = qkv.cpu().double().view(B, 3, H, d).permute(1, 2, 0, 3)
+    Pref = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1)
+    assert_close(P.cpu(), Pref, 2e-6, what="attention probabilities")
+    assert_close_scaled((Pref @ v).permute(1, 0, 2).reshape(B, H * d), out.cpu().double(), 4e-6, what="attention out")
+    base = _rand(5 * 40 + 1, seed=9).to(DEV)
+    x = base[1:].view(5, 40)                      # data_ptr 4-byte aligned only
+    W = _rand(7, 40, seed=10).to(DEV)
+    y, _ = ops.linear_fwd(x, W)
+    assert_close_scaled(y.cpu(), x.cpu().double() @ W.cpu().double().t(), 2e-6, what="unaligned base")
+
+
+def test_gemm_bf16_mode(ops):
+    M, N, K = 128, 256, 1000
+    x, W = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    ops.set_compute("bf16")
+    try:
+        y, _ = ops.linear_fwd(x.to(DEV), W.to(DEV))
+        dW = ops.linear_bwd_weight(_rand(M, N, seed=4).to(DEV), x.to(DEV))
+    finally:
+        ops.set_compute("f32")
+    ref = x.bfloat16().double() @ W.bfloat16().double().t()      # operands rounded to bf16, fp32 accumulate
+    assert_close_scaled(y.cpu(), ref, 2e-5, what="bf16 MFMA vs bf16-rounded operands")
+    ref_w = _rand(M, N, seed=4).bfloat16().double().t() @ x.bfloat16().double()
+    assert_close_scaled(dW.cpu(), ref_w, 2e-5, what="bf16 dW")
+    # and within bf16 tolerance of the fp32 product
+    assert_close_scaled(y.cpu(), x.double() @ W.double().t(), 1e-2, what="bf16 vs fp32")
+
+
+# ------------------------------------------------------------------ LayerNorm / softmax
+@pytest.mark.parametrize("rows,cols", [(128, 1000), (33, 171), (8, 785), (5, 256), (3, 3467)])
+def test_layernorm_fwd_bwd(ops, rows, cols):
+    from oracle import ref_cpu
+    x = _rand(rows, cols, seed=1, scale=3.0) + 0.5
+    g, b = 1 + 0.1 * _rand(cols, seed=2), 0.1 * _rand(cols, seed=3)
+    dy, add = _rand(rows, cols, seed=4), _rand(rows, cols, seed=5)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yref = ref_cpu.layer_norm(xr, gr, br)
+    yref.backward(dy)
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert_close(y.cpu(), yref.detach(), 3e-6, what="layernorm y")
+    dx, dg, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), g.to(DEV), mean, rstd, dx_add=add.to(DEV))
+    assert_close_scaled(dx.cpu(), xr.grad + add, 3e-6, what="layernorm dx (+residual)")
+    assert_close_scaled(dg.cpu(), gr.grad, 3e-6, what="dgamma")
+    assert_close_scaled(db.cpu(), br.grad, 3e-6, what="dbeta")
+
+
+def test_softmax_rows(ops):
+    from mclstexp_amd import _lib
+    R, Cn, scale = 70, 133, 0.125
+    s = _rand(R, Cn, seed=1, scale=40.0)
+    dp = _rand(R, Cn, seed=2)
+    sr = s.clone().double().requires_grad_(True)
+    pref = torch.softmax(sr * scale, -1)
+    pref.backward(dp.double())
+    sd = s.to(DEV)
+    _lib.check(_lib.lib().mcl_softmax_rows_fwd(sd.data_ptr(), Cn, R, Cn, scale, ops._stream()))
+    assert_close(sd.cpu(), pref.detach(), 1e-6, what="softmax")
+    dpd = dp.to(DEV)
+    _lib.check(_lib.lib().mcl_softmax_rows_bwd(sd.data_ptr(), dpd.data_ptr(), Cn, R, Cn, scale, ops._stream()))
+    assert_close_scaled(dpd.cpu(), sr.grad, 3e-6, what="softmax bwd")
+
+
+# ------------------------------------------------------------------ position embedding
+def test_pos_embed_fwd_bwd_dense_and_sparse(ops):
+    from oracle import ref_cpu
+    B, G, n_rows = 37, 171, 1000
+    expr = _rand(B, G, seed=1)
+    pos = torch.floor(_rand(B, 2, seed=2).abs() * 12)          # many duplicates
+    pos[3, 0] = 7.9                                            # .long() truncation
+    xt, yt = _rand(n_rows, G, seed=3), _rand(n_rows, G, seed=4)
+    dout = _rand(B, G, seed=5)
+    er, xr, yr = (t.clone().requires_grad_(True) for t in (expr, xt, yt))
+    ref = ref_cpu.pos_embed_add(er, pos, xr, yr)
+    ref.backward(dout)
+    ed, xd, yd = (t.to(DEV).requires_grad_(True) for t in (expr, xt, yt))
+    out = ops.PosEmbedAddFn.apply(ed, pos.to(DEV), xd, yd, None)
+    assert_close(out.detach().cpu(), ref.detach(), 0.0, what="pos_embed_add (bit exact)")
+    out.backward(dout.to(DEV))
+    assert_close_scaled(xd.grad.cpu(), xr.grad, 2e-6, what="dense x table grad")
+    assert_close_scaled(yd.grad.cpu(), yr.grad, 2e-6, what="dense y table grad")
+    assert_close(ed.grad.cpu(), er.grad, 0.0, what="d expr")
+    sink = {}
+    ed2, xd2, yd2 = (t.to(DEV).requires_grad_(True) for t in (expr, xt, yt))
+    ops.PosEmbedAddFn.apply(ed2, pos.to(DEV), xd2, yd2, sink).backward(dout.to(DEV))
+    assert xd2.grad is None and yd2.grad is None
+    rs = ops.embed_rowgrad(sink["dout"], sink["ix"])
+    owners = rs.owner_idx.cpu()
+    assert sorted(owners[owners >= 0].tolist()) == sorted(set(pos[:, 0].long().tolist()))
+    assert_close_scaled(rs.to_dense(n_rows).cpu(), xr.grad, 2e-6, what="row-sparse -> dense")
+
+
+# ------------------------------------------------------------------ InfoNCE
+@pytest.mark.parametrize("B,P,T", [(128, 256, 1.0), (33, 256, 0.5), (8, 64, 1.0), (1, 256, 1.0), (300, 256, 2.0)])
+def test_infonce_vs_oracle(ops, B, P, T):
+    from oracle import ref_cpu
+    # LayerNorm-ed embeddings: row norm ~ sqrt(P) -> logits up to +-100
+    es = torch.nn.functional.layer_norm(_rand(B, P, seed=1), (P,))
+    ei = torch.nn.functional.layer_norm(_rand(B, P, seed=2) + 0.3 * es, (P,))
+    esr, eir = es.clone().double().requires_grad_(True), ei.clone().double().requires_grad_(True)
+    s_ref = ref_cpu.logits(esr, eir, T)
+    loss_ref = ref_cpu.symmetric_infonce(s_ref)
+    loss_ref.backward()
+    loss, d_es, d_ei, S = ops.infonce_fwd_bwd(es.to(DEV), ei.to(DEV), T)
+    assert_close(S.cpu(), s_ref.detach(), 1e-4, what="logits (1e-4 abs, north_star)")
+    assert_close(loss.item(), loss_ref.item(), 1e-4, what="loss (1e-4 abs, north_star)")
+    assert_close_scaled(d_es.cpu(), esr.grad, 1e-5, what="dE_spot")
+    assert_close_scaled(d_ei.cpu(), eir.grad, 1e-5, what="dE_img")
+
+
+def test_infonce_large_properties(ops):
+    """BASELINE full size (global batch 1024/2048): size-independent properties instead of a CPU oracle:
+    dS rows/cols each sum to 0 (softmax - one-hot), loss invariant under a joint permutation of pairs,
+    loss(a*E, T=a) ... and linearity of the gradient GEMMs."""
+    B, P = 2048, 256
+    es = torch.nn.functional.layer_norm(_rand(B, P, seed=1), (P,)).to(DEV)
+    ei = torch.nn.functional.layer_norm(_rand(B, P, seed=2), (P,)).to(DEV)
+    loss, d_es, d_ei, S = ops.infonce_fwd_bwd(es, ei, 1.0)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(DEV)
+    loss_p, d_es_p, _, _ = ops.infonce_fwd_bwd(es[perm].contiguous(), ei[perm].contiguous(), 1.0)
+    assert abs(loss.item() - loss_p.item()) < 1e-4
+    assert_close_scaled(d_es_p.cpu(), d_es[perm].cpu(), 1e-5, what="permutation equivariance of dE_spot")
+    # sum_i dE_spot[i] . E_spot[i]  ==  sum_ij dS_ij S_ij == sum_j dE_img[j] . E_img[j]
+    a = (d_es.double() * es.double()).sum().item()
+    b = (d_ei.double() * ei.double()).sum().item()
+    assert abs(a - b) < 1e-5 * max(1.0, abs(a))
+    ref = torch.logsumexp(S.double(), 1) - torch.diagonal(S.double())
+    ref2 = torch.logsumexp(S.double(), 0) - torch.diagonal(S.double())
+    assert abs(0.5 * (ref.mean() + ref2.mean()).item() - loss.item()) < 1e-4
+
+
+# ------------------------------------------------------------------ Adam
+def test_adam_flat_and_table(ops):
+    from mclstexp_amd import _lib
+    from oracle import ref_cpu
+    n = 100003
+    p, g = _rand(n, seed=1), _rand(n, seed=2, scale=0.01)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = (t.to(DEV) for t in (p, g, m, v))
+    L = _lib.lib()
+    for t in (1, 2, 3):
+        ref_cpu.adam_l2_step(p, g, m, v, t)
+        _lib.check(L.mcl_adam_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, 1e-4, 0.9, 0.999,
+                                   1e-8, 1e-3, 1 - 0.9 ** t, 1 - 0.999 ** t, ops._stream()))
+    assert_close(pd.cpu(), p, 2e-7, what="adam p after 3 steps")
+    assert_close_scaled(md.cpu(), m, 1e-6, what="exp_avg")
+    assert_close_scaled(vd.cpu(), v, 1e-6, what="exp_avg_sq")
+    # table form: dense zero gradient + touched rows
+    for G in (171, 1000):
+        rows = 4096
+        tab = _rand(rows, G, seed=3)
+        B = 9
+        rg = _rand(B, G, seed=4, scale=0.1)
+        owner = torch.tensor([5, -1, 4000, 17, -1, 0, 4095, 33, 2], dtype=torch.int32)
+        dense = torch.zeros(rows, G)
+        for b_, r_ in enumerate(owner.tolist()):
+            if r_ >= 0:
+                dense[r_] = rg[b_]
+        tm, tv = torch.zeros_like(tab), torch.zeros_like(tab)
+        td_, tmd, tvd = tab.to(DEV), tm.to(DEV), tv.to(DEV)
+        slot = torch.full((rows,), -1, dtype=torch.int32, device=DEV)
+        od, rgd = owner.to(DEV), rg.to(DEV)
+        ref_cpu.adam_l2_step(tab, dense, tm, tv, 1)
+        _lib.check(L.mcl_row_slot_update(slot.data_ptr(), od.data_ptr(), B, 1, ops._stream()))
+        _lib.check(L.mcl_adam_table_step(td_.data_ptr(), tmd.data_ptr(), tvd.data_ptr(), rows, G, slot.data_ptr(),
+                                         rgd.data_ptr(), G, 1e-4, 0.9, 0.999, 1e-8, 1e-3, 0.1, 0.001, ops._stream()))
+        _lib.check(L.mcl_row_slot_update(slot.data_ptr(), od.data_ptr(), B, 0, ops._stream()))
+        assert int((slot != -1).sum().item()) == 0
+        assert_close(td_.cpu(), tab, 2e-7, what=f"table adam G={G}")
+        assert_close_scaled(tmd.cpu(), tm, 1e-6, what="table exp_avg")
+
+
+# ------------------------------------------------------------------ composite blocks vs oracle autograd
+@pytest.mark.parametrize("B,G", [(33, 171), (128, 1000), (8, 785)])
+def test_attn_block_and_head_vs_oracle(ops, B, G):
+    from mclstexp_amd import synth
+    from oracle import ref_cpu
+    params = synth.make_params(G, 1024, layers=1, with_tables=False)
+    x = _rand(B, G, seed=1, scale=2.0)
+    dy = _rand(B, G, seed=2)
+    pr = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xr = x.clone().requires_grad_(True)
+    yref = ref_cpu.attn_block(xr, pr, "spot_encoder.0.", 8, 64)
+    yref.backward(dy)
+    pd = {k: v.to(DEV).requires_grad_(True) for k, v in params.items()}
+    xd = x.to(DEV).requires_grad_(True)
+    q = "spot_encoder.0."
+    y = ops.AttnBlockFn.apply(xd, pd[q + "attn.norm.weight"], pd[q + "attn.norm.bias"], pd[q + "attn.fn.to_qkv.weight"],
+                              pd[q + "attn.fn.to_out.0.weight"], pd[q + "attn.fn.to_out.0.bias"],
+                              pd[q + "ff.norm.weight"], pd[q + "ff.norm.bias"], pd[q + "ff.fn.net.0.weight"],
+                              pd[q + "ff.fn.net.0.bias"], pd[q + "ff.fn.net.3.weight"], pd[q + "ff.fn.net.3.bias"], 8, 64)
+    assert_close(y.detach().cpu(), yref.detach(), 2e-5, what="attn_block out")
+    y.backward(dy.to(DEV))
+    assert_close_scaled(xd.grad.cpu(), xr.grad, 1e-5, what="attn_block dx")
+    for k in pr:
+        if k.startswith(q):
+            assert_close_scaled(pd[k].grad.cpu(), pr[k].grad, 2e-5, what="grad " + k)
+    # projection head
+    de = _rand(B, 256, seed=3)
+    xr2 = x.clone().requires_grad_(True)
+    eref = ref_cpu.projection_head(xr2, pr, "spot_projection.")
+    eref.backward(de)
+    xd2 = x.to(DEV).requires_grad_(True)
+    h = "spot_projection."
+    e = ops.ProjectionHeadFn.apply(xd2, pd[h + "projection.weight"], pd[h + "projection.bias"], pd[h + "fc.weight"],
+                                   pd[h + "fc.bias"], pd[h + "layer_norm.weight"], pd[h + "layer_norm.bias"])
+    assert_close(e.detach().cpu(), eref.detach(), 1e-5, what="projection head out")
+    e.backward(de.to(DEV))
+    assert_close_scaled(xd2.grad.cpu(), xr2.grad, 1e-5, what="head dx")
+    for k in pr:
+        if k.startswith(h):
+            assert_close_scaled(pd[k].grad.cpu(), pr[k].grad, 2e-5, what="grad " + k)
