@@ -143,16 +143,18 @@ int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
  *   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),   bc1 = 1-b1^t, bc2 = 1-b2^t (host-computed).
+ * Hyper-parameters are doubles (Python floats in torch.optim) and rounded to fp32 once, so that
+ * 1-beta matches torch's double-computed constant.
  * Flat fp32 buffers of n elements (28 B/element of HBM traffic).                               */
-int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, float bc1, float bc2, mcl_stream_t stream);
+int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, double bc1, double bc2, mcl_stream_t stream);
 /* Same update for an embedding table (n_rows x cols, contiguous) whose data gradient is row-sparse:
  * g = wd*p + (row_slot[r] >= 0 ? row_grad[row_slot[r],:] : 0).  24 B/element: the dense zero
  * gradient of the reference (model.py:204-205 under autograd) is never materialised.
  * row_slot (n_rows int32) maps table row -> slot in row_grad or -1.                            */
 int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
-                        const float* row_grad, int64_t ld_rg, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, float bc1, float bc2, mcl_stream_t stream);
+                        const float* row_grad, int64_t ld_rg, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, double bc1, double bc2, mcl_stream_t stream);
 /* row_slot maintenance: set row_slot[owner_idx[b]] = b for owners (fill != 0) or back to -1.    */
 int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill, mcl_stream_t stream);
 

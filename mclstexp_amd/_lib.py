@@ -17,6 +17,7 @@ ABI_VERSION = 1
 _lib: Optional[C.CDLL] = None
 
 c_f = C.c_float
+c_d = C.c_double
 c_i = C.c_int32
 c_l = C.c_int64
 c_p = C.c_void_p
@@ -57,8 +58,8 @@ PROTOTYPES = {
     "mcl_infonce_lse": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
     "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
-    "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
-    "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p],
+    "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
+    "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
 }
 _RESTYPES = {"mcl_error_string": C.c_char_p}

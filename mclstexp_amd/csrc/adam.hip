@@ -7,13 +7,13 @@
 namespace {
 
 struct AdamC {
-  float lr_over_bc1, beta1, beta2, eps, wd, rsqrt_bc2;
+  float lr_over_bc1, beta1, beta2, omb1, omb2, eps, wd, rsqrt_bc2;  // omb = 1 - beta, rounded from double
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamC& c) {
   g = fmaf(c.wd, p, g);                         // grad.add(param, alpha=wd)
-  m = fmaf(1.0f - c.beta1, g - m, m);           // exp_avg.lerp_(grad, 1-beta1)
-  v = fmaf(c.beta2, v, (1.0f - c.beta2) * g * g);
+  m = fmaf(c.omb1, g - m, m);                   // exp_avg.lerp_(grad, 1-beta1)
+  v = fmaf(c.beta2, v, c.omb2 * g * g);         // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
   const float denom = sqrtf(v) * c.rsqrt_bc2 + c.eps;
   p -= c.lr_over_bc1 * (m / denom);
 }
@@ -81,22 +81,26 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
-inline AdamC make_consts(float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+// Scalars arrive as doubles (Python floats on the host side, as in torch.optim) and are rounded once.
+inline AdamC make_consts(double lr, double b1, double b2, double eps, double wd, double bc1, double bc2) {
   AdamC c;
-  c.lr_over_bc1 = lr / bc1;
-  c.beta1 = b1;
-  c.beta2 = b2;
-  c.eps = eps;
-  c.wd = wd;
-  c.rsqrt_bc2 = 1.0f / sqrtf(bc2);
+  c.lr_over_bc1 = (float)(lr / bc1);
+  c.beta1 = (float)b1;
+  c.beta2 = (float)b2;
+  c.omb1 = (float)(1.0 - b1);
+  c.omb2 = (float)(1.0 - b2);
+  c.eps = (float)eps;
+  c.wd = (float)wd;
+  c.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
   return c;
 }
 
 }  // namespace
 
-extern "C" int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, float bc1, float bc2, mcl_stream_t stream) {
-  if (!p || !g || !m || !v || n <= 0 || bc1 <= 0.f || bc2 <= 0.f) return MCL_EINVAL;
+extern "C" int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, double bc1, double bc2,
+                             mcl_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || bc1 <= 0. || bc2 <= 0.) return MCL_EINVAL;
   const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
@@ -112,10 +116,10 @@ extern "C" int mcl_adam_step(float* p, const float* g, float* m, float* v, int64
 }
 
 extern "C" int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t cols,
-                                   const int32_t* row_slot, const float* row_grad, int64_t ld_rg, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
-                                   mcl_stream_t stream) {
-  if (!p || !m || !v || !row_slot || !row_grad || n_rows <= 0 || cols <= 0 || bc1 <= 0.f || bc2 <= 0.f)
+                                   const int32_t* row_slot, const float* row_grad, int64_t ld_rg, double lr,
+                                   double beta1, double beta2, double eps, double weight_decay, double bc1,
+                                   double bc2, mcl_stream_t stream) {
+  if (!p || !m || !v || !row_slot || !row_grad || n_rows <= 0 || cols <= 0 || bc1 <= 0. || bc2 <= 0.)
     return MCL_EINVAL;
   const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
   const int blocks = n_rows < 4096 ? n_rows : 4096;

@@ -31,6 +31,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._flat: Dict[int, dict] = {}          # group index -> flat buffers
         self._tables: Dict[int, dict] = {}        # id(param) -> table state
         self._sink: Optional[dict] = None
+        # bench.py sets this to a list to time every adam_table_kernel launch with HIP events recorded on
+        # the launch stream: [(start_event, end_event), ...]
+        self.profile_events: Optional[list] = None
 
     # ------------------------------------------------------------------ wiring
     def attach_model(self, model) -> "FusedAdam":
@@ -171,7 +174,13 @@ class FusedAdam(torch.optim.Optimizer):
         B = rs.rows.shape[0]
         slot = state["row_slot"]
         check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 1, st), "mcl_row_slot_update")
+        if self.profile_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(L.mcl_adam_table_step(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
                                     p.shape[0], p.shape[1], slot.data_ptr(), rs.rows.data_ptr(), rs.rows.stride(0),
                                     lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_table_step")
+        if self.profile_events is not None:
+            e1.record()
+            self.profile_events.append((e0, e1))
         check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 0, st), "mcl_row_slot_update")

@@ -238,3 +238,27 @@ def densenet121_features(p: Params, x: Tensor, prefix: str = "image_encoder.mode
             x = F.avg_pool2d(x, 2, 2)
     x = _bn_train(x, g("norm5.weight"), g("norm5.bias"))
     return x.mean(dim=(2, 3))
+
+
+# --------------------------------------------------------------------------- whole step (CPU baseline / smoke)
+def train_step(params: Params, state: Dict[str, Tuple[Tensor, Tensor]], batch: Dict[str, Tensor], step: int,
+               temperature: float = 1.0, layers: int = 2, heads: int = 8, dim_head: int = 64,
+               backbone: str = "densenet121") -> float:
+    """One iteration of train.py:33-41 on CPU: forward (model.py:225-247), autograd backward (dense
+    (65536, G) table gradients, as in the reference), Adam(lr=1e-4, weight_decay=1e-3) over ALL
+    parameters.  ``params`` are leaf tensors with requires_grad=True; ``state`` maps name -> (m, v).
+    ``backbone`` = "densenet121" (image (B,3,H,W)) or "identity" (image = (B, D) features)."""
+    for p in params.values():
+        p.grad = None
+    feats = batch["image"] if backbone == "identity" else densenet121_features(params, batch["image"])
+    out = forward_from_features(params, feats, batch["expression"], batch["position"], temperature, layers,
+                                heads, dim_head)
+    out["loss"].backward()
+    with torch.no_grad():
+        for n, p in params.items():
+            if p.grad is None:
+                continue
+            if n not in state:
+                state[n] = (torch.zeros_like(p), torch.zeros_like(p))
+            adam_l2_step(p, p.grad, state[n][0], state[n][1], step)
+    return float(out["loss"])
