@@ -10,6 +10,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch bundles its own libamdhip64.so.7; it MUST be in the process before our library is dlopen-ed so that
+# both bind to the same HIP runtime instance (same SONAME as /opt/rocm's: whichever loads first wins).
+# Loading ours first would give it a second, device-less runtime ("no ROCm-capable device", hipError 100).
+import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmclstexp_hip.so")
 ABI_VERSION = 1

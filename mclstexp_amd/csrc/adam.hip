@@ -100,6 +100,7 @@ inline AdamC make_consts(double lr, double b1, double b2, double eps, double wd,
 extern "C" int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                              double beta2, double eps, double weight_decay, double bc1, double bc2,
                              mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!p || !g || !m || !v || n <= 0 || bc1 <= 0. || bc2 <= 0.) return MCL_EINVAL;
   const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
   long long blocks = (n / 4 + 255) / 256;
@@ -119,6 +120,7 @@ extern "C" int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows,
                                    const int32_t* row_slot, const float* row_grad, int64_t ld_rg, double lr,
                                    double beta1, double beta2, double eps, double weight_decay, double bc1,
                                    double bc2, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!p || !m || !v || !row_slot || !row_grad || n_rows <= 0 || cols <= 0 || bc1 <= 0. || bc2 <= 0.)
     return MCL_EINVAL;
   const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);

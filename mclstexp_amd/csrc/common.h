@@ -6,6 +6,10 @@
 
 #define MCL_WAVE 64
 
+// hipGetLastError() is sticky per host thread: a benign failure inside the caller's own runtime use
+// (PyTorch probes) would otherwise be reported as ours.  Clear it before enqueueing.
+#define MCL_CLEAR_ERROR() (void)hipGetLastError()
+
 #define MCL_CHECK_LAUNCH()                                  \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \

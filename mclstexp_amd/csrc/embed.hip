@@ -84,6 +84,7 @@ extern "C" int mcl_pos_embed_add_fwd(const float* expr, int64_t ld_expr, const f
                                      const float* y_table, int64_t ld_table, int32_t n_rows, float* out,
                                      int64_t ld_out, int32_t* ix, int32_t* iy, int32_t* err_flag, int32_t B,
                                      int32_t G, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!expr || !pos || !x_table || !y_table || !out || !ix || !iy || B <= 0 || G <= 0 || n_rows <= 0)
     return MCL_EINVAL;
   hipLaunchKernelGGL(pos_embed_add_fwd_kernel, dim3(B), dim3(256), 0, mcl_stream(stream), expr, ld_expr, pos, x_table,
@@ -94,6 +95,7 @@ extern "C" int mcl_pos_embed_add_fwd(const float* expr, int64_t ld_expr, const f
 
 extern "C" int mcl_embed_rowgrad(const float* d_out, int64_t ld_dout, const int32_t* idx, int32_t* owner_idx,
                                  float* row_grad, int64_t ld_rg, int32_t B, int32_t G, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!d_out || !idx || !owner_idx || !row_grad || B <= 0 || G <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(embed_rowgrad_kernel, dim3(B), dim3(256), 0, mcl_stream(stream), d_out, ld_dout, idx, owner_idx,
                      row_grad, ld_rg, B, G);
@@ -104,6 +106,7 @@ extern "C" int mcl_embed_rowgrad(const float* d_out, int64_t ld_dout, const int3
 extern "C" int mcl_embed_scatter_rows(const int32_t* owner_idx, const float* row_grad, int64_t ld_rg,
                                       float* table_grad, int64_t ld_table, int32_t B, int32_t G, int32_t accumulate,
                                       mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!owner_idx || !row_grad || !table_grad || B <= 0 || G <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(embed_scatter_rows_kernel, dim3(B), dim3(256), 0, mcl_stream(stream), owner_idx, row_grad, ld_rg,
                      table_grad, ld_table, G, accumulate);
@@ -113,6 +116,7 @@ extern "C" int mcl_embed_scatter_rows(const int32_t* owner_idx, const float* row
 
 extern "C" int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill,
                                    mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!row_slot || !owner_idx || B <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(row_slot_update_kernel, dim3((B + 255) / 256), dim3(256), 0, mcl_stream(stream), row_slot,
                      owner_idx, B, fill);

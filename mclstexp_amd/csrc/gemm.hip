@@ -192,6 +192,7 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 }  // namespace
 
 extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!a || !a->A || !a->B || !a->C) return MCL_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return MCL_EINVAL;
   const bool akc = (a->sAk == 1), amc = (a->sAm == 1);

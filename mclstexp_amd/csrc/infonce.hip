@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void dlogits_kernel(const float* __restrict__ 
 
 extern "C" int mcl_infonce_lse(const float* S, int64_t ldS, int32_t R, int32_t C, float* row_lse, float* col_lse,
                                mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!S || R <= 0 || C <= 0 || (!row_lse && !col_lse)) return MCL_EINVAL;
   hipStream_t st = mcl_stream(stream);
   if (row_lse) hipLaunchKernelGGL(row_lse_kernel, dim3((R + 3) / 4), dim3(256), 0, st, S, ldS, R, C, row_lse);
@@ -110,6 +111,7 @@ extern "C" int mcl_infonce_lse(const float* S, int64_t ldS, int32_t R, int32_t C
 extern "C" int mcl_infonce_loss(const float* S, int64_t ldS, const float* row_lse, const float* col_lse, int32_t di0,
                                 int32_t dj0, int32_t n_diag, int32_t use_rows, int32_t use_cols, float* loss_sum,
                                 mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!S || !loss_sum || n_diag < 0 || di0 < 0 || dj0 < 0) return MCL_EINVAL;
   if ((use_rows && !row_lse) || (use_cols && !col_lse)) return MCL_EINVAL;
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, mcl_stream(stream), S, ldS, row_lse, col_lse, di0, dj0,
@@ -121,6 +123,7 @@ extern "C" int mcl_infonce_loss(const float* S, int64_t ldS, const float* row_ls
 extern "C" int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const float* col_lse, int32_t R,
                                    int32_t C, int32_t row0, int32_t col0, float coef, float* dS, int64_t lddS,
                                    mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!S || !row_lse || !col_lse || !dS || R <= 0 || C <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(dlogits_kernel, dim3((C + 255) / 256, R), dim3(256), 0, mcl_stream(stream), S, ldS, row_lse,
                      col_lse, R, C, row0, col0, coef, dS, lddS);

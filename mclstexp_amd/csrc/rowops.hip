@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 extern "C" int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                                  int64_t ldy, float* mean, float* rstd, int32_t rows, int32_t cols, float eps,
                                  mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0,
                      mcl_stream(stream), x, ldx, gamma, beta, y, ldy, mean, rstd, rows, cols, eps);
@@ -153,6 +154,7 @@ extern "C" int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
                                  const float* mean, const float* rstd, const float* dx_add, int64_t ldadd,
                                  float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t rows, int32_t cols,
                                  mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipStream_t st = mcl_stream(stream);
   hipLaunchKernelGGL(layernorm_bwd_dgb_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd,
@@ -164,6 +166,7 @@ extern "C" int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
 }
 
 extern "C" int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!x || !out || rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, mcl_stream(stream), x, ldx, out, rows, cols);
   MCL_CHECK_LAUNCH();
@@ -172,6 +175,7 @@ extern "C" int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows,
 
 extern "C" int mcl_softmax_rows_fwd(float* s, int64_t ld, int32_t n_rows, int32_t cols, float scale,
                                     mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!s || n_rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0,
                      mcl_stream(stream), s, ld, n_rows, cols, scale);
@@ -181,6 +185,7 @@ extern "C" int mcl_softmax_rows_fwd(float* s, int64_t ld, int32_t n_rows, int32_
 
 extern "C" int mcl_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int32_t n_rows, int32_t cols, float scale,
                                     mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
   if (!p || !dp || n_rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((n_rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0,
                      mcl_stream(stream), p, dp, ld, n_rows, cols, scale);

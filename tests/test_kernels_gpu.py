@@ -178,8 +178,9 @@ def test_infonce_vs_oracle(ops, B, P, T):
     assert_close(S.cpu(), s_ref.detach(), 1e-4, 5e-7, what="logits (1e-4 abs, north_star)")
     assert_close(loss.item(), loss_ref.item(), 1e-4, what="loss (1e-4 abs, north_star)")
     # floor: saturated softmax (p - 1 cancellation) leaves gradients of ~1e-7 whose fp32 exp() noise is ~1e-9
-    assert_close_scaled(d_es.cpu(), esr.grad, 1e-5, floor=1e-8, what="dE_spot")
-    assert_close_scaled(d_ei.cpu(), eir.grad, 1e-5, floor=1e-8, what="dE_img")
+    # and rel 1e-4: S - LSE is formed in fp32 at |S| ~ 64..256 (ulp 4e-6..3e-5) before exp(), then p - 1 cancels
+    assert_close_scaled(d_es.cpu(), esr.grad, 1e-4, floor=1e-8, what="dE_spot")
+    assert_close_scaled(d_ei.cpu(), eir.grad, 1e-4, floor=1e-8, what="dE_img")
 
 
 def test_infonce_large_properties(ops):
