@@ -1,0 +1,156 @@
+"""Data-parallel logic on CPU with gloo, world_size 2 (and 4): the collective plumbing of
+mclstexp_amd/dist.py with oracle-backed arithmetic primitives (the HIP primitives need a GPU).
+Checks: global InfoNCE == single-process loss on the concatenated embeddings, gradients included;
+table-row exchange; flat-bucket gradient all-reduce."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu
+
+
+class OraclePrims:
+    """CPU restatement of dist.HipPrims' five primitives (tests only)."""
+
+    @staticmethod
+    def logits(a, b, inv_t):
+        return (a @ b.t()) * inv_t
+
+    @staticmethod
+    def row_lse(S):
+        return torch.logsumexp(S, dim=1)
+
+    @staticmethod
+    def col_lse(S):
+        return torch.logsumexp(S, dim=0)
+
+    @staticmethod
+    def dlogits(S, row_lse, col_lse, row0, col0, coef):
+        i = torch.arange(S.shape[0]).unsqueeze(1) + row0
+        j = torch.arange(S.shape[1]).unsqueeze(0) + col0
+        return coef * (torch.exp(S - row_lse.unsqueeze(1)) + torch.exp(S - col_lse.unsqueeze(0)) - 2.0 * (i == j))
+
+    @staticmethod
+    def mm_nn(dS, e):
+        return dS @ e
+
+    @staticmethod
+    def mm_tn(dS, e):
+        return dS.t() @ e
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        td.destroy_process_group()
+
+
+def _spawn(fn, world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _infonce_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    b_loc, P, T = 6, 32, 0.7
+    g = torch.Generator().manual_seed(1234)
+    es_all = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,))
+    ei_all = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,))
+    sl = slice(rank * b_loc, (rank + 1) * b_loc)
+    loss, d_es, d_ei, s_rows = mdist.dist_infonce_fwd_bwd(es_all[sl].clone(), ei_all[sl].clone(), T, td.group.WORLD,
+                                                          prims=OraclePrims)
+    return loss.item(), d_es, d_ei, s_rows
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_infonce_equals_single_process(world):
+    outs = _spawn(_infonce_case, world)
+    b_loc, P, T = 6, 32, 0.7
+    g = torch.Generator().manual_seed(1234)
+    es = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,)).requires_grad_(True)
+    ei = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,)).requires_grad_(True)
+    s = ref_cpu.logits(es, ei, T)
+    loss = ref_cpu.symmetric_infonce(s)
+    loss.backward()
+    for r, (l, d_es, d_ei, s_rows) in enumerate(outs):
+        sl = slice(r * b_loc, (r + 1) * b_loc)
+        assert abs(l - loss.item()) < 1e-5                      # identical global loss on every rank
+        assert torch.allclose(s_rows, s.detach()[sl], atol=1e-5)
+        # dE of the GLOBAL mean loss: weight grads are then SUMMED over ranks
+        assert torch.allclose(d_es, es.grad[sl], atol=1e-6), (d_es - es.grad[sl]).abs().max()
+        assert torch.allclose(d_ei, ei.grad[sl], atol=1e-6)
+
+
+def _rows_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    g = torch.Generator().manual_seed(7 + rank)
+    dout = torch.randn(5, 11, generator=g)
+    ix = torch.randint(0, 9, (5,), generator=g, dtype=torch.int32)
+    iy = torch.randint(0, 9, (5,), generator=g, dtype=torch.int32)
+    G, X, Y = mdist.gather_rows(dout, ix, iy, td.group.WORLD)
+    return dout, ix, iy, G, X, Y
+
+
+def test_gather_rows_is_rank_ordered_concat():
+    outs = _spawn(_rows_case, 2)
+    dcat = torch.cat([o[0] for o in outs]); xcat = torch.cat([o[1] for o in outs]); ycat = torch.cat([o[2] for o in outs])
+    for o in outs:
+        assert torch.equal(o[3], dcat) and torch.equal(o[4], xcat) and torch.equal(o[5], ycat)
+
+
+class _FakeFlatOpt:
+    """Stands in for FusedAdam's flat-bucket interface (its step() needs the GPU)."""
+
+    def __init__(self, rank):
+        self.flat = torch.full((10,), float(rank + 1))
+        self.a = torch.nn.Parameter(torch.zeros(3)); self.a.grad = self.flat[:3]
+        self.b = torch.nn.Parameter(torch.zeros(2)); self.b.grad = torch.full((2,), 10.0 * (rank + 1))
+        self.c = torch.nn.Parameter(torch.zeros(2))                       # no grad: skipped
+        self.param_groups = [{"params": [self.a, self.b, self.c]}]
+
+    def ensure_flat(self):
+        pass
+
+    def flat_grads(self):
+        return [self.flat]
+
+    def flat_param_ids(self):
+        return {id(self.a)}
+
+
+def _reduce_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    opt = _FakeFlatOpt(rank)
+    mdist.GradReducer(td.group.WORLD).reduce(opt)
+    return opt.flat.clone(), opt.b.grad.clone()
+
+
+def test_grad_reducer_sums_flat_bucket_and_stragglers():
+    for flat, b in _spawn(_reduce_case, 2):
+        assert torch.equal(flat, torch.full((10,), 3.0))       # 1 + 2: SUM, not mean
+        assert torch.equal(b, torch.full((2,), 30.0))
+
+
+def test_init_from_env_single_process(monkeypatch):
+    from mclstexp_amd import dist as mdist
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    pg, rank, world = mdist.init_from_env()
+    assert pg is None and rank == 0 and world == 1
