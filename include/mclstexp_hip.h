@@ -139,6 +139,30 @@ int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const
                         int32_t C, int32_t row0, int32_t col0, float coef, float* dS, int64_t lddS,
                         mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- K10 DenseNet BatchNorm(+ReLU), channels-last
+ * Train-mode nn.BatchNorm2d (+ nn.ReLU) of the torchvision DenseNet-121 feature extractor that
+ * model.py:75-76 wraps, on NHWC activations viewed as (S = B*H*W rows) x (C channels) with a row stride
+ * ld (elements) -- so a dense layer reads its input as a channel slice of the block's concat buffer in
+ * place (no torch.cat), per-channel statistics are computed once per produced feature map, and the
+ * data gradient is accumulated in place.  dtype: 0 = fp32, 1 = bf16 activations; statistics and affine
+ * parameters are fp32.  C must be a multiple of 4 (fp32) / 8 (bf16), bases 16-byte aligned.
+ * workspace: mcl_bn_workspace_floats(S, C, dtype) floats.                                        */
+int64_t mcl_bn_workspace_floats(int64_t S, int32_t C, int32_t dtype);
+/* mean/var (biased)/rstd = 1/sqrt(var+eps) per channel; if copy_out != NULL also copies x there
+ * (used to place a produced feature map into its slice of the concat buffer in the same pass).  */
+int mcl_bn_stats(const void* x, int64_t ld, int64_t S, int32_t C, int32_t dtype, void* copy_out, int64_t ld_out,
+                 float* workspace, float eps, float* mean, float* var, float* rstd, mcl_stream_t stream);
+/* y = relu?( (x-mean)*rstd*gamma + beta ) */
+int mcl_bn_act_fwd(const void* x, int64_t ldx, int64_t S, int32_t C, int32_t dtype, const float* gamma,
+                   const float* beta, const float* mean, const float* rstd, int32_t relu, void* y, int64_t ldy,
+                   mcl_stream_t stream);
+/* g = dy*[y>0] (or dy); dgamma = sum g*xhat; dbeta = sum g;
+ * dx (+)= gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))   (accumulate != 0: read-modify-write of dx) */
+int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t S, int32_t C, int32_t dtype,
+                   const float* gamma, const float* beta, const float* mean, const float* rstd, int32_t relu,
+                   float* workspace, float* dgamma, float* dbeta, void* dx, int64_t lddx, int32_t accumulate,
+                   mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;

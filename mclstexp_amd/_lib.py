@@ -63,11 +63,15 @@ PROTOTYPES = {
     "mcl_infonce_lse": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
     "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+    "mcl_bn_workspace_floats": [c_l, c_i, c_i],
+    "mcl_bn_stats": [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
+    "mcl_bn_act_fwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
+    "mcl_bn_act_bwd": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
 }
-_RESTYPES = {"mcl_error_string": C.c_char_p}
+_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

@@ -166,11 +166,21 @@ class _PooledSequential(nn.Module):
 
 
 class ImageEncoder(_PooledSequential):
-    """DenseNet-121, model.py:72-85.  Output (B, 1024)."""
+    """DenseNet-121, model.py:72-85.  Output (B, 1024).
+
+    ``forward`` is the plain torch module path (MIOpen BatchNorm, torch.cat).  ``forward_fused`` runs the
+    same parameters through the concat-free / stats-caching execution of ``densenet_fused`` (hand-written
+    BN+ReLU kernels); train mode on the GPU only."""
     out_dim = 1024
 
     def __init__(self):
         super().__init__([densenet121_features_module()])
+
+    def forward_fused(self, x, act_dtype=torch.bfloat16):
+        from .densenet_fused import densenet_features_fused
+        y = densenet_features_fused(self.model[0], x, act_dtype)
+        y = F.adaptive_avg_pool2d(y.float(), (1, 1))
+        return y.view(y.size(0), -1)
 
 
 class ImageEncoder_Resnet(_PooledSequential):

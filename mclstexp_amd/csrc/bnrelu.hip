@@ -1,0 +1,432 @@
+// Train-mode BatchNorm(+ReLU) for the DenseNet backbone on channels-last activations, written for the
+// concat-free dense block: every kernel addresses a (S = B*H*W rows) x (C channels) slice of a wider
+// NHWC buffer through a row stride, so dense-layer inputs are read in place (no torch.cat copy), the
+// per-channel batch statistics of a feature map are computed ONCE when it is produced, and the
+// data-gradient is accumulated in place into the block's gradient buffer (no autograd add chain).
+//
+// All five kernels are HBM-streaming with the same thread mapping: a thread owns one 16-byte channel
+// vector (8 bf16 / 4 fp32 channels) for the whole launch and walks rows, so per-channel parameters live
+// in registers and per-channel reductions are register accumulators, merged once per workgroup through
+// LDS and once per launch by a deterministic finalize kernel (no atomics).
+//   stats:     mean/var over S per channel (shifted sums: d = x - x[0,c], immune to mean >> std)
+//   act_fwd:   y = relu?(x*scale + shift), scale = gamma*rstd, shift = beta - mean*scale
+//   act_bwd:   g = dy*[y>0]; dgamma = sum g*xhat; dbeta = sum g; dx (+)= gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))
+// nn.BatchNorm2d training semantics, torchvision DenseNet (/root/reference/model.py:75-76 via torchvision).
+#include "common.h"
+
+namespace {
+
+constexpr int NTH = 256;
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int V = 4;
+  __device__ static void load(const float* p, float (&f)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  __device__ static void store(float* p, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+};
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (unsigned short)(u >> 16);  // inf/nan: truncate
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <> struct Vec<bf16_t> {
+  static constexpr int V = 8;
+  __device__ static void load(const bf16_t* p, float (&f)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+  }
+  __device__ static void store(bf16_t* p, const float (&f)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf_rne(f[2 * i]) | ((unsigned)f2bf_rne(f[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(NTH) void stats_partial_kernel(const T* __restrict__ x, long long ld, long long S, int C,
+                                                            T* __restrict__ copy_out, long long ld_out,
+                                                            float* __restrict__ partial, int rows_per_block) {
+  constexpr int V = Vec<T>::V;
+  __shared__ float smem[NTH * 2 * V];
+  const int cvn_all = C / V;
+  const int tile0 = blockIdx.y * NTH;
+  const int cvn = min(cvn_all - tile0, NTH);
+  const int rpi = NTH / cvn;
+  const int t = threadIdx.x;
+  const bool active = t < rpi * cvn;
+  const int cv = tile0 + t % cvn, rloc = t / cvn;
+  float s1[V], s2[V], k[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.0f;
+  if (active) {
+    Vec<T>::load(x + (long long)cv * V, k);  // shift = first row's value of each channel
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(S, r0 + rows_per_block);
+    for (long long r = r0 + rloc; r < r1; r += rpi) {
+      float f[V];
+      Vec<T>::load(x + r * ld + (long long)cv * V, f);
+      if (copy_out) Vec<T>::store(copy_out + r * ld_out + (long long)cv * V, f);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float d = f[i] - k[i];
+        s1[i] += d;
+        s2[i] = fmaf(d, d, s2[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    smem[i * NTH + t] = s1[i];
+    smem[(V + i) * NTH + t] = s2[i];
+  }
+  __syncthreads();
+  if (active && rloc == 0) {
+    float* out = partial + ((long long)blockIdx.x * C + (long long)cv * V) * 2;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float a = 0.0f, b = 0.0f;
+      for (int q = 0; q < rpi; ++q) {
+        a += smem[i * NTH + t + q * cvn];
+        b += smem[(V + i) * NTH + t + q * cvn];
+      }
+      out[2 * i] = a;
+      out[2 * i + 1] = b;
+    }
+  }
+}
+
+// Finalize kernels: a workgroup owns 32 consecutive channels (one 256-byte run of each partial row, read
+// coalesced as float2 by 32 lanes) and its 8 row-groups walk the nblk partial rows in parallel; fixed
+// summation order (deterministic), double accumulation.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int rg,
+                                                double& a, double& b, double (*sm)[32][2]) {
+  a = 0.0;
+  b = 0.0;
+  if (c < C) {
+    for (int i = rg; i < nblk; i += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)i * C + c) * 2);
+      a += (double)v.x;
+      b += (double)v.y;
+    }
+  }
+  sm[rg][threadIdx.x & 31][0] = a;
+  sm[rg][threadIdx.x & 31][1] = b;
+  __syncthreads();
+  if (rg == 0) {
+    a = 0.0;
+    b = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a += sm[q][threadIdx.x & 31][0];
+      b += sm[q][threadIdx.x & 31][1];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const T* __restrict__ x,
+                                                             const float* __restrict__ partial, int nblk, int C,
+                                                             long long S, float eps, float* __restrict__ mean,
+                                                             float* __restrict__ var, float* __restrict__ rstd) {
+  __shared__ double sm[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  double a, b;
+  reduce_partials(partial, nblk, C, c, rg, a, b, sm);
+  if (rg != 0 || c >= C) return;
+  float k;
+  if (sizeof(T) == 2) k = bf2f(((const bf16_t*)x)[c]); else k = ((const float*)x)[c];
+  const double n = (double)S;
+  const double m = a / n;
+  double v = b / n - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[c] = (float)((double)k + m);
+  var[c] = (float)v;
+  rstd[c] = (float)(1.0 / sqrt(v + (double)eps));
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTH) void act_fwd_kernel(const T* __restrict__ x, long long ldx, long long S, int C,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      int relu, T* __restrict__ y, long long ldy, int rows_per_block) {
+  constexpr int V = Vec<T>::V;
+  const int cvn_all = C / V;
+  const int tile0 = blockIdx.y * NTH;
+  const int cvn = min(cvn_all - tile0, NTH);
+  const int rpi = NTH / cvn;
+  const int t = threadIdx.x;
+  if (t >= rpi * cvn) return;
+  const int cv = tile0 + t % cvn, rloc = t / cvn;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = cv * V + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = fmaf(-mean[c], sc[i], beta[c]);
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(S, r0 + rows_per_block);
+  for (long long r = r0 + rloc; r < r1; r += rpi) {
+    float f[V];
+    Vec<T>::load(x + r * ldx + (long long)cv * V, f);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float v = fmaf(f[i], sc[i], sh[i]);
+      f[i] = relu ? fmaxf(v, 0.0f) : v;
+    }
+    Vec<T>::store(y + r * ldy + (long long)cv * V, f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict__ dy, long long lddy,
+                                                             const T* __restrict__ x, long long ldx, long long S,
+                                                             int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int relu,
+                                                             float* __restrict__ partial, int rows_per_block) {
+  constexpr int V = Vec<T>::V;
+  __shared__ float smem[NTH * 2 * V];
+  const int cvn_all = C / V;
+  const int tile0 = blockIdx.y * NTH;
+  const int cvn = min(cvn_all - tile0, NTH);
+  const int rpi = NTH / cvn;
+  const int t = threadIdx.x;
+  const bool active = t < rpi * cvn;
+  const int cv = tile0 + t % cvn, rloc = t / cvn;
+  float s1[V], s2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.0f;
+  if (active) {
+    float sc[V], sh[V], mu[V], rs[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = cv * V + i;
+      mu[i] = mean[c];
+      rs[i] = rstd[c];
+      sc[i] = gamma[c] * rs[i];
+      sh[i] = fmaf(-mu[i], sc[i], beta[c]);
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(S, r0 + rows_per_block);
+    for (long long r = r0 + rloc; r < r1; r += rpi) {
+      float f[V], g[V];
+      Vec<T>::load(x + r * ldx + (long long)cv * V, f);
+      Vec<T>::load(dy + r * lddy + (long long)cv * V, g);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float gi = (relu && fmaf(f[i], sc[i], sh[i]) <= 0.0f) ? 0.0f : g[i];
+        s1[i] += gi;
+        s2[i] = fmaf(gi, (f[i] - mu[i]) * rs[i], s2[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    smem[i * NTH + t] = s1[i];
+    smem[(V + i) * NTH + t] = s2[i];
+  }
+  __syncthreads();
+  if (active && rloc == 0) {
+    float* out = partial + ((long long)blockIdx.x * C + (long long)cv * V) * 2;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float a = 0.0f, b = 0.0f;
+      for (int q = 0; q < rpi; ++q) {
+        a += smem[i * NTH + t + q * cvn];
+        b += smem[(V + i) * NTH + t + q * cvn];
+      }
+      out[2 * i] = a;
+      out[2 * i + 1] = b;
+    }
+  }
+}
+
+// dbeta = sum g ; dgamma = sum g*xhat ; coef[c] = (sum g / S, sum g*xhat / S)
+__global__ __launch_bounds__(256) void act_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                               long long S, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
+  __shared__ double sm[8][32][2];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  double a, b;
+  reduce_partials(partial, nblk, C, c, rg, a, b, sm);
+  if (rg != 0 || c >= C) return;
+  dbeta[c] = (float)a;
+  dgamma[c] = (float)b;
+  coef[2 * c] = (float)(a / (double)S);
+  coef[2 * c + 1] = (float)(b / (double)S);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ dy, long long lddy,
+                                                         const T* __restrict__ x, long long ldx, long long S, int C,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, int relu,
+                                                         const float* __restrict__ coef, T* dx, long long lddx,
+                                                         int accumulate, int rows_per_block) {
+  constexpr int V = Vec<T>::V;
+  const int cvn_all = C / V;
+  const int tile0 = blockIdx.y * NTH;
+  const int cvn = min(cvn_all - tile0, NTH);
+  const int rpi = NTH / cvn;
+  const int t = threadIdx.x;
+  if (t >= rpi * cvn) return;
+  const int cv = tile0 + t % cvn, rloc = t / cvn;
+  float sc[V], sh[V], mu[V], rs[V], c1[V], c2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = cv * V + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    sc[i] = gamma[c] * rs[i];
+    sh[i] = fmaf(-mu[i], sc[i], beta[c]);
+    c1[i] = coef[2 * c];
+    c2[i] = coef[2 * c + 1];
+  }
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(S, r0 + rows_per_block);
+  for (long long r = r0 + rloc; r < r1; r += rpi) {
+    float f[V], g[V], o[V];
+    Vec<T>::load(x + r * ldx + (long long)cv * V, f);
+    Vec<T>::load(dy + r * lddy + (long long)cv * V, g);
+    if (accumulate) Vec<T>::load(dx + r * lddx + (long long)cv * V, o);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float gi = (relu && fmaf(f[i], sc[i], sh[i]) <= 0.0f) ? 0.0f : g[i];
+      const float xh = (f[i] - mu[i]) * rs[i];
+      const float d = sc[i] * (gi - c1[i] - xh * c2[i]);
+      o[i] = accumulate ? o[i] + d : d;
+    }
+    Vec<T>::store(dx + r * lddx + (long long)cv * V, o);
+  }
+}
+
+inline int vec_of(int dtype) { return dtype == 1 ? 8 : 4; }
+inline bool ok_layout(const void* p, long long ld, int C, int dtype) {
+  const int V = vec_of(dtype);
+  return p && (C % V == 0) && (ld % V == 0) && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0);
+}
+// rows per workgroup so that the grid has at most 1024 row-blocks and each does >= 8 iterations
+inline void plan(long long S, int C, int dtype, int* nblk, int* rows_per_block, int* tiles) {
+  const int V = vec_of(dtype);
+  const int cvn_all = C / V;
+  const int cvn = cvn_all < NTH ? cvn_all : NTH;
+  const int rpi = NTH / cvn;
+  long long rpb = (long long)rpi * 8;
+  long long nb = (S + rpb - 1) / rpb;
+  if (nb > 1024) {
+    nb = 1024;
+    rpb = (S + nb - 1) / nb;
+    rpb = (rpb + rpi - 1) / rpi * rpi;
+    nb = (S + rpb - 1) / rpb;
+  }
+  *nblk = (int)nb;
+  *rows_per_block = (int)rpb;
+  *tiles = (cvn_all + NTH - 1) / NTH;
+}
+
+}  // namespace
+
+extern "C" int64_t mcl_bn_workspace_floats(int64_t S, int32_t C, int32_t dtype) {
+  if (S <= 0 || C <= 0 || (dtype != 0 && dtype != 1) || C % vec_of(dtype) != 0) return -1;
+  int nblk, rpb, tiles;
+  plan(S, C, dtype, &nblk, &rpb, &tiles);
+  return (int64_t)nblk * 2 * C + 2 * C;
+}
+
+extern "C" int mcl_bn_stats(const void* x, int64_t ld, int64_t S, int32_t C, int32_t dtype, void* copy_out,
+                            int64_t ld_out, float* workspace, float eps, float* mean, float* var, float* rstd,
+                            mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!workspace || !mean || !var || !rstd || S <= 0 || C <= 0 || (dtype != 0 && dtype != 1)) return MCL_EINVAL;
+  if (!ok_layout(x, ld, C, dtype) || (copy_out && !ok_layout(copy_out, ld_out, C, dtype))) return MCL_EUNSUPPORTED;
+  int nblk, rpb, tiles;
+  plan(S, C, dtype, &nblk, &rpb, &tiles);
+  hipStream_t st = mcl_stream(stream);
+  dim3 grid(nblk, tiles);
+  if (dtype == 1) {
+    hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)x, (long long)ld,
+                       (long long)S, C, (bf16_t*)copy_out, (long long)ld_out, workspace, rpb);
+    hipLaunchKernelGGL(stats_finalize_kernel<bf16_t>, dim3((C + 31) / 32), dim3(256), 0, st, (const bf16_t*)x,
+                       workspace, nblk, C, (long long)S, eps, mean, var, rstd);
+  } else {
+    hipLaunchKernelGGL(stats_partial_kernel<float>, grid, dim3(NTH), 0, st, (const float*)x, (long long)ld,
+                       (long long)S, C, (float*)copy_out, (long long)ld_out, workspace, rpb);
+    hipLaunchKernelGGL(stats_finalize_kernel<float>, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)x,
+                       workspace, nblk, C, (long long)S, eps, mean, var, rstd);
+  }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_bn_act_fwd(const void* x, int64_t ldx, int64_t S, int32_t C, int32_t dtype, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, int32_t relu, void* y,
+                              int64_t ldy, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!gamma || !beta || !mean || !rstd || S <= 0 || C <= 0 || (dtype != 0 && dtype != 1)) return MCL_EINVAL;
+  if (!ok_layout(x, ldx, C, dtype) || !ok_layout(y, ldy, C, dtype)) return MCL_EUNSUPPORTED;
+  int nblk, rpb, tiles;
+  plan(S, C, dtype, &nblk, &rpb, &tiles);
+  dim3 grid(nblk, tiles);
+  if (dtype == 1)
+    hipLaunchKernelGGL(act_fwd_kernel<bf16_t>, grid, dim3(NTH), 0, mcl_stream(stream), (const bf16_t*)x,
+                       (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, (bf16_t*)y, (long long)ldy, rpb);
+  else
+    hipLaunchKernelGGL(act_fwd_kernel<float>, grid, dim3(NTH), 0, mcl_stream(stream), (const float*)x,
+                       (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, (float*)y, (long long)ldy, rpb);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t S, int32_t C,
+                              int32_t dtype, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, int32_t relu, float* workspace, float* dgamma, float* dbeta,
+                              void* dx, int64_t lddx, int32_t accumulate, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || S <= 0 || C <= 0 ||
+      (dtype != 0 && dtype != 1))
+    return MCL_EINVAL;
+  if (!ok_layout(dy, lddy, C, dtype) || !ok_layout(x, ldx, C, dtype) || !ok_layout(dx, lddx, C, dtype))
+    return MCL_EUNSUPPORTED;
+  int nblk, rpb, tiles;
+  plan(S, C, dtype, &nblk, &rpb, &tiles);
+  dim3 grid(nblk, tiles);
+  hipStream_t st = mcl_stream(stream);
+  float* coef = workspace + (long long)nblk * 2 * C;
+  if (dtype == 1) {
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)dy, (long long)lddy,
+                       (const bf16_t*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, workspace, rpb);
+    hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, workspace, nblk, C,
+                       (long long)S, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(act_bwd_dx_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)dy, (long long)lddy,
+                       (const bf16_t*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
+                       (bf16_t*)dx, (long long)lddx, accumulate, rpb);
+  } else {
+    hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid, dim3(NTH), 0, st, (const float*)dy, (long long)lddy,
+                       (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, workspace, rpb);
+    hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, workspace, nblk, C,
+                       (long long)S, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(act_bwd_dx_kernel<float>, grid, dim3(NTH), 0, st, (const float*)dy, (long long)lddy,
+                       (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
+                       (float*)dx, (long long)lddx, accumulate, rpb);
+  }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

@@ -1,0 +1,317 @@
+"""Concat-free, stats-caching execution of the DenseNet-121 feature extractor.
+
+Same module tree and parameters as ``backbones.densenet121_features_module`` (torchvision layout, what
+/root/reference/model.py:75-76 wraps) -- only the execution differs.  Round-1 profiling showed the
+stock path spends ~60 % of the training step in HBM-bound BatchNorm / ReLU / torch.cat / gradient-add
+kernels.  Here:
+
+  * each dense block owns ONE channels-last buffer (B, H, W, C_total); a layer reads its input as the
+    channel slice [:C_in] in place and its 32 new channels are written into [C_in:C_in+32] -- there is
+    no torch.cat and no O(L^2) copy;
+  * BatchNorm batch statistics of a feature map are computed once, when the map is produced (fused with
+    the copy into the buffer); every later norm1 / transition norm / norm5 that consumes those channels
+    re-uses them (they are the same numbers torch would recompute per layer);
+  * BN+ReLU forward is one read + one write (csrc/bnrelu.hip); BN+ReLU backward is a reduce pass and a
+    dx pass that ACCUMULATES in place into the block's gradient buffer, replacing autograd's per-layer
+    slice gradients and their add chain;
+  * convolutions stay on MIOpen (``aten.convolution`` / ``aten.convolution_backward``).
+
+Train-mode semantics of nn.BatchNorm2d are kept: batch statistics, running_mean / running_var (unbiased)
+/ num_batches_tracked updates with momentum 0.1 (batched with torch._foreach ops at the end of forward).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from ._lib import check
+
+Tensor = torch.Tensor
+CL = torch.channels_last
+_ws_cache = {}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return 1
+    if t.dtype == torch.float32:
+        return 0
+    raise RuntimeError(f"densenet_fused: unsupported activation dtype {t.dtype}")
+
+
+def _rows(t: Tensor) -> Tuple[int, int, int, int]:
+    """(ptr, S, C, ld) of a channels-last (possibly channel-sliced) 4-D tensor."""
+    if not t.is_cuda:
+        raise RuntimeError("densenet_fused: tensors must be on the GPU (no CPU fallback)")
+    B, C, H, W = t.shape
+    ld = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else t.stride(0))
+    ok = t.stride(1) == 1 and (W == 1 or t.stride(3) == ld) and (H == 1 or t.stride(2) == W * ld) and \
+        (B == 1 or t.stride(0) == H * W * ld)
+    if not ok:
+        raise RuntimeError(f"densenet_fused: expected a channels-last view, got shape {tuple(t.shape)} "
+                           f"strides {t.stride()}")
+    return t.data_ptr(), B * H * W, C, ld
+
+
+def _ws(nfloats: int, device) -> Tensor:
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nfloats:
+        w = torch.empty(max(nfloats, 1 << 20), device=device, dtype=torch.float32)
+        _ws_cache[key] = w
+    return w
+
+
+def bn_stats(x: Tensor, mean: Tensor, var: Tensor, rstd: Tensor, eps: float, copy_out: Optional[Tensor] = None):
+    p, S, C, ld = _rows(x)
+    dt = _dt(x)
+    L = _lib.lib()
+    n = L.mcl_bn_workspace_floats(S, C, dt)
+    if n < 0:
+        raise RuntimeError(f"mcl_bn_workspace_floats rejected S={S} C={C} dtype={dt}")
+    ws = _ws(n, x.device)
+    po, ldo = (None, 0)
+    if copy_out is not None:
+        po, S2, C2, ldo = _rows(copy_out)
+        assert (S2, C2) == (S, C) and copy_out.dtype == x.dtype
+    check(L.mcl_bn_stats(p, ld, S, C, dt, po, ldo, ws.data_ptr(), eps, mean.data_ptr(), var.data_ptr(),
+                         rstd.data_ptr(), _stream()), "mcl_bn_stats")
+
+
+def bn_act_fwd(x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, relu: bool, out: Tensor):
+    p, S, C, ld = _rows(x)
+    po, S2, C2, ldo = _rows(out)
+    assert (S2, C2) == (S, C) and out.dtype == x.dtype
+    check(_lib.lib().mcl_bn_act_fwd(p, ld, S, C, _dt(x), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                    rstd.data_ptr(), int(relu), po, ldo, _stream()), "mcl_bn_act_fwd")
+
+
+def bn_act_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, relu: bool,
+               dx: Tensor, accumulate: bool) -> Tuple[Tensor, Tensor]:
+    p, S, C, ld = _rows(x)
+    pd, S2, C2, ldd = _rows(dy)
+    px, S3, C3, ldx = _rows(dx)
+    assert (S2, C2) == (S, C) == (S3, C3) and dy.dtype == x.dtype == dx.dtype
+    dt = _dt(x)
+    L = _lib.lib()
+    ws = _ws(L.mcl_bn_workspace_floats(S, C, dt), x.device)
+    dg = torch.empty(C, device=x.device, dtype=torch.float32)
+    db = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(L.mcl_bn_act_bwd(pd, ldd, p, ld, S, C, dt, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                           rstd.data_ptr(), int(relu), ws.data_ptr(), dg.data_ptr(), db.data_ptr(), px, ldx,
+                           int(accumulate), _stream()), "mcl_bn_act_bwd")
+    return dg, db
+
+
+class BNActFn(torch.autograd.Function):
+    """y = relu?(BatchNorm_train(x)) with the batch statistics supplied (they are functions of x: the
+    backward is the full train-mode BatchNorm backward)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, rstd, relu):
+        y = torch.empty_like(x, memory_format=CL)
+        bn_act_fwd(x, gamma, beta, mean, rstd, relu, y)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=CL)
+        dx = torch.empty_like(x, memory_format=CL)
+        dg, db = bn_act_bwd(dy, x, gamma, beta, mean, rstd, ctx.relu, dx, False)
+        return dx, dg, db, None, None, None
+
+
+class _RunningStats:
+    """Collects (module, mean, biased var, count) during forward; applies nn.BatchNorm2d's running-stat
+    updates with a few multi-tensor launches at the end."""
+
+    def __init__(self):
+        self.mods: List[nn.BatchNorm2d] = []
+        self.means: List[Tensor] = []
+        self.vars: List[Tensor] = []
+        self.factors: List[float] = []
+
+    def add(self, bn: nn.BatchNorm2d, mean: Tensor, var: Tensor, n: int):
+        if bn.track_running_stats and bn.running_mean is not None:
+            self.mods.append(bn)
+            self.means.append(mean)
+            self.vars.append(var)
+            self.factors.append(n / max(1, n - 1))
+
+    @torch.no_grad()
+    def flush(self):
+        if not self.mods:
+            return
+        # one momentum per group (nn.BatchNorm2d default 0.1 everywhere in DenseNet)
+        by_m = {}
+        for i, bn in enumerate(self.mods):
+            by_m.setdefault(bn.momentum if bn.momentum is not None else 0.1, []).append(i)
+        for m, idx in by_m.items():
+            rms = [self.mods[i].running_mean for i in idx]
+            rvs = [self.mods[i].running_var for i in idx]
+            torch._foreach_lerp_(rms, [self.means[i] for i in idx], m)
+            unb = torch._foreach_mul([self.vars[i] for i in idx], [self.factors[i] for i in idx])
+            torch._foreach_lerp_(rvs, unb, m)
+        torch._foreach_add_([bn.num_batches_tracked for bn in self.mods], 1)
+        self.mods, self.means, self.vars, self.factors = [], [], [], []
+
+
+class _BlockStats:
+    """Per-channel batch statistics of a dense block's concat buffer."""
+
+    def __init__(self, c_total: int, device):
+        self.mean = torch.empty(c_total, device=device, dtype=torch.float32)
+        self.var = torch.empty(c_total, device=device, dtype=torch.float32)
+        self.rstd = torch.empty(c_total, device=device, dtype=torch.float32)
+
+
+def _conv_bwd(dy, x, w, padding):
+    return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [padding, padding], [1, 1], False, [0, 0], 1,
+                                               [True, True, False])
+
+
+class DenseBlockFn(torch.autograd.Function):
+    """A whole torchvision ``_DenseBlock`` (forward AND hand-scheduled backward).
+
+    inputs: x0 (B, C0, H, W) channels-last; meta = (stats: _BlockStats, eps1 list, eps2 list, growth);
+    then per layer: norm1.weight, norm1.bias, conv1.weight, norm2.weight, norm2.bias, conv2.weight.
+    output: the concat buffer (B, C0 + L*growth, H, W); ``stats`` is filled as a side effect.
+    """
+
+    @staticmethod
+    def forward(ctx, x0, meta, *params):
+        stats, eps1, eps2, growth, bn2_stats = meta
+        L = len(params) // 6
+        B, C0, H, W = x0.shape
+        Ct = C0 + L * growth
+        dev, dt = x0.device, x0.dtype
+        buf = torch.empty((B, Ct, H, W), device=dev, dtype=dt, memory_format=CL)
+        x0 = x0.contiguous(memory_format=CL)
+        bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
+        saved = []
+        wcast = []
+        for l in range(L):
+            g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
+            cin = C0 + l * growth
+            a = torch.empty((B, cin, H, W), device=dev, dtype=dt, memory_format=CL)
+            bn_act_fwd(buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], True, a)
+            w1c = w1.to(dtype=dt, memory_format=CL)
+            z = F.conv2d(a, w1c).contiguous(memory_format=CL)
+            m2, v2, r2 = bn2_stats[l]
+            bn_stats(z, m2, v2, r2, eps2[l])
+            a2 = torch.empty_like(z, memory_format=CL)
+            bn_act_fwd(z, g2, b2, m2, r2, True, a2)
+            w2c = w2.to(dtype=dt, memory_format=CL)
+            y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
+            c1 = cin + growth
+            # eps of the NEXT consumer's norm1 is the same module default everywhere (1e-5); rstd is
+            # stored for eps1[min(l+1, L-1)] -- all equal in torchvision's DenseNet
+            bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
+                     copy_out=buf[:, cin:c1])
+            saved += [a, z, a2]
+            wcast += [w1c, w2c]
+        ctx.save_for_backward(buf, *params, *saved, *wcast)
+        ctx.meta = (stats, growth, bn2_stats, L, C0)
+        return buf
+
+    @staticmethod
+    def backward(ctx, gbuf):
+        stats, growth, bn2_stats, L, C0 = ctx.meta
+        t = ctx.saved_tensors
+        buf = t[0]
+        params = t[1: 1 + 6 * L]
+        saved = t[1 + 6 * L: 1 + 9 * L]
+        wcast = t[1 + 9 * L:]
+        # the incoming gradient is produced by our own BNActFn for the block's single consumer: accumulate
+        # in place into it (no clone) when it is already a dense channels-last tensor
+        if not gbuf.is_contiguous(memory_format=CL):
+            gbuf = gbuf.contiguous(memory_format=CL)
+        grads = [None] * (6 * L)
+        for l in range(L - 1, -1, -1):
+            g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
+            a, z, a2 = saved[3 * l: 3 * l + 3]
+            w1c, w2c = wcast[2 * l: 2 * l + 2]
+            cin = C0 + l * growth
+            dy = gbuf[:, cin:cin + growth].contiguous(memory_format=CL)
+            da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
+            m2, v2, r2 = bn2_stats[l]
+            dz = torch.empty_like(z, memory_format=CL)
+            dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False)
+            da, dw1, _ = _conv_bwd(dz, a, w1c, 0)
+            dg1, db1 = bn_act_bwd(da.contiguous(memory_format=CL), buf[:, :cin], g1, b1, stats.mean[:cin],
+                                  stats.rstd[:cin], True, gbuf[:, :cin], True)
+            grads[6 * l: 6 * l + 6] = [dg1, db1, dw1.to(w1.dtype), dg2, db2, dw2.to(w2.dtype)]
+        return (gbuf[:, :C0], None, *grads)
+
+
+def _bn_train(x: Tensor, bn: nn.BatchNorm2d, relu: bool, rec: _RunningStats) -> Tensor:
+    C = x.shape[1]
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    var = torch.empty_like(mean)
+    rstd = torch.empty_like(mean)
+    x = x.contiguous(memory_format=CL)
+    bn_stats(x, mean, var, rstd, bn.eps)
+    rec.add(bn, mean, var, x.numel() // C)
+    return BNActFn.apply(x, bn.weight, bn.bias, mean, rstd, relu)
+
+
+def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats) -> Tuple[Tensor, _BlockStats]:
+    layers = list(blk.values())
+    growth = layers[0].conv2.out_channels
+    C0 = x.shape[1]
+    Ct = C0 + len(layers) * growth
+    stats = _BlockStats(Ct, x.device)
+    bott = layers[0].conv1.out_channels
+    bn2 = [tuple(torch.empty(bott, device=x.device, dtype=torch.float32) for _ in range(3)) for _ in layers]
+    params = []
+    for ly in layers:
+        params += [ly.norm1.weight, ly.norm1.bias, ly.conv1.weight, ly.norm2.weight, ly.norm2.bias, ly.conv2.weight]
+    meta = (stats, [ly.norm1.eps for ly in layers], [ly.norm2.eps for ly in layers], growth, bn2)
+    buf = DenseBlockFn.apply(x, meta, *params)
+    n = x.shape[0] * x.shape[2] * x.shape[3]
+    for i, ly in enumerate(layers):
+        cin = C0 + i * growth
+        rec.add(ly.norm1, stats.mean[:cin], stats.var[:cin], n)
+        rec.add(ly.norm2, bn2[i][0], bn2[i][1], n)
+    return buf, stats
+
+
+def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """Train-mode forward of torchvision-layout DenseNet ``features`` (conv0 ... norm5), returning the
+    (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly)."""
+    if not x.is_cuda:
+        raise RuntimeError("densenet_features_fused: input is on the CPU; the fused backbone path is GPU-only")
+    rec = _RunningStats()
+    x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
+    x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
+                 padding=features.conv0.padding)
+    x = _bn_train(x, features.norm0, True, rec)
+    x = F.max_pool2d(x, 3, 2, 1)
+    i = 1
+    out = None
+    while hasattr(features, f"denseblock{i}"):
+        buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec)
+        n = buf.shape[0] * buf.shape[2] * buf.shape[3]
+        if hasattr(features, f"transition{i}"):
+            tr = getattr(features, f"transition{i}")
+            a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
+            rec.add(tr.norm, stats.mean, stats.var, n)
+            x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
+            x = F.avg_pool2d(x, 2, 2)
+        else:
+            out = BNActFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd, False)
+            rec.add(features.norm5, stats.mean, stats.var, n)
+        i += 1
+    rec.flush()
+    return out

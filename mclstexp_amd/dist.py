@@ -47,7 +47,7 @@ def init_from_env() -> Tuple[Optional[td.ProcessGroup], int, int]:
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not td.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("MCL_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
@@ -60,13 +60,33 @@ def shutdown() -> None:
         td.destroy_process_group()
 
 
+def _host_staged(x: Tensor, pg) -> bool:
+    """gloo has no device collectives for every op: GPU tensors are staged through the host.  Only the
+    single-GPU multi-process correctness test uses gloo with GPU tensors; production is RCCL."""
+    return x.is_cuda and td.get_backend(pg) == "gloo"
+
+
 def _all_gather_cat(x: Tensor, pg) -> Tensor:
     """Concatenation over ranks along dim 0 (equal shapes on every rank)."""
     x = x.contiguous()
     world = td.get_world_size(pg)
+    if _host_staged(x, pg):
+        xc = x.cpu()
+        outc = torch.empty((world * xc.shape[0],) + tuple(xc.shape[1:]), dtype=xc.dtype)
+        td.all_gather_into_tensor(outc, xc, group=pg)
+        return outc.to(x.device)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
     td.all_gather_into_tensor(out, x, group=pg)
     return out
+
+
+def _all_reduce_sum(x: Tensor, pg) -> None:
+    if _host_staged(x, pg):
+        xc = x.cpu()
+        td.all_reduce(xc, op=td.ReduceOp.SUM, group=pg)
+        x.copy_(xc)
+        return
+    td.all_reduce(x, op=td.ReduceOp.SUM, group=pg)
 
 
 # --------------------------------------------------------------------------- arithmetic primitives
@@ -194,10 +214,10 @@ class GradReducer:
         flat_ids = set()
         if hasattr(optimizer, "flat_grads"):
             for g in optimizer.flat_grads():
-                td.all_reduce(g, op=td.ReduceOp.SUM, group=self.pg)
+                _all_reduce_sum(g, self.pg)
             flat_ids = optimizer.flat_param_ids()
         for group in optimizer.param_groups:
             for p in group["params"]:
                 if id(p) in flat_ids or p.grad is None:
                     continue
-                td.all_reduce(p.grad, op=td.ReduceOp.SUM, group=self.pg)
+                _all_reduce_sum(p.grad, self.pg)

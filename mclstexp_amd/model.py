@@ -200,6 +200,7 @@ class _ContrastiveBase(nn.Module):
         self.backbone_dtype = backbone_dtype
         self.embedding_grad = embedding_grad
         self.process_group = process_group
+        self.fused_backbone = True      # DenseNet-121: concat-free BN+ReLU kernels (densenet_fused.py)
         self.capture = False
         self.last: Dict[str, Tensor] = {}
         self.sparse_grads: Dict[str, ops.RowSparseGrad] = {}
@@ -207,6 +208,9 @@ class _ContrastiveBase(nn.Module):
     def _encode_image(self, encoder: nn.Module, image: Tensor) -> Tensor:
         if isinstance(encoder, nn.Identity):
             return image
+        if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and encoder.training
+                and image.is_cuda and torch.is_grad_enabled()):
+            return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
         if self.backbone_dtype is not None and self.backbone_dtype != torch.float32:
             if image.dim() == 4:
                 image = image.contiguous(memory_format=torch.channels_last)

@@ -1,0 +1,135 @@
+"""DenseNet-121 fused execution (hand-written channels-last BN+ReLU kernels, concat-free dense blocks,
+cached statistics) against the plain torch module path with the same parameters, on the MI355X."""
+import copy
+
+import pytest
+import torch
+
+from helpers import assert_close, assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g)
+
+
+@pytest.mark.parametrize("dtype,S,C,ld", [(torch.float32, 1000, 64, 64), (torch.float32, 333, 32, 96),
+                                          (torch.bfloat16, 4096, 128, 128), (torch.bfloat16, 777, 96, 256),
+                                          (torch.bfloat16, 50, 1024, 1024), (torch.float32, 3, 8, 8)])
+def test_bn_kernels_vs_torch(dtype, S, C, ld):
+    """mcl_bn_stats / mcl_bn_act_fwd / mcl_bn_act_bwd on a channel slice of a wider NHWC buffer."""
+    from mclstexp_amd import densenet_fused as dn
+    B, H, W = 1, S, 1
+    wide = (_rand(B, H, W, ld, seed=1) * 3 - 1 + torch.arange(ld) * 0.05).to(dtype)      # non-zero means
+    buf = wide.to(DEV).permute(0, 3, 1, 2)                                            # (B, ld, H, W) channels-last
+    x = buf[:, 8 if ld > C else 0: (8 if ld > C else 0) + C]
+    xf = x.float().cpu()
+    gamma, beta = 1 + 0.2 * _rand(C, seed=2), 0.3 * _rand(C, seed=3) - 0.1
+    mean, var, rstd = (torch.empty(C, device=DEV) for _ in range(3))
+    copy_out = torch.empty((B, C, H, W), device=DEV, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    dn.bn_stats(x, mean, var, rstd, 1e-5, copy_out=copy_out)
+    m_ref = xf.double().mean(dim=(0, 2, 3))
+    v_ref = xf.double().var(dim=(0, 2, 3), unbiased=False)
+    assert_close(mean.cpu(), m_ref, 2e-5, what="mean")
+    assert_close_scaled(var.cpu(), v_ref, 1e-4, what="var")
+    assert torch.equal(copy_out.cpu(), x.cpu())
+    xr = xf.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref = torch.relu(torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    dy = (_rand(B, C, H, W, seed=4) - 0.5).to(dtype)
+    yref.backward(dy.float())
+    y = torch.empty_like(copy_out)
+    dn.bn_act_fwd(x, gamma.to(DEV), beta.to(DEV), mean, rstd, True, y)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert_close(y.float().cpu(), yref.detach(), tol, tol, what="bn+relu fwd")
+    dx = torch.full_like(copy_out, 0.5)
+    dyd = dy.to(DEV).contiguous(memory_format=torch.channels_last)
+    dg, db = dn.bn_act_bwd(dyd, x, gamma.to(DEV), beta.to(DEV), mean, rstd, True, dx, True)
+    # the relu mask is taken from the fp32 pre-activation: elements within rounding of 0 may differ in bf16
+    rel = 1e-4 if dtype == torch.float32 else 3e-2
+    assert_close_scaled(dg.cpu(), gr.grad, rel, what="dgamma")
+    assert_close_scaled(db.cpu(), br.grad, rel, what="dbeta")
+    assert_close_scaled(dx.float().cpu() - 0.5, xr.grad, rel, floor=1e-6, what="dx (accumulated onto 0.5)")
+
+
+def _make(seed=0):
+    from mclstexp_amd.backbones import ImageEncoder
+    torch.manual_seed(seed)
+    enc = ImageEncoder()
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    return enc
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_densenet_as_accurate_as_module_path(dtype):
+    """A random-init 121-layer BN/ReLU net has ill-conditioned gradients (the stock fp32 module path itself
+    deviates from an fp64 run by up to ~10 % on individual tensors), so both executions are measured against
+    an fp64 reference of the same module and the fused path must be as close to it as the stock path is."""
+    import numpy as np
+    base = _make()
+    ref64 = copy.deepcopy(base).double().to(DEV).train()
+    ref = copy.deepcopy(base).to(DEV).train()
+    fus = copy.deepcopy(base).to(DEV).train()
+    # 8 x 96x96: the last block still normalises over 8*3*3 = 72 samples
+    x = _rand(8, 3, 96, 96, seed=5).to(DEV)
+    dy = (_rand(8, 1024, seed=6) - 0.5).to(DEV)
+    y64 = ref64(x.double())
+    y64.backward(dy.double())
+    if dtype == torch.float32:
+        y_ref = ref(x)
+    else:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y_ref = ref(x.contiguous(memory_format=torch.channels_last)).float()
+    y_ref.backward(dy)
+    y = fus.forward_fused(x, dtype)
+    y.backward(dy)
+    scale = y64.abs().max().item()
+    e_ref = (y_ref.double() - y64).abs().max().item() / scale
+    e_fus = (y.double() - y64).abs().max().item() / scale
+    assert e_fus <= 2.0 * e_ref + 1e-5, (e_fus, e_ref)
+    d_ref, d_fus = [], []
+    for (n, p64), (_, p), (_, q) in zip(ref64.named_parameters(), ref.named_parameters(), fus.named_parameters()):
+        assert q.grad is not None, n
+        s_ = p64.grad.abs().max().item() + 1e-30
+        d_ref.append((p.grad.double() - p64.grad).abs().max().item() / s_)
+        d_fus.append((q.grad.double() - p64.grad).abs().max().item() / s_)
+    d_ref, d_fus = np.array(d_ref), np.array(d_fus)
+    print(f"{dtype}: features err stock {e_ref:.2e} fused {e_fus:.2e}; grad rel-dev median stock "
+          f"{np.median(d_ref):.2e} fused {np.median(d_fus):.2e}; p90 stock {np.percentile(d_ref, 90):.2e} fused "
+          f"{np.percentile(d_fus, 90):.2e}; max stock {d_ref.max():.2e} fused {d_fus.max():.2e}")
+    assert np.median(d_fus) <= 1.5 * np.median(d_ref) + 1e-5
+    assert np.percentile(d_fus, 90) <= 1.5 * np.percentile(d_ref, 90) + 1e-5
+    assert d_fus.max() <= 2.5 * d_ref.max() + 1e-4
+    for (n, b64), (_, c) in zip(ref64.named_buffers(), fus.named_buffers()):
+        if n.endswith("num_batches_tracked"):
+            assert int(c) == 1
+        else:
+            assert_close_scaled(c.cpu(), b64.cpu(), 1e-4 if dtype == torch.float32 else 3e-2, floor=1e-6, what=n)
+
+
+def test_model_uses_fused_backbone_and_matches_unfused():
+    from mclstexp_amd import synth
+    from mclstexp_amd.model import mclSTExp_Attention
+    torch.manual_seed(0)
+    G = 171
+    m = mclSTExp_Attention("densenet121", 1.0, 1024, G, 256, 8, 64, 2)
+    sd = m.state_dict()
+    sd.update(synth.make_params(G, 1024, seed=0))
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    m2 = copy.deepcopy(m)
+    m2.fused_backbone = False
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(4, G, image_hw=64, seed=0).items()}
+    l1 = m(batch); l1.backward()
+    l2 = m2(batch); l2.backward()
+    assert abs(l1.item() - l2.item()) < 2e-3, (l1.item(), l2.item())
+    g1 = m.image_encoder.model[0].conv0.weight.grad
+    g2 = m2.image_encoder.model[0].conv0.weight.grad
+    assert (g1 - g2).abs().max() < 5e-3 * g2.abs().max()
