@@ -46,6 +46,8 @@ def parse():
                     help="MFMA operand type of the hand-written spot-path kernels")
     ap.add_argument("--backbone_dtype", type=str, default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--conv1x1", type=str, default="miopen", choices=["mm", "miopen"], help="A/B: 1x1 convs of the dense blocks")
+    ap.add_argument("--unfused_backbone", action="store_true", help="A/B: plain torch module path for the backbone")
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
     return ap.parse_args()
 
@@ -137,6 +139,9 @@ def main():
     model = mclSTExp_Attention(args.encoder, 1.0, args.image_dim, args.genes, 256, 8, 64, 2, compute=args.compute,
                                backbone_dtype=bb, embedding_grad="rowsparse",
                                process_group=pg if world > 1 else None)
+    from mclstexp_amd import densenet_fused
+    densenet_fused.USE_MM_1X1 = args.conv1x1 == "mm"
+    model.fused_backbone = not args.unfused_backbone
     model.to(dev)
     if bb is not None:
         model.to(memory_format=torch.channels_last)

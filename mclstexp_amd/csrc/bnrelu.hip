@@ -95,7 +95,8 @@ __global__ __launch_bounds__(NTH) void stats_partial_kernel(const T* __restrict_
   }
   __syncthreads();
   if (active && rloc == 0) {
-    float* out = partial + ((long long)blockIdx.x * C + (long long)cv * V) * 2;
+    // partial layout [C][nblk] float2: the finalize kernel then reads one channel's partials contiguously
+    const long long nblk = gridDim.x;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       float a = 0.0f, b = 0.0f;
@@ -103,38 +104,38 @@ __global__ __launch_bounds__(NTH) void stats_partial_kernel(const T* __restrict_
         a += smem[i * NTH + t + q * cvn];
         b += smem[(V + i) * NTH + t + q * cvn];
       }
-      out[2 * i] = a;
-      out[2 * i + 1] = b;
+      *reinterpret_cast<float2*>(partial + (((long long)cv * V + i) * nblk + blockIdx.x) * 2) = make_float2(a, b);
     }
   }
 }
 
-// Finalize kernels: a workgroup owns 32 consecutive channels (one 256-byte run of each partial row, read
-// coalesced as float2 by 32 lanes) and its 8 row-groups walk the nblk partial rows in parallel; fixed
-// summation order (deterministic), double accumulation.
-__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int rg,
-                                                double& a, double& b, double (*sm)[32][2]) {
-  a = 0.0;
-  b = 0.0;
-  if (c < C) {
-    for (int i = rg; i < nblk; i += 8) {
-      const float2 v = *reinterpret_cast<const float2*>(partial + ((long long)i * C + c) * 2);
-      a += (double)v.x;
-      b += (double)v.y;
+// Finalize kernels: ONE WAVE PER CHANNEL.  Partials are stored [C][nblk] (float2), so a channel's nblk
+// partial pairs are contiguous: each lane sums a strided subset (independent loads, no serial chain), then a
+// shuffle tree in double.  Fixed summation order -> deterministic.  4 channels per 256-thread workgroup.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partial, int nblk, int c, double& a,
+                                                double& b) {
+  const int lane = threadIdx.x & 63;
+  const float2* p = reinterpret_cast<const float2*>(partial) + (long long)c * nblk;
+  float fa = 0.0f, fb = 0.0f;
+  double da = 0.0, db = 0.0;
+  int cnt = 0;
+  for (int i = lane; i < nblk; i += 64) {
+    const float2 v = p[i];
+    fa += v.x;
+    fb += v.y;
+    if (++cnt == 4) {  // keep fp32 chains short (<= 4 terms) before widening
+      da += (double)fa; db += (double)fb; fa = fb = 0.0f; cnt = 0;
     }
   }
-  sm[rg][threadIdx.x & 31][0] = a;
-  sm[rg][threadIdx.x & 31][1] = b;
-  __syncthreads();
-  if (rg == 0) {
-    a = 0.0;
-    b = 0.0;
+  da += (double)fa;
+  db += (double)fb;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      a += sm[q][threadIdx.x & 31][0];
-      b += sm[q][threadIdx.x & 31][1];
-    }
+  for (int o = 32; o > 0; o >>= 1) {
+    da += __shfl_xor(da, o, 64);
+    db += __shfl_xor(db, o, 64);
   }
+  a = da;
+  b = db;
 }
 
 template <typename T>
@@ -142,11 +143,11 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const T* __restrict
                                                              const float* __restrict__ partial, int nblk, int C,
                                                              long long S, float eps, float* __restrict__ mean,
                                                              float* __restrict__ var, float* __restrict__ rstd) {
-  __shared__ double sm[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
   double a, b;
-  reduce_partials(partial, nblk, C, c, rg, a, b, sm);
-  if (rg != 0 || c >= C) return;
+  reduce_partials(partial, nblk, c, a, b);
+  if ((threadIdx.x & 63) != 0) return;
   float k;
   if (sizeof(T) == 2) k = bf2f(((const bf16_t*)x)[c]); else k = ((const float*)x)[c];
   const double n = (double)S;
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
   }
   __syncthreads();
   if (active && rloc == 0) {
-    float* out = partial + ((long long)blockIdx.x * C + (long long)cv * V) * 2;
+    // partial layout [C][nblk] float2: the finalize kernel then reads one channel's partials contiguously
+    const long long nblk = gridDim.x;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       float a = 0.0f, b = 0.0f;
@@ -251,8 +253,7 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
         a += smem[i * NTH + t + q * cvn];
         b += smem[(V + i) * NTH + t + q * cvn];
       }
-      out[2 * i] = a;
-      out[2 * i + 1] = b;
+      *reinterpret_cast<float2*>(partial + (((long long)cv * V + i) * nblk + blockIdx.x) * 2) = make_float2(a, b);
     }
   }
 }
@@ -261,11 +262,11 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
 __global__ __launch_bounds__(256) void act_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                long long S, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double sm[8][32][2];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
   double a, b;
-  reduce_partials(partial, nblk, C, c, rg, a, b, sm);
-  if (rg != 0 || c >= C) return;
+  reduce_partials(partial, nblk, c, a, b);
+  if ((threadIdx.x & 63) != 0) return;
   dbeta[c] = (float)a;
   dgamma[c] = (float)b;
   coef[2 * c] = (float)(a / (double)S);
@@ -364,12 +365,12 @@ extern "C" int mcl_bn_stats(const void* x, int64_t ld, int64_t S, int32_t C, int
   if (dtype == 1) {
     hipLaunchKernelGGL(stats_partial_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)x, (long long)ld,
                        (long long)S, C, (bf16_t*)copy_out, (long long)ld_out, workspace, rpb);
-    hipLaunchKernelGGL(stats_finalize_kernel<bf16_t>, dim3((C + 31) / 32), dim3(256), 0, st, (const bf16_t*)x,
+    hipLaunchKernelGGL(stats_finalize_kernel<bf16_t>, dim3((C + 3) / 4), dim3(256), 0, st, (const bf16_t*)x,
                        workspace, nblk, C, (long long)S, eps, mean, var, rstd);
   } else {
     hipLaunchKernelGGL(stats_partial_kernel<float>, grid, dim3(NTH), 0, st, (const float*)x, (long long)ld,
                        (long long)S, C, (float*)copy_out, (long long)ld_out, workspace, rpb);
-    hipLaunchKernelGGL(stats_finalize_kernel<float>, dim3((C + 31) / 32), dim3(256), 0, st, (const float*)x,
+    hipLaunchKernelGGL(stats_finalize_kernel<float>, dim3((C + 3) / 4), dim3(256), 0, st, (const float*)x,
                        workspace, nblk, C, (long long)S, eps, mean, var, rstd);
   }
   MCL_CHECK_LAUNCH();
@@ -413,7 +414,7 @@ extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64
   if (dtype == 1) {
     hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)dy, (long long)lddy,
                        (const bf16_t*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, workspace, rpb);
-    hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, workspace, nblk, C,
+    hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nblk, C,
                        (long long)S, dgamma, dbeta, coef);
     hipLaunchKernelGGL(act_bwd_dx_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)dy, (long long)lddy,
                        (const bf16_t*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
@@ -421,7 +422,7 @@ extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64
   } else {
     hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid, dim3(NTH), 0, st, (const float*)dy, (long long)lddy,
                        (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, workspace, rpb);
-    hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, workspace, nblk, C,
+    hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nblk, C,
                        (long long)S, dgamma, dbeta, coef);
     hipLaunchKernelGGL(act_bwd_dx_kernel<float>, grid, dim3(NTH), 0, st, (const float*)dy, (long long)lddy,
                        (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
