@@ -46,6 +46,7 @@ def parse():
                     help="MFMA operand type of the hand-written spot-path kernels")
     ap.add_argument("--backbone_dtype", type=str, default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay")
     ap.add_argument("--conv1x1", type=str, default="miopen", choices=["mm", "miopen"], help="A/B: 1x1 convs of the dense blocks")
     ap.add_argument("--unfused_backbone", action="store_true", help="A/B: plain torch module path for the backbone")
     ap.add_argument("--cpu_budget_s", type=float, default=15.0)
@@ -158,15 +159,17 @@ def main():
             b["image"] = b["image"].contiguous(memory_format=torch.channels_last)
         batches.append(b)
 
-    def step(i):
-        loss = model(batches[i % len(batches)])
-        opt.zero_grad()
-        loss.backward()
-        if reducer is not None:
-            reducer.reduce(opt)
-        opt.step()
-        return loss
+    from mclstexp_amd.engine import TrainStep
+    trainer = TrainStep(model, opt, reducer, graphs=not args.no_graphs, warmup=3)
 
+    def step(i):
+        return trainer(batches[i % len(batches)])
+
+    # setup (not part of the W warm-up steps): MIOpen solver search, flat optimizer bucket, HIP-graph capture
+    log("setup: 3 eager steps + graph capture")
+    for i in range(5 if not args.no_graphs else 2):
+        step(i)
+    torch.cuda.synchronize()
     log(f"model + inputs resident; warm-up {args.warmup} steps")
     for i in range(args.warmup):
         tw = time.perf_counter()
@@ -183,11 +186,14 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    t_host = time.perf_counter() - t0          # host enqueue time (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    log(f"host enqueue {1e3 * t_host / args.steps:.2f} ms/step, wall {1e3 * dt / args.steps:.2f} ms/step "
+        f"({'HOST-bound' if t_host > 0.9 * dt else 'GPU-bound'})")
     final_loss = float(loss.item())
     ev = opt.profile_events
     opt.profile_events = None
@@ -226,7 +232,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: train step, batch {args.batch}/GPU, {args.image}x{args.image} "
                                    f"patches, {args.genes} genes, {args.encoder} image encoder",
                        "global_batch": gb, "parallelism": f"dp{world}", "backbone_dtype": args.backbone_dtype,
-                       "spot_path_mfma": args.compute, "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
+                       "spot_path_mfma": args.compute, "hip_graphs": not args.no_graphs, "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
                        "final_loss": round(final_loss, 4)},
             "roofline": roof,
         }

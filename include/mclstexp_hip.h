@@ -156,12 +156,13 @@ int mcl_bn_stats(const void* x, int64_t ld, int64_t S, int32_t C, int32_t dtype,
 int mcl_bn_act_fwd(const void* x, int64_t ldx, int64_t S, int32_t C, int32_t dtype, const float* gamma,
                    const float* beta, const float* mean, const float* rstd, int32_t relu, void* y, int64_t ldy,
                    mcl_stream_t stream);
-/* g = dy*[y>0] (or dy); dgamma = sum g*xhat; dbeta = sum g;
+/* g = dy*[y>0] (or dy); dgamma (+)= sum g*xhat; dbeta (+)= sum g  (accumulate_params != 0 adds into the
+ * given buffers -- the parameters' .grad views of the flat optimizer bucket -- instead of overwriting);
  * dx (+)= gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))   (accumulate != 0: read-modify-write of dx) */
 int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t S, int32_t C, int32_t dtype,
                    const float* gamma, const float* beta, const float* mean, const float* rstd, int32_t relu,
-                   float* workspace, float* dgamma, float* dbeta, void* dx, int64_t lddx, int32_t accumulate,
-                   mcl_stream_t stream);
+                   float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx, int64_t lddx,
+                   int32_t accumulate, mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:

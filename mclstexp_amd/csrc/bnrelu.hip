@@ -261,14 +261,20 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
 // dbeta = sum g ; dgamma = sum g*xhat ; coef[c] = (sum g / S, sum g*xhat / S)
 __global__ __launch_bounds__(256) void act_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                                long long S, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
+                                                               float* __restrict__ dbeta, float* __restrict__ coef,
+                                                               int accumulate_params) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   double a, b;
   reduce_partials(partial, nblk, c, a, b);
   if ((threadIdx.x & 63) != 0) return;
-  dbeta[c] = (float)a;
-  dgamma[c] = (float)b;
+  if (accumulate_params) {  // straight into the parameters' .grad (flat optimizer bucket)
+    dbeta[c] += (float)a;
+    dgamma[c] += (float)b;
+  } else {
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+  }
   coef[2 * c] = (float)(a / (double)S);
   coef[2 * c + 1] = (float)(b / (double)S);
 }
@@ -399,7 +405,8 @@ extern "C" int mcl_bn_act_fwd(const void* x, int64_t ldx, int64_t S, int32_t C, 
 extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int64_t S, int32_t C,
                               int32_t dtype, const float* gamma, const float* beta, const float* mean,
                               const float* rstd, int32_t relu, float* workspace, float* dgamma, float* dbeta,
-                              void* dx, int64_t lddx, int32_t accumulate, mcl_stream_t stream) {
+                              int32_t accumulate_params, void* dx, int64_t lddx, int32_t accumulate,
+                              mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || S <= 0 || C <= 0 ||
       (dtype != 0 && dtype != 1))
@@ -415,7 +422,7 @@ extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64
     hipLaunchKernelGGL(act_bwd_reduce_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)dy, (long long)lddy,
                        (const bf16_t*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, workspace, rpb);
     hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nblk, C,
-                       (long long)S, dgamma, dbeta, coef);
+                       (long long)S, dgamma, dbeta, coef, accumulate_params);
     hipLaunchKernelGGL(act_bwd_dx_kernel<bf16_t>, grid, dim3(NTH), 0, st, (const bf16_t*)dy, (long long)lddy,
                        (const bf16_t*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
                        (bf16_t*)dx, (long long)lddx, accumulate, rpb);
@@ -423,7 +430,7 @@ extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64
     hipLaunchKernelGGL(act_bwd_reduce_kernel<float>, grid, dim3(NTH), 0, st, (const float*)dy, (long long)lddy,
                        (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, workspace, rpb);
     hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nblk, C,
-                       (long long)S, dgamma, dbeta, coef);
+                       (long long)S, dgamma, dbeta, coef, accumulate_params);
     hipLaunchKernelGGL(act_bwd_dx_kernel<float>, grid, dim3(NTH), 0, st, (const float*)dy, (long long)lddy,
                        (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
                        (float*)dx, (long long)lddx, accumulate, rpb);

@@ -21,6 +21,7 @@ Train-mode semantics of nn.BatchNorm2d are kept: batch statistics, running_mean 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -94,8 +95,17 @@ def bn_act_fwd(x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tenso
                                     rstd.data_ptr(), int(relu), po, ldo, _stream()), "mcl_bn_act_fwd")
 
 
+def _direct_grad_ok(p: Tensor) -> bool:
+    g = getattr(p, "grad", None)
+    return (g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape
+            and g.stride() == p.stride() and not g.requires_grad)
+
+
 def bn_act_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, relu: bool,
-               dx: Tensor, accumulate: bool) -> Tuple[Tensor, Tensor]:
+               dx: Tensor, accumulate: bool, into_param_grads: bool = False
+               ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """``into_param_grads``: add dgamma/dbeta straight into ``gamma.grad`` / ``beta.grad`` (they must exist:
+    the flat FusedAdam bucket) and return (None, None) -- no temporaries, no AccumulateGrad add kernels."""
     p, S, C, ld = _rows(x)
     pd, S2, C2, ldd = _rows(dy)
     px, S3, C3, ldx = _rows(dx)
@@ -103,12 +113,21 @@ def bn_act_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor,
     dt = _dt(x)
     L = _lib.lib()
     ws = _ws(L.mcl_bn_workspace_floats(S, C, dt), x.device)
-    dg = torch.empty(C, device=x.device, dtype=torch.float32)
-    db = torch.empty(C, device=x.device, dtype=torch.float32)
+    if into_param_grads:
+        dg, db = gamma.grad, beta.grad
+    else:
+        dg = torch.empty(C, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32)
     check(L.mcl_bn_act_bwd(pd, ldd, p, ld, S, C, dt, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
-                           rstd.data_ptr(), int(relu), ws.data_ptr(), dg.data_ptr(), db.data_ptr(), px, ldx,
-                           int(accumulate), _stream()), "mcl_bn_act_bwd")
-    return dg, db
+                           rstd.data_ptr(), int(relu), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                           int(into_param_grads), px, ldx, int(accumulate), _stream()), "mcl_bn_act_bwd")
+    return (None, None) if into_param_grads else (dg, db)
+
+
+# When a parameter already owns a dense fp32 .grad (FusedAdam's flat bucket, zeroed every step), backward
+# adds its gradient straight into it and returns None to autograd: saves one temporary, one dtype cast and
+# one AccumulateGrad add kernel per parameter (~480 tiny launches per DenseNet-121 step).
+DIRECT_PARAM_GRADS = os.environ.get("MCL_DIRECT_GRADS", "1") != "0"
 
 
 class BNActFn(torch.autograd.Function):
@@ -119,16 +138,19 @@ class BNActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, mean, rstd, relu):
         y = torch.empty_like(x, memory_format=CL)
         bn_act_fwd(x, gamma, beta, mean, rstd, relu, y)
-        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.save_for_backward(x, mean, rstd)
         ctx.relu = relu
+        ctx.params = (gamma, beta)      # the Parameter objects themselves (their .grad may be written directly)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
         dy = dy.contiguous(memory_format=CL)
         dx = torch.empty_like(x, memory_format=CL)
-        dg, db = bn_act_bwd(dy, x, gamma, beta, mean, rstd, ctx.relu, dx, False)
+        direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
+        dg, db = bn_act_bwd(dy, x, gamma, beta, mean, rstd, ctx.relu, dx, False, into_param_grads=direct)
         return dx, dg, db, None, None, None
 
 
@@ -206,6 +228,35 @@ def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
     return da, dw
 
 
+def _wgrad(w: Tensor, dw: Tensor) -> Optional[Tensor]:
+    """Weight gradient hand-over: add into an existing dense fp32 .grad (one mixed-dtype add kernel) or
+    return it to autograd in the parameter's dtype."""
+    if DIRECT_PARAM_GRADS and _direct_grad_ok(w):
+        w.grad.add_(dw)
+        return None
+    return dw.to(w.dtype)
+
+
+# Optional provider of low-precision weight copies: FusedAdam keeps every parameter in one flat fp32 buffer, so
+# ONE cast kernel per step yields a flat bf16 shadow whose views replace ~120 per-weight cast kernels.
+_weight_provider = None
+
+
+def set_weight_provider(fn) -> None:
+    global _weight_provider
+    _weight_provider = fn if os.environ.get("MCL_BF16_SHADOW", "1") != "0" else None
+
+
+def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
+    if w.dtype == dt:
+        return w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
+    if _weight_provider is not None:
+        v = _weight_provider(w, dt)
+        if v is not None:
+            return v if v.is_contiguous(memory_format=CL) else v.contiguous(memory_format=CL)
+    return w.to(dtype=dt, memory_format=CL)
+
+
 def _conv_bwd(dy, x, w, padding):
     return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [padding, padding], [1, 1], False, [0, 0], 1,
                                                [True, True, False])
@@ -236,13 +287,13 @@ class DenseBlockFn(torch.autograd.Function):
             cin = C0 + l * growth
             a = torch.empty((B, cin, H, W), device=dev, dtype=dt, memory_format=CL)
             bn_act_fwd(buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], True, a)
-            w1c = w1.to(dtype=dt, memory_format=CL)
+            w1c = _weight(w1, dt)
             z = _conv1x1_fwd(a, w1c)
             m2, v2, r2 = bn2_stats[l]
             bn_stats(z, m2, v2, r2, eps2[l])
             a2 = torch.empty_like(z, memory_format=CL)
             bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-            w2c = w2.to(dtype=dt, memory_format=CL)
+            w2c = _weight(w2, dt)
             y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
             c1 = cin + growth
             # eps of the NEXT consumer's norm1 is the same module default everywhere (1e-5); rstd is
@@ -251,7 +302,8 @@ class DenseBlockFn(torch.autograd.Function):
                      copy_out=buf[:, cin:c1])
             saved += [a, z, a2]
             wcast += [w1c, w2c]
-        ctx.save_for_backward(buf, *params, *saved, *wcast)
+        ctx.save_for_backward(buf, *saved, *wcast)
+        ctx.params = params             # Parameter objects (for direct .grad accumulation)
         ctx.meta = (stats, growth, bn2_stats, L, C0)
         return buf
 
@@ -260,9 +312,9 @@ class DenseBlockFn(torch.autograd.Function):
         stats, growth, bn2_stats, L, C0 = ctx.meta
         t = ctx.saved_tensors
         buf = t[0]
-        params = t[1: 1 + 6 * L]
-        saved = t[1 + 6 * L: 1 + 9 * L]
-        wcast = t[1 + 9 * L:]
+        params = ctx.params
+        saved = t[1: 1 + 3 * L]
+        wcast = t[1 + 3 * L:]
         # the incoming gradient is produced by our own BNActFn for the block's single consumer: accumulate
         # in place into it (no clone) when it is already a dense channels-last tensor
         if not gbuf.is_contiguous(memory_format=CL):
@@ -277,11 +329,14 @@ class DenseBlockFn(torch.autograd.Function):
             da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
             m2, v2, r2 = bn2_stats[l]
             dz = torch.empty_like(z, memory_format=CL)
-            dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False)
+            d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
+            dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
+                                  into_param_grads=d2)
             da, dw1 = _conv1x1_bwd(dz, a, w1c)
+            d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
             dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
-                                  stats.rstd[:cin], True, gbuf[:, :cin], True)
-            grads[6 * l: 6 * l + 6] = [dg1, db1, dw1.to(w1.dtype), dg2, db2, dw2.to(w2.dtype)]
+                                  stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
+            grads[6 * l: 6 * l + 6] = [dg1, db1, _wgrad(w1, dw1), dg2, db2, _wgrad(w2, dw2)]
         return (gbuf[:, :C0], None, *grads)
 
 

@@ -236,6 +236,27 @@ class _ContrastiveBase(nn.Module):
         return ops.InfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature), stash)
 
 
+    # ---- split form of forward(), used by engine.TrainStep (HIP-graph capture around the collectives)
+    def embed(self, batch):
+        """(spot_embeddings, image_embeddings): everything of forward() up to the logits."""
+        raise NotImplementedError
+
+    def loss_and_grads(self, spot_embeddings: Tensor, image_embeddings: Tensor):
+        """Eager (no autograd): (loss, dE_spot, dE_img) of the symmetric InfoNCE -- global over the process
+        group if one is set.  Forward and backward of model.py:242-247 in closed form."""
+        es, ei = spot_embeddings.detach(), image_embeddings.detach()
+        if self.capture:
+            self.last["spot_embeddings"], self.last["image_embeddings"] = es, ei
+        if self.process_group is not None:
+            from . import dist as mdist
+            loss, d_es, d_ei, s = mdist.dist_infonce_fwd_bwd(es, ei, float(self.temperature), self.process_group)
+        else:
+            loss, d_es, d_ei, s = ops.infonce_fwd_bwd(es, ei, float(self.temperature), want_logits=self.capture)
+        if self.capture:
+            self.last["logits"] = s
+        return loss, d_es, d_ei
+
+
 class mclSTExp_MLP(_ContrastiveBase):
     """model.py:171-198 (ablation without the spot encoder; attribute name ``image_ecode`` kept)."""
 
@@ -250,12 +271,15 @@ class mclSTExp_MLP(_ContrastiveBase):
         self.spot_projection = ProjectionHead(embedding_dim=spot_embedding, projection_dim=projection_dim)
         self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group)
 
-    def forward(self, batch):
+    def embed(self, batch):
         ops.set_compute(self.compute)
         image_features = self._encode_image(self.image_ecode, batch["image"])
         image_embeddings = self.image_projection(image_features)
         spot_embeddings = self.spot_projection(self._spot_features(batch))
-        return self._loss(spot_embeddings, image_embeddings)
+        return spot_embeddings, image_embeddings
+
+    def forward(self, batch):
+        return self._loss(*self.embed(batch))
 
 
 class mclSTExp_Attention(_ContrastiveBase):
@@ -276,14 +300,17 @@ class mclSTExp_Attention(_ContrastiveBase):
         self.spot_projection = ProjectionHead(embedding_dim=spot_dim, projection_dim=projection_dim)
         self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group)
 
-    def forward(self, batch):
+    def embed(self, batch):
         ops.set_compute(self.compute)
         image_features = self._encode_image(self.image_encoder, batch["image"])
         image_embeddings = self.image_projection(image_features)
         spot_features = self._spot_features(batch).unsqueeze(dim=0)        # (1, B, G): batch is the sequence
         spot_embeddings = self.spot_encoder(spot_features)
         spot_embeddings = self.spot_projection(spot_embeddings).squeeze(dim=0)
-        return self._loss(spot_embeddings, image_embeddings)
+        return spot_embeddings, image_embeddings
+
+    def forward(self, batch):
+        return self._loss(*self.embed(batch))
 
 
 def _make_encoder(encoder_name: str) -> nn.Module:

@@ -30,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_count = 0
         self._flat: Dict[int, dict] = {}          # group index -> flat buffers
         self._tables: Dict[int, dict] = {}        # id(param) -> table state
+        self._where: Dict[int, tuple] = {}        # id(param) -> (group index, element offset in the flat buffer)
         self._sink: Optional[dict] = None
         # bench.py sets this to a list to time every adam_table_kernel launch with HIP events recorded on
         # the launch stream: [(start_event, end_event), ...]
@@ -45,6 +46,9 @@ class FusedAdam(torch.optim.Optimizer):
                 self._tables[id(emb.weight)] = {"key": key, "param": emb.weight}
         if self.process_group is None:
             self.process_group = getattr(model, "process_group", None)
+        # bf16 shadow weights for the fused backbone: one flat cast per step instead of ~120 per-weight casts
+        from . import densenet_fused
+        densenet_fused.set_weight_provider(self.shadow)
         return self
 
     # ------------------------------------------------------------------ flat buffers
@@ -74,6 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
             vg.copy_(p.grad)        # copy_ is layout-aware: logical element (i,j,..) -> same logical slot
             p.data = vp
             p.grad = vg
+            self._where[id(p)] = (gi, o)
         self._flat[gi] = {"params": ps, "n": n, "p": flat_p, "g": flat_g,
                           "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p)}
 
@@ -84,6 +89,25 @@ class FusedAdam(torch.optim.Optimizer):
 
     def flat_param_ids(self) -> set:
         return {id(p) for f in self._flat.values() for p in f["params"]}
+
+    def shadow(self, p: Tensor, dtype: torch.dtype) -> Optional[Tensor]:
+        """Low-precision view of parameter ``p`` inside a flat shadow copy of the flat fp32 buffer (same
+        offsets/strides), refreshed by ONE cast kernel after every step.  None if ``p`` is not flat-managed."""
+        loc = self._where.get(id(p))
+        if loc is None:
+            return None
+        gi, off = loc
+        f = self._flat[gi]
+        key = "shadow_" + str(dtype)
+        if key not in f:
+            f[key] = f["p"].to(dtype)
+            f.setdefault("shadow_keys", []).append((key, dtype))
+        return f[key].as_strided(p.shape, p.stride(), off)
+
+    def _refresh_shadows(self) -> None:
+        for f in self._flat.values():
+            for key, _ in f.get("shadow_keys", []):
+                f[key].copy_(f["p"])
 
     def flat_grads(self) -> List[Tensor]:
         """Flat gradient buffers (the data-parallel all-reduce buckets)."""
@@ -146,7 +170,13 @@ class FusedAdam(torch.optim.Optimizer):
                                       state["exp_avg_sq"].data_ptr(), p.numel(), lr, b1, b2, eps, wd, bc1, bc2, st),
                       "mcl_adam_step")
         if self._sink is not None:
-            self._sink.clear()
+            if self._sink.get("static"):
+                # graph-captured backward: dout/ix/iy are static buffers refreshed by every replay
+                for k in ("g_dout", "g_ix", "g_iy"):
+                    self._sink.pop(k, None)
+            else:
+                self._sink.clear()
+        self._refresh_shadows()
         return loss
 
     # ------------------------------------------------------------------ tables

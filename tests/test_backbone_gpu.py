@@ -133,3 +133,47 @@ def test_model_uses_fused_backbone_and_matches_unfused():
     g1 = m.image_encoder.model[0].conv0.weight.grad
     g2 = m2.image_encoder.model[0].conv0.weight.grad
     assert (g1 - g2).abs().max() < 5e-3 * g2.abs().max()
+
+
+def test_direct_param_grads_and_bf16_shadow():
+    """FusedAdam's flat bucket lets the fused backbone (a) add gradients straight into .grad and (b) read bf16
+    weight views of ONE flat shadow cast.  (a) must equal the plain autograd hand-over; (b) must equal
+    p.to(bf16) after optimizer steps.  (bf16 trajectories themselves are chaotic -- two stock runs differ by
+    percents -- so gradients of one backward are compared in fp32.)"""
+    from mclstexp_amd import densenet_fused as dn, synth
+    from mclstexp_amd.model import mclSTExp_Attention
+    from mclstexp_amd.optim import FusedAdam
+    G = 171
+    torch.manual_seed(0)
+    m = mclSTExp_Attention("densenet121", 1.0, 1024, G, 256, 8, 64, 2, backbone_dtype=None, embedding_grad="rowsparse")
+    sd = m.state_dict()
+    sd.update(synth.make_params(G, 1024, seed=0))
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(8, G, image_hw=64, seed=0).items()}
+    # step 1 builds the flat bucket (plain hand-over: .grad does not exist yet)
+    loss = m(batch); opt.zero_grad(); loss.backward(); opt.step()
+    grads = []
+    for direct in (True, False):
+        dn.DIRECT_PARAM_GRADS = direct
+        try:
+            loss = m(batch)
+            opt.zero_grad()
+            loss.backward()
+        finally:
+            dn.DIRECT_PARAM_GRADS = True
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if n.startswith("image_encoder")})
+    worst = 0.0
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        worst = max(worst, ((a - b).abs().max() / (b.abs().max() + 1e-20)).item())
+    assert worst < 2e-2, worst          # MIOpen split-K weight-gradient kernels use atomics: not bit-reproducible
+    # shadow views follow the parameters
+    opt.step()
+    for n, p in m.named_parameters():
+        v = opt.shadow(p, torch.bfloat16)
+        if n.startswith("image_encoder"):
+            assert v is not None and v.shape == p.shape and v.stride() == p.stride()
+            assert torch.equal(v, p.detach().to(torch.bfloat16)), n
+    dn.set_weight_provider(None)
