@@ -164,6 +164,10 @@ int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int
                    float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx, int64_t lddx,
                    int32_t accumulate, mcl_stream_t stream);
 
+/* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
+ * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
+int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;

@@ -325,6 +325,18 @@ __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ d
   }
 }
 
+// dst[i] += (float)src[i] over n elements in storage order (both tensors dense with identical strides): hands
+// a bf16 / fp32 weight gradient to the fp32 .grad view of the flat optimizer bucket in one small launch.
+template <typename T>
+__global__ __launch_bounds__(256) void accum_kernel(float* __restrict__ dst, const T* __restrict__ src, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float v;
+    if (sizeof(T) == 2) v = bf2f(((const bf16_t*)src)[i]); else v = ((const float*)src)[i];
+    dst[i] += v;
+  }
+}
+
 inline int vec_of(int dtype) { return dtype == 1 ? 8 : 4; }
 inline bool ok_layout(const void* p, long long ld, int C, int dtype) {
   const int V = vec_of(dtype);
@@ -435,6 +447,21 @@ extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64
                        (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
                        (float*)dx, (long long)lddx, accumulate, rpb);
   }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dst || !src || n <= 0 || (src_dtype != 0 && src_dtype != 1)) return MCL_EINVAL;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (src_dtype == 1)
+    hipLaunchKernelGGL(accum_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), dst,
+                       (const bf16_t*)src, (long long)n);
+  else
+    hipLaunchKernelGGL(accum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), dst,
+                       (const float*)src, (long long)n);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -228,11 +228,24 @@ def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
     return da, dw
 
 
+def _same_order(a: Tensor, b: Tensor) -> bool:
+    """Same shape and same storage order (strides compared on dims of extent > 1 only), both dense."""
+    if a.shape != b.shape:
+        return False
+    sa = [s for s, n in zip(a.stride(), a.shape) if n > 1]
+    sb = [s for s, n in zip(b.stride(), b.shape) if n > 1]
+    dense = sorted(sa, reverse=True) and True
+    return sa == sb and dense
+
+
 def _wgrad(w: Tensor, dw: Tensor) -> Optional[Tensor]:
     """Weight gradient hand-over: add into an existing dense fp32 .grad (one mixed-dtype add kernel) or
     return it to autograd in the parameter's dtype."""
-    if DIRECT_PARAM_GRADS and _direct_grad_ok(w):
-        w.grad.add_(dw)
+    if DIRECT_PARAM_GRADS and _direct_grad_ok(w) and _same_order(dw, w.grad) and dw.dtype in (
+            torch.bfloat16, torch.float32):
+        # (a mixed-dtype torch add_ on the channels-last strided view costs 45 us per weight)
+        check(_lib.lib().mcl_accum_into_f32(w.grad.data_ptr(), dw.data_ptr(), dw.numel(), _dt(dw), _stream()),
+              "mcl_accum_into_f32")
         return None
     return dw.to(w.dtype)
 
