@@ -164,6 +164,15 @@ int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int
                    float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx, int64_t lddx,
                    int32_t accumulate, mcl_stream_t stream);
 
+/* 1x1-convolution weight gradient (DenseNet bottleneck conv1 / transition conv) on channels-last bf16:
+ *   dW[m][n] += sum_s dz[s][m] * a'[s][n],   a' = a, or relu(a*scale[n] + shift[n]) when scale/shift != NULL
+ * (BatchNorm+ReLU of the layer input recomputed on the fly from the concat buffer).  dz: (S, M) row stride
+ * ldz; a: (S, N) row stride lda; dW: (M, N) fp32, ACCUMULATED with float atomics (pass the parameter's
+ * .grad view).  M, N, ldz, lda multiples of 8; bases 16-byte aligned.  bf16 MFMA, fp32 accumulate.        */
+int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* scale,
+                         const float* shift, float* dW, int64_t lddw, int64_t S, int32_t M, int32_t N,
+                         mcl_stream_t stream);
+
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

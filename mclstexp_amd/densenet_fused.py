@@ -217,8 +217,32 @@ def _conv1x1_fwd(a: Tensor, w: Tensor) -> Tensor:
     return z.view(B, H, W, w.shape[0]).permute(0, 3, 1, 2)
 
 
-def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
+USE_HIP_WRW_1X1 = os.environ.get("MCL_HIP_WRW", "1") != "0"
+
+
+def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor) -> Optional[Tensor]:
+    """Weight gradient of a 1x1 convolution through csrc/conv1x1.hip.  Adds straight into ``w_param.grad``
+    when it is a dense fp32 tensor (returns None), else returns a fresh fp32 gradient."""
+    pz, S, M, ldz = _rows(dz)
+    pa, S2, N, lda = _rows(a)
+    assert S == S2 and dz.dtype == a.dtype == torch.bfloat16
+    if DIRECT_PARAM_GRADS and _direct_grad_ok(w_param) and w_param.grad.is_contiguous():
+        tgt, ret = w_param.grad, None
+    else:
+        tgt = torch.zeros((M, N, 1, 1), device=dz.device, dtype=torch.float32)
+        ret = tgt
+    check(_lib.lib().mcl_conv1x1_wrw_bf16(pz, ldz, pa, lda, None, None, tgt.data_ptr(), N, S, M, N, _stream()),
+          "mcl_conv1x1_wrw_bf16")
+    return ret
+
+
+def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Optional[Tensor] = None):
+    """(da, dw) -- dw is None when it was added straight into ``w_param.grad``."""
     if not USE_MM_1X1:
+        if USE_HIP_WRW_1X1 and w_param is not None and dz.dtype == torch.bfloat16:
+            da = torch.ops.aten.convolution_backward(dz, a, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+            return da.contiguous(memory_format=CL), ("direct", conv1x1_wrw(dz, a, w_param))
         da, dw, _ = _conv_bwd(dz, a, w, 0)
         return da.contiguous(memory_format=CL), dw
     B, C, H, W = a.shape
@@ -345,11 +369,12 @@ class DenseBlockFn(torch.autograd.Function):
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
                                   into_param_grads=d2)
-            da, dw1 = _conv1x1_bwd(dz, a, w1c)
+            da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
             d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
             dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
                                   stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
-            grads[6 * l: 6 * l + 6] = [dg1, db1, _wgrad(w1, dw1), dg2, db2, _wgrad(w2, dw2)]
+            gw1 = dw1[1] if isinstance(dw1, tuple) else _wgrad(w1, dw1)
+            grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, _wgrad(w2, dw2)]
         return (gbuf[:, :C0], None, *grads)
 
 

@@ -177,3 +177,28 @@ def test_direct_param_grads_and_bf16_shadow():
             assert v is not None and v.shape == p.shape and v.stride() == p.stride()
             assert torch.equal(v, p.detach().to(torch.bfloat16)), n
     dn.set_weight_provider(None)
+
+
+@pytest.mark.parametrize("S,M,N,lda", [(4096, 128, 256, 256), (1000, 128, 96, 96), (777, 128, 160, 416),
+                                        (50000, 128, 64, 64), (300, 256, 512, 512), (31, 128, 992, 1024)])
+def test_conv1x1_wrw_kernel(S, M, N, lda):
+    """dW = dz^T a on bf16 channels-last operands (LDS transpose-read MFMA kernel) vs fp64 of the same bf16 data;
+    ragged S, channel-sliced a (lda > N), N not a multiple of the 128 tile."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    g = torch.Generator().manual_seed(S + N)
+    dz = (torch.rand(S, M, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    wide = (torch.rand(S, lda, generator=g) - 0.3).to(torch.bfloat16).to(DEV)
+    a = wide[:, :N]
+    dW = torch.full((M, N), 0.25, device=DEV)          # accumulate semantics
+    _lib.check(_lib.lib().mcl_conv1x1_wrw_bf16(dz.data_ptr(), M, a.data_ptr(), lda, None, None, dW.data_ptr(), N, S,
+                                               M, N, dn._stream()))
+    ref = dz.double().t() @ a.double() + 0.25
+    assert_close_scaled(dW.cpu(), ref.cpu(), 2e-5, what="conv1x1 wrw")
+    # fused BN+ReLU prologue on a
+    sc = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    sh = (torch.rand(N, generator=g) - 0.5).to(DEV)
+    dW2 = torch.zeros((M, N), device=DEV)
+    _lib.check(_lib.lib().mcl_conv1x1_wrw_bf16(dz.data_ptr(), M, a.data_ptr(), lda, sc.data_ptr(), sh.data_ptr(),
+                                               dW2.data_ptr(), N, S, M, N, dn._stream()))
+    ap = torch.relu(a.float() * sc + sh).to(torch.bfloat16)
+    assert_close_scaled(dW2.cpu(), (dz.double().t() @ ap.double()).cpu(), 2e-5, what="conv1x1 wrw + prologue")
