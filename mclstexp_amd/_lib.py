@@ -63,6 +63,10 @@ PROTOTYPES = {
     "mcl_infonce_lse": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
     "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+    "mcl_infonce_fused_workspace_bytes": [c_i, c_i, c_i],
+    "mcl_infonce_fused_lse": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p],
+    "mcl_infonce_fused_grad": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
+    "mcl_cast_f32_to_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
     "mcl_bn_workspace_floats": [c_l, c_i, c_i],
     "mcl_bn_stats": [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_bn_act_fwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
@@ -73,7 +77,8 @@ PROTOTYPES = {
     "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
 }
-_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64}
+_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
+             "mcl_infonce_fused_workspace_bytes": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

@@ -389,6 +389,84 @@ def infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, want_logi
     return loss, d_es, d_ei, (S if want_logits else None)
 
 
+# --------------------------------------------------------------------------- fused InfoNCE (bf16 MFMA, no logits in HBM)
+FUSED_DIM = 256
+_fused_ws = {}
+
+
+def _fused_workspace(R: int, C: int, device) -> Tensor:
+    need = _lib.lib().mcl_infonce_fused_workspace_bytes(R, C, FUSED_DIM)
+    if need < 0:
+        raise RuntimeError(f"mcl_infonce_fused_workspace_bytes rejected R={R} C={C}")
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    w = _fused_ws.get(key)
+    if w is None or w.numel() < need:
+        w = torch.empty(max(int(need), 1 << 20), device=device, dtype=torch.uint8)
+        _fused_ws[key] = w
+    return w
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    """fp32 (rows, cols) -> contiguous bf16 copy (round to nearest even) on the HIP cast kernel."""
+    x = _rowmajor(x, "x")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(_lib.lib().mcl_cast_f32_to_bf16(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), x.shape[0],
+                                          x.shape[1], _stream()), "mcl_cast_f32_to_bf16")
+    return y
+
+
+def _bf16_rows(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous 2-D bf16 GPU tensor")
+    if t.shape[1] != FUSED_DIM:
+        raise RuntimeError(f"{name}: the fused InfoNCE kernel is built for projection_dim {FUSED_DIM}, "
+                           f"got {t.shape[1]}")
+    return t
+
+
+def infonce_fused_lse(a16: Tensor, b16: Tensor, inv_t: float, diag_off: int = 0) -> Tuple[Tensor, Tensor]:
+    """(lse (R,), diag (R,)) of S = a b^T * inv_t without materialising S (csrc/infonce_fused.hip)."""
+    a16, b16 = _bf16_rows(a16, "a"), _bf16_rows(b16, "b")
+    R, Cn = a16.shape[0], b16.shape[0]
+    lse = torch.empty((R,), device=a16.device, dtype=torch.float32)
+    diag = torch.zeros((R,), device=a16.device, dtype=torch.float32)
+    ws = _fused_workspace(R, Cn, a16.device)
+    check(_lib.lib().mcl_infonce_fused_lse(a16.data_ptr(), b16.data_ptr(), R, Cn, FUSED_DIM, diag_off, inv_t,
+                                           lse.data_ptr(), diag.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "mcl_infonce_fused_lse")
+    return lse, diag
+
+
+def infonce_fused_grad(a16: Tensor, b16: Tensor, inv_t: float, lse_a: Tensor, lse_b: Tensor, coef: float,
+                       diag_off: int = 0) -> Tensor:
+    """dA (R, 256) fp32 = coef * sum_c (exp(S-lse_a[r]) + exp(S-lse_b[c]) - 2[c == r+diag_off]) b[c]."""
+    a16, b16 = _bf16_rows(a16, "a"), _bf16_rows(b16, "b")
+    R, Cn = a16.shape[0], b16.shape[0]
+    assert lse_a.shape == (R,) and lse_b.shape == (Cn,) and lse_a.is_contiguous() and lse_b.is_contiguous()
+    dA = torch.empty((R, FUSED_DIM), device=a16.device, dtype=torch.float32)
+    ws = _fused_workspace(R, Cn, a16.device)
+    check(_lib.lib().mcl_infonce_fused_grad(a16.data_ptr(), b16.data_ptr(), R, Cn, FUSED_DIM, diag_off, inv_t,
+                                            _chk(lse_a).data_ptr(), _chk(lse_b).data_ptr(), coef, dA.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _stream()), "mcl_infonce_fused_grad")
+    return dA
+
+
+def infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
+                          ) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """Single-device symmetric InfoNCE on the fused bf16 kernels: (loss, dE_spot, dE_img, None).  Same closed
+    form as ``infonce_fwd_bwd``; the embeddings are rounded to bf16 once, logits never reach HBM."""
+    es16, ei16 = cast_bf16(e_spot), cast_bf16(e_img)
+    B = es16.shape[0]
+    inv_t = 1.0 / temperature
+    rl, diag = infonce_fused_lse(es16, ei16, inv_t)
+    cl, _ = infonce_fused_lse(ei16, es16, inv_t)
+    loss = ((rl - diag).sum() + (cl - diag).sum()) / (2.0 * B)
+    coef = inv_t / (2.0 * B)
+    d_es = infonce_fused_grad(es16, ei16, inv_t, rl, cl, coef)
+    d_ei = infonce_fused_grad(ei16, es16, inv_t, cl, rl, coef)
+    return loss, d_es, d_ei, None
+
+
 class InfoNCEFn(torch.autograd.Function):
     """loss = 0.5*[CE(S, I) + CE(S^T, I)], S = E_spot E_img^T / T.  Forward and backward are computed
     together (closed-form dS from the two LSE vectors); autograd's backward only scales by grad_output."""

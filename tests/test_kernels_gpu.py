@@ -285,3 +285,75 @@ def test_attn_block_and_head_vs_oracle(ops, B, G):
     for k in pr:
         if k.startswith(h):
             assert_close_scaled(pd[k].grad.cpu(), pr[k].grad, 2e-5, what="grad " + k)
+
+
+# ------------------------------------------------------------------ fused InfoNCE (bf16 MFMA, logits never in HBM)
+def _fused_ref(a, b, inv_t, diag_off, lse_b=None):
+    """fp64 reference on the bf16-rounded operands: (lse, diag, dA/coef given lse_b)."""
+    a64, b64 = a.bfloat16().double(), b.bfloat16().double()
+    S = a64 @ b64.t() * inv_t
+    lse = torch.logsumexp(S, dim=1)
+    R, C = S.shape
+    idx = torch.arange(R)
+    ok = (idx + diag_off >= 0) & (idx + diag_off < C)
+    diag = torch.zeros(R, dtype=torch.float64)
+    diag[ok] = S[idx[ok], idx[ok] + diag_off]
+    dA = None
+    if lse_b is not None:
+        w = torch.exp(S - lse[:, None]) + torch.exp(S - lse_b.double()[None, :])
+        w[idx[ok], idx[ok] + diag_off] -= 2.0
+        dA = w @ b64
+    return lse, diag, dA
+
+
+@pytest.mark.parametrize("R,C,T,doff", [(128, 128, 1.0, 0), (33, 33, 0.5, 0), (256, 1024, 1.0, 512), (200, 333, 2.0, 100),
+                                        (1, 1, 1.0, 0), (512, 512, 1.0, 0), (128, 2048, 1.0, 1920)])
+def test_infonce_fused_strip(ops, R, C, T, doff):
+    """One orientation of the fused kernel (rows = own embeddings, columns = the other side's), including
+    ragged tiles, the split over column ranges and a data-parallel diagonal offset."""
+    P = 256
+    g = torch.Generator().manual_seed(R * 7 + C)
+    a = torch.nn.functional.layer_norm(torch.randn(R, P, generator=g), (P,))
+    b = torch.nn.functional.layer_norm(torch.randn(C, P, generator=g), (P,))
+    n_pos = max(0, min(R, C - doff))
+    b[doff: doff + n_pos] += 0.08 * a[:n_pos]                # positive pairs correlate (not saturated)
+    inv_t = 1.0 / T
+    lse_b = torch.logsumexp((b.bfloat16().double() @ a.bfloat16().double().t()) * inv_t, dim=1).float()
+    lse_ref, diag_ref, dA_ref = _fused_ref(a, b, inv_t, doff, lse_b)
+    a16, b16 = ops.cast_bf16(a.to(DEV)), ops.cast_bf16(b.to(DEV))
+    assert torch.equal(a16.cpu(), a.bfloat16()), "cast kernel is round-to-nearest-even"
+    lse, diag = ops.infonce_fused_lse(a16, b16, inv_t, doff)
+    # logits reach +-(16*16)/T; fp32 accumulation of exact bf16 products
+    assert_close(lse.cpu(), lse_ref, 2e-4 * max(1.0, inv_t), what="fused lse")
+    idx = torch.arange(R)
+    ok = (idx + doff < C)
+    assert_close(diag.cpu()[ok], diag_ref[ok], 2e-4 * max(1.0, inv_t), what="fused diag")
+    dA = ops.infonce_fused_grad(a16, b16, inv_t, lse_ref.float().to(DEV), lse_b.to(DEV), 1.0, doff)
+    # w is rounded to bf16 before the second contraction: 2^-9 relative per term
+    # + an absolute floor: exponent arguments carry ~1e-5 of fp32 rounding at |logit| ~ 100
+    assert_close(dA.cpu(), dA_ref, 6e-3 * float(dA_ref.abs().max()) + 2e-3, what="fused dA")
+
+
+def test_infonce_fused_matches_unfused_loss_and_grads(ops):
+    """Whole symmetric loss: fused bf16 path vs the exact-fp32 unfused kernels on bf16-representable inputs."""
+    B, P = 384, 256
+    g = torch.Generator().manual_seed(5)
+    es = torch.nn.functional.layer_norm(torch.randn(B, P, generator=g), (P,)).bfloat16().float()
+    ei = torch.nn.functional.layer_norm(torch.randn(B, P, generator=g) + 0.08 * es, (P,)).bfloat16().float()
+    loss_u, des_u, dei_u, _ = ops.infonce_fwd_bwd(es.to(DEV), ei.to(DEV), 1.0)
+    loss_f, des_f, dei_f, _ = ops.infonce_fused_fwd_bwd(es.to(DEV), ei.to(DEV), 1.0)
+    assert abs(loss_f.item() - loss_u.item()) < 2e-4 * max(1.0, abs(loss_u.item()))
+    assert_close_scaled(des_f.cpu(), des_u.cpu(), 6e-3, what="dE_spot fused vs exact")
+    assert_close_scaled(dei_f.cpu(), dei_u.cpu(), 6e-3, what="dE_img fused vs exact")
+
+
+def test_infonce_fused_spike_forces_rescale(ops):
+    """One column far above the running maximum in a LATER tile: the online (max, sum) rescale must fire."""
+    R, C, P = 64, 640, 256
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(R, P, generator=g) * 0.1
+    b = torch.randn(C, P, generator=g) * 0.1
+    b[600] = a[7] * 300.0          # huge logit for row 7 in the last tile
+    lse_ref, _, _ = _fused_ref(a, b, 1.0, 0)
+    lse, _ = ops.infonce_fused_lse(ops.cast_bf16(a.to(DEV)), ops.cast_bf16(b.to(DEV)), 1.0, 0)
+    assert_close(lse.cpu(), lse_ref, 1e-3, rtol=1e-5, what="lse with a late spike")
