@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--image_dim", type=int, default=1024)
     ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16"],
                     help="MFMA operand type of the hand-written spot-path kernels")
+    ap.add_argument("--infonce", type=str, default="fused", choices=["fused", "exact"],
+                    help="fused = flash-style bf16 MFMA InfoNCE (logits never in HBM); exact = fp32 GEMM + LSE kernels")
     ap.add_argument("--backbone_dtype", type=str, default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay")
@@ -139,7 +141,7 @@ def main():
     bb = torch.bfloat16 if args.backbone_dtype == "bf16" else None
     model = mclSTExp_Attention(args.encoder, 1.0, args.image_dim, args.genes, 256, 8, 64, 2, compute=args.compute,
                                backbone_dtype=bb, embedding_grad="rowsparse",
-                               process_group=pg if world > 1 else None)
+                               process_group=pg if world > 1 else None, infonce=args.infonce)
     from mclstexp_amd import densenet_fused
     densenet_fused.USE_MM_1X1 = args.conv1x1 == "mm"
     model.fused_backbone = not args.unfused_backbone
@@ -232,7 +234,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: train step, batch {args.batch}/GPU, {args.image}x{args.image} "
                                    f"patches, {args.genes} genes, {args.encoder} image encoder",
                        "global_batch": gb, "parallelism": f"dp{world}", "backbone_dtype": args.backbone_dtype,
-                       "spot_path_mfma": args.compute, "hip_graphs": not args.no_graphs, "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
+                       "spot_path_mfma": args.compute, "infonce": args.infonce, "hip_graphs": not args.no_graphs, "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
                        "final_loss": round(final_loss, 4)},
             "roofline": roof,
         }

@@ -141,7 +141,8 @@ int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const
 
 /* ---------------------------------------------------------------- K8 fused InfoNCE (model.py:242-247), bf16 MFMA
  * The same loss without ever writing the logits to HBM (flash-attention-shaped; csrc/infonce_fused.hip).
- * a: (R, dim) and b: (C, dim) bf16, contiguous rows, dim == 256 (projection_dim); S = a b^T * inv_temp.
+ * a: (R, dim) and b: (C, dim) bf16 with row strides lda / ldb (elements, multiples of 8; bases 16-byte
+ * aligned), dim == 256 (projection_dim); S = a b^T * inv_temp.
  * The positive pair of local row r is column r + diag_off (data parallel: rank * B_loc).  Calling with (a, b)
  * = (E_spot, E_img) gives the row direction of the symmetric loss, with (E_img, E_spot) the column direction.
  *
@@ -152,11 +153,11 @@ int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const
  *   i.e. d loss / d a with coef = inv_temp / (2*B_glob): the closed-form backward of model.py:244-247.
  * workspace: mcl_infonce_fused_workspace_bytes(R, C, dim) bytes of device memory, 16-byte aligned.       */
 int64_t mcl_infonce_fused_workspace_bytes(int32_t R, int32_t C, int32_t dim);
-int mcl_infonce_fused_lse(const void* a, const void* b, int32_t R, int32_t C, int32_t dim, int32_t diag_off,
-                          float inv_temp, float* lse, float* diag, void* workspace, int64_t ws_bytes,
+int mcl_infonce_fused_lse(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t R, int32_t C, int32_t dim,
+                          int32_t diag_off, float inv_temp, float* lse, float* diag, void* workspace, int64_t ws_bytes,
                           mcl_stream_t stream);
-int mcl_infonce_fused_grad(const void* a, const void* b, int32_t R, int32_t C, int32_t dim, int32_t diag_off,
-                           float inv_temp, const float* lse_a, const float* lse_b, float coef, float* dA,
+int mcl_infonce_fused_grad(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t R, int32_t C, int32_t dim,
+                           int32_t diag_off, float inv_temp, const float* lse_a, const float* lse_b, float coef, float* dA,
                            void* workspace, int64_t ws_bytes, mcl_stream_t stream);
 /* y (bf16, row stride ldy) = round-to-nearest-even(x (fp32, row stride ldx)); cols % 8 == 0.             */
 int mcl_cast_f32_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols,

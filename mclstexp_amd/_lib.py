@@ -64,8 +64,8 @@ PROTOTYPES = {
     "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
     "mcl_infonce_fused_workspace_bytes": [c_i, c_i, c_i],
-    "mcl_infonce_fused_lse": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p],
-    "mcl_infonce_fused_grad": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
+    "mcl_infonce_fused_lse": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p],
+    "mcl_infonce_fused_grad": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
     "mcl_cast_f32_to_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
     "mcl_bn_workspace_floats": [c_l, c_i, c_i],
     "mcl_bn_stats": [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],

@@ -176,10 +176,59 @@ def dist_infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, 
     return loss, d_es, d_ei, s_rows
 
 
+# --------------------------------------------------------------------------- fused (bf16, logits never in HBM)
+class HipFusedPrims:
+    """csrc/infonce_fused.hip behind the three primitives of the fused data-parallel InfoNCE."""
+
+    @staticmethod
+    def cast(x: Tensor) -> Tensor:
+        from . import ops
+        return ops.cast_bf16(x)
+
+    @staticmethod
+    def lse(a16: Tensor, b16: Tensor, inv_t: float, diag_off: int) -> Tuple[Tensor, Tensor]:
+        from . import ops
+        return ops.infonce_fused_lse(a16, b16, inv_t, diag_off)
+
+    @staticmethod
+    def grad(a16: Tensor, b16: Tensor, inv_t: float, lse_a: Tensor, lse_b: Tensor, coef: float, diag_off: int) -> Tensor:
+        from . import ops
+        return ops.infonce_fused_grad(a16, b16, inv_t, lse_a, lse_b, coef, diag_off)
+
+
+def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipFusedPrims
+                               ) -> Tuple[Tensor, Tensor, Tensor, None]:
+    """Same global symmetric InfoNCE as ``dist_infonce_fwd_bwd`` on the fused kernels: the embeddings are rounded
+    to bf16 BEFORE the all-gather (half the bytes on xGMI), each rank runs the strip kernel in both orientations
+    (own spots vs all images: row LSEs + dE_spot; own images vs all spots: column LSEs + dE_img) and no logits
+    strip is ever written.  Still two collectives: [E_spot | E_img] bf16, then [row_lse | col_lse | diag]."""
+    world, rank = td.get_world_size(pg), td.get_rank(pg)
+    b_loc, P = e_spot.shape
+    b_glob = world * b_loc
+    doff = rank * b_loc
+    inv_t = 1.0 / temperature
+    loc16 = torch.cat([prims.cast(e_spot), prims.cast(e_img)], dim=1)       # (B_loc, 2P) bf16
+    all16 = _all_gather_cat(loc16, pg)                                       # collective 1: (B_glob, 2P) bf16
+    es_loc, ei_loc = loc16[:, :P], loc16[:, P:]                              # row stride 2P: read in place
+    es_all, ei_all = all16[:, :P], all16[:, P:]
+    rl, diag = prims.lse(es_loc, ei_all, inv_t, doff)                        # rows of S owned by this rank
+    cl, _ = prims.lse(ei_loc, es_all, inv_t, doff)                           # columns of S owned by this rank
+    packed = _all_gather_cat(torch.stack([rl, cl, diag]).unsqueeze(0), pg)   # collective 2: (W, 3, B_loc)
+    rl_all = packed[:, 0].reshape(-1).contiguous()
+    cl_all = packed[:, 1].reshape(-1).contiguous()
+    diag_all = packed[:, 2].reshape(-1)
+    loss = ((rl_all - diag_all).sum() + (cl_all - diag_all).sum()) / (2.0 * b_glob)
+    coef = inv_t / (2.0 * b_glob)
+    d_es = prims.grad(es_loc, ei_all, inv_t, rl, cl_all, coef, doff)
+    d_ei = prims.grad(ei_loc, es_all, inv_t, cl, rl_all, coef, doff)
+    return loss, d_es, d_ei, None
+
+
 class DistInfoNCEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, e_spot, e_img, temperature, pg, stash):
-        loss, d_es, d_ei, s_rows = dist_infonce_fwd_bwd(e_spot, e_img, temperature, pg)
+    def forward(ctx, e_spot, e_img, temperature, pg, stash, fused=False):
+        fn = dist_infonce_fused_fwd_bwd if fused else dist_infonce_fwd_bwd
+        loss, d_es, d_ei, s_rows = fn(e_spot, e_img, temperature, pg)
         if stash is not None:
             stash["logits"] = s_rows
         ctx.save_for_backward(d_es, d_ei)
@@ -188,7 +237,7 @@ class DistInfoNCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         d_es, d_ei = ctx.saved_tensors
-        return d_es * gl, d_ei * gl, None, None, None
+        return d_es * gl, d_ei * gl, None, None, None, None
 
 
 # --------------------------------------------------------------------------- gradient exchange

@@ -14,7 +14,9 @@ Differences from the reference, all deliberate:
   * keyword-only extras: ``compute`` ("f32" exact / "bf16" MFMA), ``backbone_dtype`` (autocast dtype
     for the delegated backbone), ``embedding_grad`` ("dense" = stock-optimizer compatible,
     "rowsparse" = hand the 2 x (65536, G) tables' gradients to FusedAdam as touched rows only),
-    ``process_group`` (data-parallel global InfoNCE).
+    ``process_group`` (data-parallel global InfoNCE), ``infonce`` ("exact" = fp32 logits through the
+    GEMM + LSE kernels, the reference's numerics; "fused" = flash-style bf16 MFMA kernel that never writes the
+    B x B logits, csrc/infonce_fused.hip).
 """
 from __future__ import annotations
 
@@ -192,8 +194,12 @@ def ops_gelu(x: Tensor) -> Tensor:
 class _ContrastiveBase(nn.Module):
     """Shared forward tail of mclSTExp_Attention / mclSTExp_MLP (model.py:187-198, 225-247)."""
 
-    def _init_common(self, temperature, compute, backbone_dtype, embedding_grad, process_group):
+    def _init_common(self, temperature, compute, backbone_dtype, embedding_grad, process_group, infonce="exact"):
         self.temperature = temperature
+        if infonce not in ("exact", "fused"):
+            raise ValueError("infonce must be 'exact' (fp32 logits, reference numerics) or 'fused' (bf16 MFMA, "
+                             "logits never written to HBM)")
+        self.infonce = infonce
         if embedding_grad not in ("dense", "rowsparse"):
             raise ValueError("embedding_grad must be 'dense' or 'rowsparse'")
         self.compute = compute
@@ -232,8 +238,9 @@ class _ContrastiveBase(nn.Module):
         if self.process_group is not None:
             from . import dist as mdist
             return mdist.DistInfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature),
-                                             self.process_group, stash)
-        return ops.InfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature), stash)
+                                             self.process_group, stash, self.infonce == "fused")
+        return ops.InfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature), stash,
+                                   self.infonce == "fused")
 
 
     # ---- split form of forward(), used by engine.TrainStep (HIP-graph capture around the collectives)
@@ -247,9 +254,13 @@ class _ContrastiveBase(nn.Module):
         es, ei = spot_embeddings.detach(), image_embeddings.detach()
         if self.capture:
             self.last["spot_embeddings"], self.last["image_embeddings"] = es, ei
+        fused = self.infonce == "fused"
         if self.process_group is not None:
             from . import dist as mdist
-            loss, d_es, d_ei, s = mdist.dist_infonce_fwd_bwd(es, ei, float(self.temperature), self.process_group)
+            fn = mdist.dist_infonce_fused_fwd_bwd if fused else mdist.dist_infonce_fwd_bwd
+            loss, d_es, d_ei, s = fn(es, ei, float(self.temperature), self.process_group)
+        elif fused:
+            loss, d_es, d_ei, s = ops.infonce_fused_fwd_bwd(es, ei, float(self.temperature))
         else:
             loss, d_es, d_ei, s = ops.infonce_fwd_bwd(es, ei, float(self.temperature), want_logits=self.capture)
         if self.capture:
@@ -262,14 +273,14 @@ class mclSTExp_MLP(_ContrastiveBase):
 
     def __init__(self, temperature, image_embedding, spot_embedding, projection_dim, dropout=0., *,
                  encoder_name="densenet121", compute="f32", backbone_dtype=None, embedding_grad="dense",
-                 process_group=None):
+                 process_group=None, infonce="exact"):
         super().__init__()
         self.x_embed = nn.Embedding(65536, spot_embedding)
         self.y_embed = nn.Embedding(65536, spot_embedding)
         self.image_ecode = _make_encoder(encoder_name)
         self.image_projection = ProjectionHead(embedding_dim=image_embedding, projection_dim=projection_dim)
         self.spot_projection = ProjectionHead(embedding_dim=spot_embedding, projection_dim=projection_dim)
-        self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group)
+        self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group, infonce)
 
     def embed(self, batch):
         ops.set_compute(self.compute)
@@ -287,7 +298,7 @@ class mclSTExp_Attention(_ContrastiveBase):
 
     def __init__(self, encoder_name, temperature, image_dim, spot_dim, projection_dim, heads_num, heads_dim,
                  head_layers, dropout=0., *, compute="f32", backbone_dtype=None, embedding_grad="dense",
-                 process_group=None):
+                 process_group=None, infonce="exact"):
         super().__init__()
         self.x_embed = nn.Embedding(65536, spot_dim)
         self.y_embed = nn.Embedding(65536, spot_dim)
@@ -298,7 +309,7 @@ class mclSTExp_Attention(_ContrastiveBase):
               for _ in range(head_layers)])
         self.image_projection = ProjectionHead(embedding_dim=image_dim, projection_dim=projection_dim)
         self.spot_projection = ProjectionHead(embedding_dim=spot_dim, projection_dim=projection_dim)
-        self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group)
+        self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group, infonce)
 
     def embed(self, batch):
         ops.set_compute(self.compute)

@@ -416,8 +416,10 @@ def cast_bf16(x: Tensor) -> Tensor:
 
 
 def _bf16_rows(t: Tensor, name: str) -> Tensor:
-    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or not t.is_contiguous():
-        raise RuntimeError(f"{name}: expected a contiguous 2-D bf16 GPU tensor")
+    """2-D bf16 GPU tensor with unit column stride (a row stride is allowed: column slices of a wider buffer)."""
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or \
+            t.data_ptr() % 16:
+        raise RuntimeError(f"{name}: expected a 2-D bf16 GPU tensor with unit column stride, 16-byte aligned rows")
     if t.shape[1] != FUSED_DIM:
         raise RuntimeError(f"{name}: the fused InfoNCE kernel is built for projection_dim {FUSED_DIM}, "
                            f"got {t.shape[1]}")
@@ -431,7 +433,7 @@ def infonce_fused_lse(a16: Tensor, b16: Tensor, inv_t: float, diag_off: int = 0)
     lse = torch.empty((R,), device=a16.device, dtype=torch.float32)
     diag = torch.zeros((R,), device=a16.device, dtype=torch.float32)
     ws = _fused_workspace(R, Cn, a16.device)
-    check(_lib.lib().mcl_infonce_fused_lse(a16.data_ptr(), b16.data_ptr(), R, Cn, FUSED_DIM, diag_off, inv_t,
+    check(_lib.lib().mcl_infonce_fused_lse(a16.data_ptr(), a16.stride(0), b16.data_ptr(), b16.stride(0), R, Cn, FUSED_DIM, diag_off, inv_t,
                                            lse.data_ptr(), diag.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
           "mcl_infonce_fused_lse")
     return lse, diag
@@ -445,7 +447,7 @@ def infonce_fused_grad(a16: Tensor, b16: Tensor, inv_t: float, lse_a: Tensor, ls
     assert lse_a.shape == (R,) and lse_b.shape == (Cn,) and lse_a.is_contiguous() and lse_b.is_contiguous()
     dA = torch.empty((R, FUSED_DIM), device=a16.device, dtype=torch.float32)
     ws = _fused_workspace(R, Cn, a16.device)
-    check(_lib.lib().mcl_infonce_fused_grad(a16.data_ptr(), b16.data_ptr(), R, Cn, FUSED_DIM, diag_off, inv_t,
+    check(_lib.lib().mcl_infonce_fused_grad(a16.data_ptr(), a16.stride(0), b16.data_ptr(), b16.stride(0), R, Cn, FUSED_DIM, diag_off, inv_t,
                                             _chk(lse_a).data_ptr(), _chk(lse_b).data_ptr(), coef, dA.data_ptr(),
                                             ws.data_ptr(), ws.numel(), _stream()), "mcl_infonce_fused_grad")
     return dA
@@ -472,8 +474,11 @@ class InfoNCEFn(torch.autograd.Function):
     together (closed-form dS from the two LSE vectors); autograd's backward only scales by grad_output."""
 
     @staticmethod
-    def forward(ctx, e_spot, e_img, temperature, stash):
-        loss, d_es, d_ei, S = infonce_fwd_bwd(e_spot, e_img, temperature, want_logits=stash is not None)
+    def forward(ctx, e_spot, e_img, temperature, stash, fused=False):
+        if fused:
+            loss, d_es, d_ei, S = infonce_fused_fwd_bwd(e_spot, e_img, temperature)
+        else:
+            loss, d_es, d_ei, S = infonce_fwd_bwd(e_spot, e_img, temperature, want_logits=stash is not None)
         if stash is not None:
             stash["logits"] = S
         ctx.save_for_backward(d_es, d_ei)
@@ -482,4 +487,4 @@ class InfoNCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         d_es, d_ei = ctx.saved_tensors
-        return d_es * gl, d_ei * gl, None, None
+        return d_es * gl, d_ei * gl, None, None, None

@@ -99,6 +99,59 @@ def test_dist_infonce_equals_single_process(world):
         assert torch.allclose(d_ei, ei.grad[sl], atol=1e-6)
 
 
+class OracleFusedPrims:
+    """CPU restatement of dist.HipFusedPrims (tests only): bf16-rounded operands, fp64 arithmetic."""
+
+    @staticmethod
+    def cast(x):
+        return x.bfloat16()
+
+    @staticmethod
+    def lse(a16, b16, inv_t, diag_off):
+        S = (a16.double() @ b16.double().t()) * inv_t
+        idx = torch.arange(S.shape[0])
+        return torch.logsumexp(S, dim=1).float(), S[idx, idx + diag_off].float()
+
+    @staticmethod
+    def grad(a16, b16, inv_t, lse_a, lse_b, coef, diag_off):
+        S = (a16.double() @ b16.double().t()) * inv_t
+        w = torch.exp(S - lse_a.double()[:, None]) + torch.exp(S - lse_b.double()[None, :])
+        idx = torch.arange(S.shape[0])
+        w[idx, idx + diag_off] -= 2.0
+        return (coef * (w @ b16.double())).float()
+
+
+def _fused_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    b_loc, P, T = 6, 32, 0.7
+    g = torch.Generator().manual_seed(4321)
+    es_all = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,)).bfloat16().float()
+    ei_all = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,)).bfloat16().float()
+    sl = slice(rank * b_loc, (rank + 1) * b_loc)
+    loss, d_es, d_ei, _ = mdist.dist_infonce_fused_fwd_bwd(es_all[sl].clone(), ei_all[sl].clone(), T, td.group.WORLD,
+                                                           prims=OracleFusedPrims)
+    return loss.item(), d_es, d_ei
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_fused_infonce_equals_single_process(world):
+    """The fused data-parallel decomposition (bf16 all-gather, two strip orientations per rank, LSE exchange)
+    reproduces the single-process loss and gradients on bf16-representable embeddings."""
+    outs = _spawn(_fused_case, world)
+    b_loc, P, T = 6, 32, 0.7
+    g = torch.Generator().manual_seed(4321)
+    es = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,)).bfloat16().float()
+    ei = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,)).bfloat16().float()
+    es.requires_grad_(True); ei.requires_grad_(True)
+    loss = ref_cpu.symmetric_infonce(ref_cpu.logits(es, ei, T))
+    loss.backward()
+    for r, (l, d_es, d_ei) in enumerate(outs):
+        sl = slice(r * b_loc, (r + 1) * b_loc)
+        assert abs(l - loss.item()) < 1e-5
+        assert torch.allclose(d_es, es.grad[sl], atol=2e-6), (d_es - es.grad[sl]).abs().max()
+        assert torch.allclose(d_ei, ei.grad[sl], atol=2e-6)
+
+
 def _rows_case(rank, world):
     from mclstexp_amd import dist as mdist
     g = torch.Generator().manual_seed(7 + rank)

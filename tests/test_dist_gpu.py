@@ -35,6 +35,8 @@ def _worker(rank, world, port, ret):
         ei_all = torch.nn.functional.layer_norm(torch.randn(world * b_loc, P, generator=g), (P,))
         sl = slice(rank * b_loc, (rank + 1) * b_loc)
         loss, d_es, d_ei, _ = mdist.dist_infonce_fwd_bwd(es_all[sl].cuda(), ei_all[sl].cuda(), T, pg)
+        # (a') the same through the fused bf16 strip kernels (row stride 2P views of the gathered buffer)
+        loss_f, d_es_f, d_ei_f, _ = mdist.dist_infonce_fused_fwd_bwd(es_all[sl].cuda(), ei_all[sl].cuda(), T, pg)
         # (b) two full DP training steps, identity encoder, G=171
         G, D, B = 171, 1024, 8
         m = mclSTExp_Attention("identity", 1.0, D, G, 256, 8, 64, 2, embedding_grad="rowsparse", process_group=pg)
@@ -53,7 +55,8 @@ def _worker(rank, world, port, ret):
             losses.append(l.item())
         chk = {n: p.detach().double().sum().item() for n, p in m.named_parameters()}
         touched = m.x_embed.weight.detach()[:64].cpu()
-        ret[rank] = dict(loss=loss.item(), d_es=d_es.cpu(), d_ei=d_ei.cpu(), losses=losses, chk=chk, xrows=touched)
+        ret[rank] = dict(loss=loss.item(), d_es=d_es.cpu(), d_ei=d_ei.cpu(), losses=losses, chk=chk, xrows=touched,
+                         loss_f=loss_f.item(), d_es_f=d_es_f.cpu(), d_ei_f=d_ei_f.cpu())
     finally:
         td.destroy_process_group()
 
@@ -75,6 +78,16 @@ def test_two_rank_dp_step_on_one_gpu():
         assert abs(ret[r]["loss"] - ref.item()) < 1e-4
         assert (ret[r]["d_es"].double() - es.grad[sl]).abs().max() < 1e-4 * es.grad.abs().max() + 1e-8
         assert (ret[r]["d_ei"].double() - ei.grad[sl]).abs().max() < 1e-4 * ei.grad.abs().max() + 1e-8
+    # fused bf16 path against the same math on bf16-rounded embeddings
+    es16 = es.detach().float().bfloat16().double().requires_grad_(True)
+    ei16 = ei.detach().float().bfloat16().double().requires_grad_(True)
+    ref16 = ref_cpu.symmetric_infonce(ref_cpu.logits(es16, ei16, 1.0))
+    ref16.backward()
+    for r in range(world):
+        sl = slice(r * b_loc, (r + 1) * b_loc)
+        assert abs(ret[r]["loss_f"] - ref16.item()) < 2e-4
+        assert (ret[r]["d_es_f"].double() - es16.grad[sl]).abs().max() < 6e-3 * es16.grad.abs().max() + 1e-5
+        assert (ret[r]["d_ei_f"].double() - ei16.grad[sl]).abs().max() < 6e-3 * ei16.grad.abs().max() + 1e-5
     # replicas stay bit-identical (same reduced gradients, same deterministic table reduction)
     assert ret[0]["losses"] == ret[1]["losses"]
     for n in ret[0]["chk"]:
