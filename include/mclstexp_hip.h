@@ -189,13 +189,24 @@ int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int
                    int32_t accumulate, mcl_stream_t stream);
 
 /* 1x1-convolution weight gradient (DenseNet bottleneck conv1 / transition conv) on channels-last bf16:
- *   dW[m][n] += sum_s dz[s][m] * a'[s][n],   a' = a, or relu(a*scale[n] + shift[n]) when scale/shift != NULL
- * (BatchNorm+ReLU of the layer input recomputed on the fly from the concat buffer).  dz: (S, M) row stride
- * ldz; a: (S, N) row stride lda; dW: (M, N) fp32, ACCUMULATED with float atomics (pass the parameter's
+ *   dW[m][n] += sum_s dz[s][m] * a'[s][n],   a' = a, or relu(BatchNorm(a)) when gamma/beta/mean/rstd (all four,
+ * per input channel) are given: the layer input is then read straight from the concat buffer and its BN+ReLU is
+ * recomputed on the fly, so the normalised activation never has to be kept for the backward.  dz: (S, M) row
+ * stride ldz; a: (S, N) row stride lda; dW: (M, N) fp32, ACCUMULATED with float atomics (pass the parameter's
  * .grad view).  M, N, ldz, lda multiples of 8; bases 16-byte aligned.  bf16 MFMA, fp32 accumulate.        */
-int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* scale,
-                         const float* shift, float* dW, int64_t lddw, int64_t S, int32_t M, int32_t N,
-                         mcl_stream_t stream);
+int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* gamma,
+                         const float* beta, const float* mean, const float* rstd, float* dW, int64_t lddw, int64_t S,
+                         int32_t M, int32_t N, mcl_stream_t stream);
+
+/* DenseNet bottleneck 1x1 convolution with both BatchNorms folded in (torchvision _DenseLayer norm1/relu1/conv1 +
+ * norm2's statistics):   z[s][n] = sum_k relu(x[s][k]*g[k]*rstd[k] + beta[k] - mean[k]*g[k]*rstd[k]) * W[n][k],
+ * n < 128;  zmean/zvar (biased)/zrstd = batch statistics of the bf16-rounded z.  x: (S, K) bf16 row stride ldx
+ * (a channel slice of the block's concat buffer), W: (128, K) bf16 contiguous, z: (S, 128) bf16 row stride ldz.
+ * K % 8 == 0, K <= 1024.  workspace: mcl_dense_conv1x1_workspace_floats(S) floats.                        */
+int64_t mcl_dense_conv1x1_workspace_floats(int64_t S);
+int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int32_t K, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, const void* W, void* z, int64_t ldz, float* workspace,
+                          float eps, float* zmean, float* zvar, float* zrstd, mcl_stream_t stream);
 
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */

@@ -85,8 +85,10 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* tile, int kbase, int cbase,
 template <bool PRO>
 __global__ __launch_bounds__(256) void conv1x1_wrw_kernel(const bf16_t* __restrict__ dz, long long ldz,
                                                           const bf16_t* __restrict__ a, long long lda,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, float* __restrict__ dW,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ dW,
                                                           long long lddw, long long S, int M, int N,
                                                           long long rows_per_wg) {
   __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][BK * PITCH];   // [buffer][operand][tile]
@@ -101,9 +103,10 @@ __global__ __launch_bounds__(256) void conv1x1_wrw_kernel(const bf16_t* __restri
   if (PRO) {
     const int col = n0 + (tid & 15) * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sc[i] = col + i < N ? scale[col + i] : 0.0f;
-      sh[i] = col + i < N ? shift[col + i] : 0.0f;
+    for (int i = 0; i < 8; ++i) {   // BatchNorm folded to a = relu(x*sc + sh), recomputed from the layer input
+      const bool ok = col + i < N;
+      sc[i] = ok ? gamma[col + i] * rstd[col + i] : 0.0f;
+      sh[i] = ok ? fmaf(-mean[col + i], sc[i], beta[col + i]) : 0.0f;
     }
   }
 
@@ -171,15 +174,16 @@ __global__ __launch_bounds__(256) void conv1x1_wrw_kernel(const bf16_t* __restri
 
 }  // namespace
 
-extern "C" int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* scale,
-                                    const float* shift, float* dW, int64_t lddw, int64_t S, int32_t M, int32_t N,
-                                    mcl_stream_t stream) {
+extern "C" int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* gamma,
+                                    const float* beta, const float* mean, const float* rstd, float* dW,
+                                    int64_t lddw, int64_t S, int32_t M, int32_t N, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!dz || !a || !dW || S <= 0 || M <= 0 || N <= 0) return MCL_EINVAL;
   if ((M % 8) || (N % 8) || (ldz % 8) || (lda % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
       (reinterpret_cast<uintptr_t>(a) & 15u))
     return MCL_EUNSUPPORTED;
-  if ((scale == nullptr) != (shift == nullptr)) return MCL_EINVAL;
+  const bool pro = gamma || beta || mean || rstd;
+  if (pro && !(gamma && beta && mean && rstd)) return MCL_EINVAL;
   const int tn = (N + BT - 1) / BT, tm = (M + BT - 1) / BT;
   long long ks = (768 + tn * tm - 1) / (tn * tm);
   const long long max_ks = (S + 255) / 256;
@@ -190,13 +194,13 @@ extern "C" int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, 
   rows = (rows + BK - 1) / BK * BK;
   ks = (S + rows - 1) / rows;
   dim3 grid(tn, tm, (unsigned)ks);
-  if (scale)
+  if (pro)
     hipLaunchKernelGGL(conv1x1_wrw_kernel<true>, grid, dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
-                       (long long)ldz, (const bf16_t*)a, (long long)lda, scale, shift, dW, (long long)lddw,
+                       (long long)ldz, (const bf16_t*)a, (long long)lda, gamma, beta, mean, rstd, dW, (long long)lddw,
                        (long long)S, M, N, rows);
   else
     hipLaunchKernelGGL(conv1x1_wrw_kernel<false>, grid, dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
-                       (long long)ldz, (const bf16_t*)a, (long long)lda, scale, shift, dW, (long long)lddw,
+                       (long long)ldz, (const bf16_t*)a, (long long)lda, gamma, beta, mean, rstd, dW, (long long)lddw,
                        (long long)S, M, N, rows);
   MCL_CHECK_LAUNCH();
   return MCL_OK;

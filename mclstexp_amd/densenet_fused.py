@@ -218,11 +218,36 @@ def _conv1x1_fwd(a: Tensor, w: Tensor) -> Tensor:
 
 
 USE_HIP_WRW_1X1 = os.environ.get("MCL_HIP_WRW", "1") != "0"
+# norm1 + relu1 + conv1 + norm2-statistics of a dense layer as ONE kernel (csrc/dense_conv.hip): the normalised
+# input `a` is never materialised (the weight-gradient kernel recomputes it from the concat buffer).
+USE_FUSED_1X1 = os.environ.get("MCL_FUSED_1X1", "1") != "0"
 
 
-def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor) -> Optional[Tensor]:
+def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, w16: Tensor, eps2: float,
+                      zmean: Tensor, zvar: Tensor, zrstd: Tensor) -> Tensor:
+    """z = conv1x1(relu(bn(x)), w16) and z's batch statistics.  x: channel slice of the concat buffer (bf16
+    channels-last), w16: (128, C_in, 1, 1) bf16 whose storage is (128, C_in) row-major."""
+    px, S, K, ldx = _rows(x)
+    B, _, H, W = x.shape
+    z = torch.empty((B, 128, H, W), device=x.device, dtype=torch.bfloat16, memory_format=CL)
+    L = _lib.lib()
+    ws = _ws(L.mcl_dense_conv1x1_workspace_floats(S), x.device)
+    check(L.mcl_dense_conv1x1_fwd(px, ldx, S, K, g1.data_ptr(), b1.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                  w16.data_ptr(), z.data_ptr(), 128, ws.data_ptr(), eps2, zmean.data_ptr(),
+                                  zvar.data_ptr(), zrstd.data_ptr(), _stream()), "mcl_dense_conv1x1_fwd")
+    return z
+
+
+def _fused_1x1_ok(x: Tensor, w16: Tensor) -> bool:
+    return (USE_FUSED_1X1 and x.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.shape[0] == 128
+            and w16.shape[1] % 8 == 0 and w16.shape[1] <= 1024 and w16.shape[2:] == (1, 1)
+            and w16.permute(0, 2, 3, 1).is_contiguous())
+
+
+def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Tensor]:
     """Weight gradient of a 1x1 convolution through csrc/conv1x1.hip.  Adds straight into ``w_param.grad``
-    when it is a dense fp32 tensor (returns None), else returns a fresh fp32 gradient."""
+    when it is a dense fp32 tensor (returns None), else returns a fresh fp32 gradient.  ``bn`` = (gamma, beta,
+    mean, rstd): ``a`` is then the layer INPUT (concat-buffer slice) and relu(bn(a)) is recomputed in-kernel."""
     pz, S, M, ldz = _rows(dz)
     pa, S2, N, lda = _rows(a)
     assert S == S2 and dz.dtype == a.dtype == torch.bfloat16
@@ -231,13 +256,21 @@ def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor) -> Optional[Tensor]:
     else:
         tgt = torch.zeros((M, N, 1, 1), device=dz.device, dtype=torch.float32)
         ret = tgt
-    check(_lib.lib().mcl_conv1x1_wrw_bf16(pz, ldz, pa, lda, None, None, tgt.data_ptr(), N, S, M, N, _stream()),
+    g_, b_, m_, r_ = (t.data_ptr() for t in bn) if bn is not None else (None, None, None, None)
+    check(_lib.lib().mcl_conv1x1_wrw_bf16(pz, ldz, pa, lda, g_, b_, m_, r_, tgt.data_ptr(), N, S, M, N, _stream()),
           "mcl_conv1x1_wrw_bf16")
     return ret
 
 
-def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Optional[Tensor] = None):
-    """(da, dw) -- dw is None when it was added straight into ``w_param.grad``."""
+def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Optional[Tensor] = None, bn=None):
+    """(da, dw) -- dw is None when it was added straight into ``w_param.grad``.  With ``bn`` the tensor ``a`` is
+    the un-normalised layer input (fused forward) and only the HIP weight-gradient kernel can consume it."""
+    if bn is not None:
+        assert dz.dtype == torch.bfloat16 and w_param is not None
+        # the data gradient needs only dz and w: a transposed convolution IS the backward-data kernel and, unlike
+        # aten.convolution_backward, does not make a contiguous copy of the (channel-sliced) layer input first
+        da = F.conv_transpose2d(dz, w)
+        return da.contiguous(memory_format=CL), ("direct", conv1x1_wrw(dz, a, w_param, bn=bn))
     if not USE_MM_1X1:
         if USE_HIP_WRW_1X1 and w_param is not None and dz.dtype == torch.bfloat16:
             da = torch.ops.aten.convolution_backward(dz, a, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
@@ -322,12 +355,16 @@ class DenseBlockFn(torch.autograd.Function):
         for l in range(L):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
             cin = C0 + l * growth
-            a = torch.empty((B, cin, H, W), device=dev, dtype=dt, memory_format=CL)
-            bn_act_fwd(buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], True, a)
             w1c = _weight(w1, dt)
-            z = _conv1x1_fwd(a, w1c)
             m2, v2, r2 = bn2_stats[l]
-            bn_stats(z, m2, v2, r2, eps2[l])
+            if _fused_1x1_ok(buf, w1c):
+                a = None      # never materialised; the backward recomputes relu(bn1(.)) from buf where needed
+                z = dense_conv1x1_fwd(buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], w1c, eps2[l], m2, v2, r2)
+            else:
+                a = torch.empty((B, cin, H, W), device=dev, dtype=dt, memory_format=CL)
+                bn_act_fwd(buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], True, a)
+                z = _conv1x1_fwd(a, w1c)
+                bn_stats(z, m2, v2, r2, eps2[l])
             a2 = torch.empty_like(z, memory_format=CL)
             bn_act_fwd(z, g2, b2, m2, r2, True, a2)
             w2c = _weight(w2, dt)
@@ -337,7 +374,7 @@ class DenseBlockFn(torch.autograd.Function):
             # stored for eps1[min(l+1, L-1)] -- all equal in torchvision's DenseNet
             bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
                      copy_out=buf[:, cin:c1])
-            saved += [a, z, a2]
+            saved += [a if a is not None else buf.new_empty(0), z, a2]
             wcast += [w1c, w2c]
         ctx.save_for_backward(buf, *saved, *wcast)
         ctx.params = params             # Parameter objects (for direct .grad accumulation)
@@ -369,7 +406,11 @@ class DenseBlockFn(torch.autograd.Function):
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
                                   into_param_grads=d2)
-            da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
+            if a.numel() == 0:    # fused forward: BN1+ReLU recomputed from the concat buffer inside the wrw kernel
+                da, dw1 = _conv1x1_bwd(dz, buf[:, :cin], w1c, w1,
+                                       bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
+            else:
+                da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
             d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
             dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
                                   stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)

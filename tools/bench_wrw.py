@@ -26,7 +26,7 @@ for S, C in shapes:
     a = (torch.rand(B, C, hw, hw, device=dev) - 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w = torch.zeros(128, C, 1, 1, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dW = torch.zeros(128, C, device=dev)
-    f1 = lambda: _lib.check(L.mcl_conv1x1_wrw_bf16(dz.data_ptr(), 128, a.data_ptr(), C, None, None, dW.data_ptr(), C, S, 128, C, dn._stream()))
+    f1 = lambda: _lib.check(L.mcl_conv1x1_wrw_bf16(dz.data_ptr(), 128, a.data_ptr(), C, None, None, None, None, dW.data_ptr(), C, S, 128, C, dn._stream()))
     f2 = lambda: torch.ops.aten.convolution_backward(dz, a, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])
     t1, t2 = timeit(f1), timeit(f2)
     mb = S * (128 + C) * 2 / 1e6
