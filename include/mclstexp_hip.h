@@ -208,6 +208,17 @@ int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int32_t K, cons
                           const float* mean, const float* rstd, const void* W, void* z, int64_t ldz, float* workspace,
                           float eps, float* zmean, float* zvar, float* zrstd, mcl_stream_t stream);
 
+/* DenseNet growth 3x3 convolution (pad 1, 128 -> 32) with both BatchNorms folded in (torchvision _DenseLayer
+ * norm2/relu2/conv2 + the statistics of the new feature map), written straight into the concat buffer:
+ *   y[p][co] = sum_{ky,kx,ci} relu(bn2(z))[p + (ky-1)*W + (kx-1)][ci] * W2[co][ky][kx][ci]   (zero outside the image)
+ * z: (S, 128) bf16 contiguous NHWC pixels (S = B*H*W), W2: (32, 3, 3, 128) bf16 (a channels-last (32,128,3,3)
+ * weight), out: bf16 with row stride ldo (the block buffer's channel slice), ymean/yvar (biased)/yrstd = batch
+ * statistics of the bf16-rounded y.  workspace: mcl_dense_conv3x3_workspace_floats(S) floats.            */
+int64_t mcl_dense_conv3x3_workspace_floats(int64_t S);
+int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_t W, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, const void* W2, void* out, int64_t ldo,
+                          float* workspace, float eps, float* ymean, float* yvar, float* yrstd, mcl_stream_t stream);
+
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

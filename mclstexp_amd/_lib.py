@@ -74,13 +74,16 @@ PROTOTYPES = {
     "mcl_conv1x1_wrw_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_p],
     "mcl_dense_conv1x1_workspace_floats": [c_l],
     "mcl_dense_conv1x1_fwd": [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
+    "mcl_dense_conv3x3_workspace_floats": [c_l],
+    "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
 }
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
-             "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64}
+             "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
+             "mcl_dense_conv3x3_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

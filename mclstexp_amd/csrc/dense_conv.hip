@@ -292,3 +292,210 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
+
+// =====================================================================================================================
+// DenseNet growth 3x3 convolution with BatchNorm folded in on both sides (torchvision _DenseLayer: norm2 -> relu2 ->
+// conv2 (3x3, pad 1, 128 -> 32), followed by the statistics the next layers' norm1 need), writing straight into
+// the block's concat buffer:
+//
+//     y[p][co] = sum_{ky,kx,ci} relu(z[p + (ky-1)*W + (kx-1)][ci]*scale[ci] + shift[ci]) * W2[co][ky][kx][ci]
+//
+// over flattened NHWC pixels p, taps that leave the image contributing zero.  Implicit GEMM M = S pixels, N = 32,
+// K = 9*128.  One workgroup (4 waves, two per CU) owns 128 consecutive pixels: it stages the contiguous pixel
+// range [p0 - W - 1, p0 + 128 + W + 1) of z ONCE into an XOR-swizzled LDS slab with BN+ReLU applied on the way
+// (each staging thread owns 8 fixed channels), so `a2 = relu(bn2(z))` never exists in HBM and all nine taps are LDS
+// row offsets.  N = 32 gives a B fragment no reuse across output columns, so the K dimension is split over the
+// four waves instead (wave w owns k-steps 18w..18w+17 of 72 and keeps its 18 weight fragments in registers for the
+// whole tile): every MFMA costs one ds_read_b128.  Invalid taps select the address of an all-zero LDS row.  The
+// four K-partials meet in LDS; the tile's (sum, M2) per channel go to the same finalize as the 1x1 kernel.
+constexpr int C3_IN = 128, C3_OUT = 32, T3 = 128;   // channels in / out, pixels per tile
+
+__global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __restrict__ z, long long S, int H, int W,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const bf16_t* __restrict__ W2, bf16_t* __restrict__ out,
+                                                             long long ldo, float2* __restrict__ partial, int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const long long p0 = (long long)blockIdx.x * T3;
+  const int nrow = T3 + 2 * W + 2;                 // slab rows; slab row j <-> pixel p0 - (W+1) + j
+  unsigned char* zero_row = lds + nrow * 256;      // 256 B of zeros
+
+  // this wave's 18 weight fragments: k-step kidx = 18*wave + i -> tap = kidx >> 3, channels 16*(kidx & 7) + 8h ..
+  bf16x8 breg[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const int kidx = 18 * wave + i;
+    breg[i] = *reinterpret_cast<const bf16x8*>(W2 + ((long long)l31 * 9 + (kidx >> 3)) * C3_IN + 16 * (kidx & 7) + 8 * h);
+  }
+
+  // ---- stage the slab with BN+ReLU: thread owns chunk column cc (8 channels) of rows (tid >> 4) + 16*i
+  {
+    const int cc = tid & 15;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = cc * 8 + i;
+      sc[i] = gamma[c] * rstd[c];
+      sh[i] = fmaf(-mean[c], sc[i], beta[c]);
+    }
+    for (int j = tid >> 4; j < nrow; j += 16) {
+      const long long p = p0 - (W + 1) + j;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (p >= 0 && p < S) v = bn_relu_chunk(*reinterpret_cast<const uint4*>(z + p * C3_IN + cc * 8), sc, sh);
+      *reinterpret_cast<uint4*>(lds + j * 256 + ((cc ^ (j & 15)) << 4)) = v;
+    }
+    if (tid < 16) *reinterpret_cast<uint4*>(zero_row + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  // per pixel block mb: slab row of tap (0,0) and the 9-bit tap validity of this lane's pixel
+  int rbase[4];
+  unsigned vmask[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const long long p = p0 + mb * 32 + l31;
+    rbase[mb] = mb * 32 + l31;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    unsigned m = 0;
+    if (p < S) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) m |= 1u << (ky * 3 + kx);
+        }
+    }
+    vmask[mb] = m;
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+  __syncthreads();
+
+  const int zero_off = nrow * 256;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const int kidx = 18 * wave + i;                // wave-uniform
+    const int tap = kidx >> 3, kk = kidx & 7;
+    const int toff = (tap / 3) * W + (tap % 3);   // slab row offset of the tap
+    const int chunk = 2 * kk + h;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int row = rbase[mb] + toff;
+      const int off = ((vmask[mb] >> tap) & 1u) ? row * 256 + ((chunk ^ (row & 15)) << 4) : zero_off;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + off);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, breg[i], acc[mb], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // slab dead: reuse it for the K-partials  red[wave][pixel][co] fp32
+  float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      red[(wave * T3 + px) * C3_OUT + l31] = acc[mb][r];
+    }
+  __syncthreads();
+  // thread -> pixel tid >> 1, 16 channels (tid & 1) * 16 ..
+  const int px = tid >> 1, c0 = (tid & 1) * 16;
+  const long long p = p0 + px;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float4 s = *reinterpret_cast<const float4*>(red + px * C3_OUT + c0 + 4 * q);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + (w * T3 + px) * C3_OUT + c0 + 4 * q);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    v[4 * q] = s.x; v[4 * q + 1] = s.y; v[4 * q + 2] = s.z; v[4 * q + 3] = s.w;
+  }
+  unsigned pk[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) pk[q] = pack2(v[2 * q], v[2 * q + 1]);
+  if (p < S) {
+    *reinterpret_cast<uint4*>(out + p * ldo + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    *reinterpret_cast<uint4*>(out + p * ldo + c0 + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+  }
+  // ---- statistics of the bf16-rounded tile: rounded values -> LDS [px][32], then (channel, 16-pixel group) partials
+  __syncthreads();
+  float* rv = reinterpret_cast<float*>(lds);                 // [128][32]
+  float* grp = rv + T3 * C3_OUT;                             // [8][32] float2
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    rv[px * C3_OUT + c0 + 2 * q] = bf_lo(pk[q]);
+    rv[px * C3_OUT + c0 + 2 * q + 1] = bf_hi(pk[q]);
+  }
+  __syncthreads();
+  {
+    const int c = tid & 31, g = tid >> 5;
+    const float ks = rv[c];                                  // shift: pixel 0 of the tile (always < S)
+    const int nvalid = (int)min((long long)T3, S - p0);
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int pp = g * 16 + q;
+      if (pp < nvalid) {
+        const float dlt = rv[pp * C3_OUT + c] - ks;
+        s1 += dlt;
+        s2 = fmaf(dlt, dlt, s2);
+      }
+    }
+    grp[(g * 32 + c) * 2] = s1;
+    grp[(g * 32 + c) * 2 + 1] = s2;
+    __syncthreads();
+    if (tid < 32) {
+      float a = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) {
+        a += grp[(gg * 32 + tid) * 2];
+        b += grp[(gg * 32 + tid) * 2 + 1];
+      }
+      const float n = (float)nvalid;
+      partial[(long long)tid * ntile + blockIdx.x] = make_float2(fmaf(n, rv[tid], a), b - a * a / n);
+    }
+  }
+}
+
+extern "C" int64_t mcl_dense_conv3x3_workspace_floats(int64_t S) {
+  if (S <= 0) return -1;
+  return ((S + T3 - 1) / T3) * C3_OUT * 2;
+}
+
+extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_t W, const float* gamma,
+                                     const float* beta, const float* mean, const float* rstd, const void* W2, void* out,
+                                     int64_t ldo, float* workspace, float eps, float* ymean, float* yvar, float* yrstd,
+                                     mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!z || !gamma || !beta || !mean || !rstd || !W2 || !out || !workspace || !ymean || !yvar || !yrstd || S <= 0 ||
+      H <= 0 || W <= 0)
+    return MCL_EINVAL;
+  if ((S % ((int64_t)H * W)) || W > 150 || (ldo % 8) || ldo < C3_OUT || (reinterpret_cast<uintptr_t>(z) & 15u) ||
+      (reinterpret_cast<uintptr_t>(W2) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int ntile = (int)((S + T3 - 1) / T3);
+  // slab + zero row; the epilogue reuses it for 4 x 128 x 32 fp32 partials (64 KiB) / the statistics scratch
+  size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256;
+  if (lds_bytes < 4 * T3 * C3_OUT * 4) lds_bytes = 4 * T3 * C3_OUT * 4;
+  hipStream_t st = mcl_stream(stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    attr_set = true;
+  }
+  float2* part = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(ntile), dim3(256), lds_bytes, st, (const bf16_t*)z, (long long)S, H, W,
+                     gamma, beta, mean, rstd, (const bf16_t*)W2, (bf16_t*)out, (long long)ldo, part, ntile);
+  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3((C3_OUT + 3) / 4), dim3(256), 0, st, (const float2*)part, ntile,
+                     C3_OUT, (long long)S, T3, eps, ymean, yvar, yrstd);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

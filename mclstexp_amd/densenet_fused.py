@@ -238,6 +238,29 @@ def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Ten
     return z
 
 
+# norm2 + relu2 + conv2 (3x3) + the new feature map's statistics as ONE kernel writing into the concat buffer
+USE_FUSED_3X3 = os.environ.get("MCL_FUSED_3X3", "1") != "0"
+
+
+def dense_conv3x3_fwd(z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor, w16: Tensor, out: Tensor, eps: float,
+                      ymean: Tensor, yvar: Tensor, yrstd: Tensor) -> None:
+    """out (a 32-channel slice of the concat buffer) = conv3x3(relu(bn2(z)), w16), plus its batch statistics."""
+    B, C, H, W = z.shape
+    po, S, Co, ldo = _rows(out)
+    assert C == 128 and Co == 32 and z.is_contiguous(memory_format=CL) and S == B * H * W
+    L = _lib.lib()
+    ws = _ws(L.mcl_dense_conv3x3_workspace_floats(S), z.device)
+    check(L.mcl_dense_conv3x3_fwd(z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(), m2.data_ptr(), r2.data_ptr(),
+                                  w16.data_ptr(), po, ldo, ws.data_ptr(), eps, ymean.data_ptr(), yvar.data_ptr(),
+                                  yrstd.data_ptr(), _stream()), "mcl_dense_conv3x3_fwd")
+
+
+def _fused_3x3_ok(z: Tensor, w16: Tensor) -> bool:
+    return (USE_FUSED_3X3 and z.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16
+            and tuple(w16.shape) == (32, 128, 3, 3) and w16.permute(0, 2, 3, 1).is_contiguous()
+            and z.shape[1] == 128 and z.shape[3] <= 150 and z.is_contiguous(memory_format=CL))
+
+
 def _fused_1x1_ok(x: Tensor, w16: Tensor) -> bool:
     return (USE_FUSED_1X1 and x.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.shape[0] == 128
             and w16.shape[1] % 8 == 0 and w16.shape[1] <= 1024 and w16.shape[2:] == (1, 1)
@@ -365,16 +388,21 @@ class DenseBlockFn(torch.autograd.Function):
                 bn_act_fwd(buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], True, a)
                 z = _conv1x1_fwd(a, w1c)
                 bn_stats(z, m2, v2, r2, eps2[l])
-            a2 = torch.empty_like(z, memory_format=CL)
-            bn_act_fwd(z, g2, b2, m2, r2, True, a2)
             w2c = _weight(w2, dt)
-            y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
             c1 = cin + growth
             # eps of the NEXT consumer's norm1 is the same module default everywhere (1e-5); rstd is
             # stored for eps1[min(l+1, L-1)] -- all equal in torchvision's DenseNet
-            bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
-                     copy_out=buf[:, cin:c1])
-            saved += [a if a is not None else buf.new_empty(0), z, a2]
+            if growth == 32 and _fused_3x3_ok(z, w2c):
+                a2 = None     # never materialised in the forward; recomputed from z in the backward
+                dense_conv3x3_fwd(z, g2, b2, m2, r2, w2c, buf[:, cin:c1], eps1[min(l + 1, L - 1)],
+                                  stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1])
+            else:
+                a2 = torch.empty_like(z, memory_format=CL)
+                bn_act_fwd(z, g2, b2, m2, r2, True, a2)
+                y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
+                bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
+                         copy_out=buf[:, cin:c1])
+            saved += [a if a is not None else buf.new_empty(0), z, a2 if a2 is not None else buf.new_empty(0)]
             wcast += [w1c, w2c]
         ctx.save_for_backward(buf, *saved, *wcast)
         ctx.params = params             # Parameter objects (for direct .grad accumulation)
@@ -400,8 +428,11 @@ class DenseBlockFn(torch.autograd.Function):
             w1c, w2c = wcast[2 * l: 2 * l + 2]
             cin = C0 + l * growth
             dy = gbuf[:, cin:cin + growth].contiguous(memory_format=CL)
-            da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
             m2, v2, r2 = bn2_stats[l]
+            if a2.numel() == 0:   # fused forward: a2 = relu(bn2(z)) was never stored
+                a2 = torch.empty_like(z, memory_format=CL)
+                bn_act_fwd(z, g2, b2, m2, r2, True, a2)
+            da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
             dz = torch.empty_like(z, memory_format=CL)
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,

@@ -159,7 +159,7 @@ def test_direct_param_grads_and_bf16_shadow():
     loss = m(batch); opt.zero_grad(); loss.backward(); opt.step()
     loss = m(batch); opt.zero_grad(); loss.backward()
     grads = []
-    for direct in (True, False):
+    for direct in (True, False, False):
         dn.DIRECT_PARAM_GRADS = direct
         try:
             loss = m(batch)
@@ -168,18 +168,21 @@ def test_direct_param_grads_and_bf16_shadow():
         finally:
             dn.DIRECT_PARAM_GRADS = True
         grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if n.startswith("image_encoder")})
-    worst_tail, worst_all = 0.0, 0.0
-    for n in grads[0]:
-        a, b = grads[0][n], grads[1][n]
-        d = ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
-        worst_all = max(worst_all, d)
-        if "denseblock4" in n or "norm5" in n:
-            worst_tail = max(worst_tail, d)
-    # MIOpen's split-K weight-gradient kernels use atomics: two backward passes are not bit-identical and the
-    # difference is amplified on the way down through 120 BN layers.  The hand-over itself is checked where that
-    # amplification is small (last block), the rest only for gross errors (a missed or doubled gradient is O(1)).
-    assert worst_tail < 2e-2, worst_tail
-    assert worst_all < 0.5, worst_all
+
+    def worst(x, y, tail):
+        w = 0.0
+        for n in x:
+            if tail and not ("denseblock4" in n or "norm5" in n):
+                continue
+            w = max(w, ((x[n] - y[n]).abs().max() / (y[n].abs().max() + 1e-20)).item())
+        return w
+    # Self-calibrating: MIOpen's weight-gradient kernels use atomics (and its solver choice can change between
+    # calls), so two IDENTICAL backward passes already differ, amplified through 120 BN layers.  The hand-over
+    # (direct accumulation vs autograd) must not differ by more than a few times that run-to-run noise.
+    noise_tail, noise_all = worst(grads[1], grads[2], True), worst(grads[1], grads[2], False)
+    d_tail, d_all = worst(grads[0], grads[1], True), worst(grads[0], grads[1], False)
+    assert d_tail <= 4.0 * noise_tail + 2e-2, (d_tail, noise_tail)
+    assert d_all <= 4.0 * noise_all + 0.1, (d_all, noise_all)      # a missed or doubled gradient would be O(1)
     # shadow views follow the parameters
     opt.step()
     for n, p in m.named_parameters():
@@ -248,3 +251,39 @@ def test_dense_conv1x1_fwd_fused(S, K, ldx):
     assert_close(zm.cpu(), zd.mean(0).cpu(), 1e-5, rtol=1e-5, what="z mean")
     assert_close(zv.cpu(), zd.var(0, unbiased=False).cpu(), 1e-6, rtol=2e-5, what="z var")
     assert_close(zr.cpu(), (1.0 / torch.sqrt(zd.var(0, unbiased=False) + 1e-5)).cpu(), 1e-6, rtol=2e-5, what="z rstd")
+
+
+@pytest.mark.parametrize("B,H,W,ldo", [(4, 56, 56, 256), (8, 28, 28, 512), (16, 14, 14, 1024), (32, 7, 7, 1024), (3, 10, 6, 64),
+                                       (1, 5, 3, 32), (2, 64, 64, 160)])
+def test_dense_conv3x3_fwd_fused(B, H, W, ldo):
+    """y = conv3x3(relu(bn2(z))) written into a channel slice of a wider NHWC buffer + batch statistics of y, in one
+    kernel (csrc/dense_conv.hip) vs torch on the same bf16 data: every DenseNet stage geometry, image borders,
+    ragged last tile, tiles spanning several images."""
+    import torch.nn.functional as F
+    from mclstexp_amd import _lib, densenet_fused as dn
+    S = B * H * W
+    g = torch.Generator().manual_seed(S + W)
+    z = ((torch.rand(B, H, W, 128, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)          # NHWC storage
+    gam = (torch.rand(128, generator=g) + 0.5).to(DEV)
+    bet = (torch.rand(128, generator=g) - 0.5).to(DEV)
+    mu = (torch.rand(128, generator=g) - 0.5).to(DEV)
+    rs = (torch.rand(128, generator=g) + 0.5).to(DEV)
+    W2 = ((torch.rand(32, 3, 3, 128, generator=g) - 0.5) / 34.0).to(torch.bfloat16).to(DEV)     # [co][ky][kx][ci]
+    wide = torch.zeros((S, ldo), device=DEV, dtype=torch.bfloat16)
+    off = ldo - 32
+    out = wide[:, off:]
+    ym, yv, yr = (torch.empty(32, device=DEV) for _ in range(3))
+    ws = torch.empty(_lib.lib().mcl_dense_conv3x3_workspace_floats(S), device=DEV)
+    _lib.check(_lib.lib().mcl_dense_conv3x3_fwd(z.data_ptr(), S, H, W, gam.data_ptr(), bet.data_ptr(), mu.data_ptr(),
+                                                rs.data_ptr(), W2.data_ptr(), out.data_ptr(), ldo, ws.data_ptr(), 1e-5,
+                                                ym.data_ptr(), yv.data_ptr(), yr.data_ptr(), dn._stream()))
+    sc = gam * rs
+    sh = torch.addcmul(bet, mu, sc, value=-1.0)
+    a2 = torch.relu(torch.addcmul(sh, z.float(), sc)).to(torch.bfloat16)                          # (B,H,W,128)
+    ref = F.conv2d(a2.double().permute(0, 3, 1, 2), W2.double().permute(0, 3, 1, 2), padding=1)   # (B,32,H,W)
+    ref = ref.permute(0, 2, 3, 1).reshape(S, 32)
+    assert_close_scaled(out.float().cpu(), ref.cpu(), 6e-3, what="fused conv3x3 output (bf16)")
+    assert float(wide[:, :off].abs().max()) == 0.0 if off else True, "wrote outside its channel slice"
+    yd = out.double()
+    assert_close(ym.cpu(), yd.mean(0).cpu(), 1e-5, rtol=1e-5, what="y mean")
+    assert_close(yv.cpu(), yd.var(0, unbiased=False).cpu(), 1e-6, rtol=2e-5, what="y var")
