@@ -219,6 +219,13 @@ int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_t W, const 
                           const float* mean, const float* rstd, const void* W2, void* out, int64_t ldo,
                           float* workspace, float eps, float* ymean, float* yvar, float* yrstd, mcl_stream_t stream);
 
+/* Weight gradient of that 3x3 convolution: dW2[co][ky][kx][ci] += sum_p dy[p][co] * relu(bn2(z))[p + tap][ci], the
+ * normalised input recomputed from z on the fly; dW2: (32, 3, 3, 128) fp32 contiguous (the channels-last parameter's
+ * .grad), ACCUMULATED with float atomics.  dy: (S, 32) bf16 row stride lddy; z: (S, 128) bf16 contiguous.   */
+int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
+                          const float* gamma, const float* beta, const float* mean, const float* rstd, float* dW,
+                          mcl_stream_t stream);
+
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "mcl_dense_conv1x1_workspace_floats": [c_l],
     "mcl_dense_conv1x1_fwd": [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_dense_conv3x3_workspace_floats": [c_l],
+    "mcl_dense_conv3x3_wrw": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],

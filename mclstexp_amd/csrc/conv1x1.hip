@@ -185,7 +185,10 @@ extern "C" int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, 
   const bool pro = gamma || beta || mean || rstd;
   if (pro && !(gamma && beta && mean && rstd)) return MCL_EINVAL;
   const int tn = (N + BT - 1) / BT, tm = (M + BT - 1) / BT;
-  long long ks = (768 + tn * tm - 1) / (tn * tm);
+  // workgroup count: the 128x128 fp32 atomics per workgroup are throughput-bound (~0.3 T lane-atomics/s), so the
+  // S split is kept as coarse as the streaming loop's latency hiding allows (measured: 384 / 256 beat 768)
+  const long long target = S >= 200000 ? 384 : 256;
+  long long ks = (target + tn * tm - 1) / (tn * tm);
   const long long max_ks = (S + 255) / 256;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;

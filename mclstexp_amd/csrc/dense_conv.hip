@@ -310,6 +310,33 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
 // four K-partials meet in LDS; the tile's (sum, M2) per channel go to the same finalize as the 1x1 kernel.
 constexpr int C3_IN = 128, C3_OUT = 32, T3 = 128;   // channels in / out, pixels per tile
 
+// Stage slab rows [0, nrow) of 256 B (pixel p0 - (W+1) + j) with BN+ReLU, 16 rows per pass over the workgroup, in
+// batches of NB independent global loads per thread (a load -> transform -> store loop would serialise one full
+// memory latency per pass: the slab is 10-16 passes).
+template <int NB>
+__device__ __forceinline__ void stage_slab(unsigned char* lds, const bf16_t* __restrict__ z, int p0, long long S,
+                                           int W, int nrow, int tid, const float (&sc)[8], const float (&sh)[8]) {
+  const int cc = tid & 15;
+  for (int jb = tid >> 4; jb < nrow; jb += 16 * NB) {
+    uint4 v[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = jb + 16 * i;
+      const int p = p0 - (W + 1) + j;
+      ok[i] = j < nrow && p >= 0 && p < (int)S;
+      v[i] = ok[i] ? *reinterpret_cast<const uint4*>(z + (long long)p * C3_IN + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = jb + 16 * i;
+      if (j < nrow)
+        *reinterpret_cast<uint4*>(lds + j * 256 + ((cc ^ (j & 15)) << 4)) =
+            ok[i] ? bn_relu_chunk(v[i], sc, sh) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __restrict__ z, long long S, int H, int W,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
@@ -320,9 +347,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const long long p0 = (long long)blockIdx.x * T3;
   const int nrow = T3 + 2 * W + 2;                 // slab rows; slab row j <-> pixel p0 - (W+1) + j
   unsigned char* zero_row = lds + nrow * 256;      // 256 B of zeros
+  const int Si = (int)S;
 
   // this wave's 18 weight fragments: k-step kidx = 18*wave + i -> tap = kidx >> 3, channels 16*(kidx & 7) + 8h ..
   bf16x8 breg[18];
@@ -331,36 +358,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
     const int kidx = 18 * wave + i;
     breg[i] = *reinterpret_cast<const bf16x8*>(W2 + ((long long)l31 * 9 + (kidx >> 3)) * C3_IN + 16 * (kidx & 7) + 8 * h);
   }
-
-  // ---- stage the slab with BN+ReLU: thread owns chunk column cc (8 channels) of rows (tid >> 4) + 16*i
+  float sc[8], sh[8];
   {
     const int cc = tid & 15;
-    float sc[8], sh[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = cc * 8 + i;
       sc[i] = gamma[c] * rstd[c];
       sh[i] = fmaf(-mean[c], sc[i], beta[c]);
     }
-    for (int j = tid >> 4; j < nrow; j += 16) {
-      const long long p = p0 - (W + 1) + j;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (p >= 0 && p < S) v = bn_relu_chunk(*reinterpret_cast<const uint4*>(z + p * C3_IN + cc * 8), sc, sh);
-      *reinterpret_cast<uint4*>(lds + j * 256 + ((cc ^ (j & 15)) << 4)) = v;
-    }
-    if (tid < 16) *reinterpret_cast<uint4*>(zero_row + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
+  // slab byte offset of this lane's fragment for k-step i in pixel block 0 (block mb adds 32 rows = 8192 B, which
+  // leaves the swizzle term (row & 15) untouched); tap of each k-step for the validity test
+  int abase[18], tapk[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const int kidx = 18 * wave + i, tap = kidx >> 3, kk = kidx & 7;
+    const int row = l31 + (tap / 3) * W + (tap % 3);
+    abase[i] = row * 256 + (((2 * kk + h) ^ (row & 15)) << 4);
+    tapk[i] = tap;
+  }
+  // persistent over tiles: the weight fragments and BN coefficients are loaded once per workgroup
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  const int p0 = tile * T3;
+  __syncthreads();   // the previous tile's epilogue scratch is dead
+
+  // ---- stage the slab with BN+ReLU: thread owns chunk column tid & 15 (8 channels) of rows (tid >> 4) + 16*i
+  stage_slab<4>(lds, z, p0, S, W, nrow, tid, sc, sh);
+  if (tid < 16) *reinterpret_cast<uint4*>(zero_row + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
   // per pixel block mb: slab row of tap (0,0) and the 9-bit tap validity of this lane's pixel
-  int rbase[4];
   unsigned vmask[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) {
-    const long long p = p0 + mb * 32 + l31;
-    rbase[mb] = mb * 32 + l31;
-    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const int p = p0 + mb * 32 + l31;
+    const int x = p % W, y = (p / W) % H;
     unsigned m = 0;
-    if (p < S) {
+    if (p < Si) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -381,14 +415,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
   const int zero_off = nrow * 256;
 #pragma unroll
   for (int i = 0; i < 18; ++i) {
-    const int kidx = 18 * wave + i;                // wave-uniform
-    const int tap = kidx >> 3, kk = kidx & 7;
-    const int toff = (tap / 3) * W + (tap % 3);   // slab row offset of the tap
-    const int chunk = 2 * kk + h;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      const int row = rbase[mb] + toff;
-      const int off = ((vmask[mb] >> tap) & 1u) ? row * 256 + ((chunk ^ (row & 15)) << 4) : zero_off;
+      const int off = ((vmask[mb] >> tapk[i]) & 1u) ? abase[i] + mb * 8192 : zero_off;
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + off);
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, breg[i], acc[mb], 0, 0, 0);
     }
@@ -405,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
   __syncthreads();
   // thread -> pixel tid >> 1, 16 channels (tid & 1) * 16 ..
   const int px = tid >> 1, c0 = (tid & 1) * 16;
-  const long long p = p0 + px;
+  const long long p = (long long)p0 + px;
   float v[16];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -437,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
   {
     const int c = tid & 31, g = tid >> 5;
     const float ks = rv[c];                                  // shift: pixel 0 of the tile (always < S)
-    const int nvalid = (int)min((long long)T3, S - p0);
+    const int nvalid = min(T3, Si - p0);
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -459,9 +488,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
         b += grp[(gg * 32 + tid) * 2 + 1];
       }
       const float n = (float)nvalid;
-      partial[(long long)tid * ntile + blockIdx.x] = make_float2(fmaf(n, rv[tid], a), b - a * a / n);
+      partial[(long long)tid * ntile + tile] = make_float2(fmaf(n, rv[tid], a), b - a * a / n);
     }
   }
+  }   // tile loop
 }
 
 extern "C" int64_t mcl_dense_conv3x3_workspace_floats(int64_t S) {
@@ -477,7 +507,7 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
   if (!z || !gamma || !beta || !mean || !rstd || !W2 || !out || !workspace || !ymean || !yvar || !yrstd || S <= 0 ||
       H <= 0 || W <= 0)
     return MCL_EINVAL;
-  if ((S % ((int64_t)H * W)) || W > 150 || (ldo % 8) || ldo < C3_OUT || (reinterpret_cast<uintptr_t>(z) & 15u) ||
+  if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (ldo % 8) || ldo < C3_OUT || (reinterpret_cast<uintptr_t>(z) & 15u) ||
       (reinterpret_cast<uintptr_t>(W2) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return MCL_EUNSUPPORTED;
   const int ntile = (int)((S + T3 - 1) / T3);
@@ -492,10 +522,174 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
     attr_set = true;
   }
   float2* part = reinterpret_cast<float2*>(workspace);
-  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(ntile), dim3(256), lds_bytes, st, (const bf16_t*)z, (long long)S, H, W,
+  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, st, (const bf16_t*)z, (long long)S, H, W,
                      gamma, beta, mean, rstd, (const bf16_t*)W2, (bf16_t*)out, (long long)ldo, part, ntile);
   hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3((C3_OUT + 3) / 4), dim3(256), 0, st, (const float2*)part, ntile,
                      C3_OUT, (long long)S, T3, eps, ymean, yvar, yrstd);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+// =====================================================================================================================
+// Weight gradient of the growth 3x3 convolution, with norm2+relu2 recomputed on the fly and accumulation straight
+// into the parameter's fp32 .grad:
+//
+//     dW2[co][ky][kx][ci] += sum_p dy[p][co] * relu(bn2(z))[p + (ky-1)*W + (kx-1)][ci]        (taps inside the image)
+//
+// A "TN" GEMM M = 32, N = 9*128, K = S pixels, both operands pixel-major -> both MFMA fragments come from
+// transposing LDS reads (ds_read_b64_tr_b16).  A workgroup (4 waves, two per CU) walks 128-pixel tiles: dy tile
+// (128 x 32) and the z slab [p0 - W - 1, p0 + 128 + W + 1) with BN+ReLU applied while staging (the same slab as the
+// forward kernel, so a2 never exists in HBM in the backward either); N is split over the waves (9 blocks of 32 =
+// 2.25 taps each, 144 accumulator registers); taps that leave the image select an all-zero LDS row per PIXEL (the
+// pixel is the reduction index here, so the mask rides on the row address each lane supplies to the transposing
+// read).  fp32 partials go to dW with hardware float atomics (no zero-fill / cast / accumulate passes).
+__global__ __launch_bounds__(256, 2) void conv3x3_wrw_kernel(const bf16_t* __restrict__ dy, long long lddy,
+                                                             const bf16_t* __restrict__ z, long long S, int H, int W,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dW,
+                                                             int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nrow = T3 + 2 * W + 2;
+  const int zero_off = nrow * 256;                       // 256 B of zeros
+  unsigned char* dyt = lds + zero_off + 256;             // dy tile [128][32] bf16, 64-byte rows (chunk ^ (row>>1)&3)
+  unsigned short* vm = reinterpret_cast<unsigned short*>(dyt + T3 * 64);   // [128 + 2W + 2] 9-bit tap validity per SLAB row
+
+  const int cc = tid & 15;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cc * 8 + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = fmaf(-mean[c], sc[i], beta[c]);
+  }
+  if (tid < 16) *reinterpret_cast<uint4*>(lds + zero_off + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int b = 0; b < 9; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+
+  // transposing-read lane geometry (see csrc/conv1x1.hip frag()): lane i = lane & 15 supplies pixel row (i >> 2)
+  // [+4 for the second read] of the 8-pixel k-group 8*(lane >> 5), 4 channels at (i & 3)*4 of the 16-channel half
+  const int i15 = lane & 15, q = i15 >> 2, jj = i15 & 3;
+  const int half16 = 16 * ((lane >> 4) & 1);
+
+  // per (lane, column block b): slab byte offset of pixel row 8h+q (+4) for the block's tap and input-channel chunk.
+  // (row + toff) & 15 does not depend on the 16-pixel k-step, so a read address is base[b] + 4096*ks.
+  int base_lo[9], base_hi[9], tapb[9];
+#pragma unroll
+  for (int b = 0; b < 9; ++b) {
+    const int nb = 9 * wave + b, tap = nb >> 2, cb = nb & 3;
+    const int toff = (tap / 3) * W + (tap % 3);
+    const int chunk = cb * 4 + ((half16 + jj * 4) >> 3), byte = (jj & 1) * 8;
+    const int r0 = 8 * h + q + toff, r1 = r0 + 4;
+    base_lo[b] = r0 * 256 + ((chunk ^ (r0 & 15)) << 4) + byte;
+    base_hi[b] = r1 * 256 + ((chunk ^ (r1 & 15)) << 4) + byte;
+    tapb[b] = tap;
+  }
+  const int Si = (int)S;
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int p0 = tile * T3;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage: z slab with BN+ReLU, dy tile, validity masks
+    stage_slab<4>(lds, z, p0, S, W, nrow, tid, sc, sh);
+    {
+      const int r = tid >> 1, c2 = tid & 1;              // 128 pixels x 4 chunks: two chunks per thread
+      const int p = p0 + r;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ch = c2 * 2 + u;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (p < Si) v = *reinterpret_cast<const uint4*>(dy + (long long)p * lddy + ch * 8);
+        *reinterpret_cast<uint4*>(dyt + r * 64 + ((ch ^ ((r >> 1) & 3)) << 4)) = v;
+      }
+    }
+    if (tid < T3) {   // tap validity of OUTPUT pixel p0 + tid (the reduction index)
+      const int p = p0 + tid;
+      unsigned m = 0;
+      if (p < Si) {
+        const int x = p % W, y = (p / W) % H;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) m |= 1u << (ky * 3 + kx);
+          }
+      }
+      vm[tid] = (unsigned short)m;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ks = 0; ks < 8; ++ks) {                     // 16 pixels per step
+      const int r_lo = ks * 16 + 8 * h + q, r_hi = r_lo + 4;   // tile pixel rows this lane supplies
+      // A operand: dy^T, channels l31 (32 wide), pixels = k
+      bf16x8 fa;
+      {
+        const int chunk = (half16 + jj * 4) >> 3, byte = ((jj & 1) * 8);
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(dyt + r_lo * 64 + ((chunk ^ ((r_lo >> 1) & 3)) << 4) + byte));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(dyt + r_hi * 64 + ((chunk ^ ((r_hi >> 1) & 3)) << 4) + byte));
+        fa[0] = lo[0]; fa[1] = lo[1]; fa[2] = lo[2]; fa[3] = lo[3];
+        fa[4] = hi[0]; fa[5] = hi[1]; fa[6] = hi[2]; fa[7] = hi[3];
+      }
+      const unsigned m_lo = vm[r_lo], m_hi = vm[r_hi];
+#pragma unroll
+      for (int b = 0; b < 9; ++b) {
+        const int byte = (jj & 1) * 8;
+        const int a_lo = ((m_lo >> tapb[b]) & 1u) ? base_lo[b] + ks * 4096 : zero_off + byte;
+        const int a_hi = ((m_hi >> tapb[b]) & 1u) ? base_hi[b] + ks * 4096 : zero_off + byte;
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + a_lo));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + a_hi));
+        bf16x8 fb;
+        fb[0] = lo[0]; fb[1] = lo[1]; fb[2] = lo[2]; fb[3] = lo[3];
+        fb[4] = hi[0]; fb[5] = hi[1]; fb[6] = hi[2]; fb[7] = hi[3];
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[b], 0, 0, 0);
+      }
+    }
+  }
+  // dW[co][n] += acc: co = (r&3) + 8*(r>>2) + 4*h, n = 32*nb + l31 of the 1152-wide row
+#pragma unroll
+  for (int b = 0; b < 9; ++b) {
+    const int n = 32 * (9 * wave + b) + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+      unsafeAtomicAdd(dW + co * (9 * C3_IN) + n, acc[b][r]);
+    }
+  }
+}
+
+extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                     float* dW, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dy || !z || !gamma || !beta || !mean || !rstd || !dW || S <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
+  if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (lddy % 8) || lddy < C3_OUT || (reinterpret_cast<uintptr_t>(dy) & 15u) ||
+      (reinterpret_cast<uintptr_t>(z) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int ntile = (int)((S + T3 - 1) / T3);
+  const size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256 + T3 * 64 + (T3 + 2 * W + 2) * 2 + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wrw_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  // The fp32 atomics of the epilogue (36,864 per workgroup) run at ~0.3 T lane-atomics/s: fewer, longer pixel
+  // ranges per workgroup trade compute parallelism against that (measured optimum per DenseNet stage size).
+  const int gmax = S >= 200000 ? 512 : (S >= 50000 ? 192 : 128);
+  const int grid = ntile < gmax ? ntile : gmax;
+  hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(grid), dim3(256), lds_bytes, mcl_stream(stream), (const bf16_t*)dy,
+                     (long long)lddy, (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

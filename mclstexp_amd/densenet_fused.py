@@ -255,6 +255,22 @@ def dense_conv3x3_fwd(z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor,
                                   yrstd.data_ptr(), _stream()), "mcl_dense_conv3x3_fwd")
 
 
+def dense_conv3x3_wrw(dy: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor, w_param: Tensor) -> bool:
+    """Adds the 3x3 weight gradient (a2 = relu(bn2(z)) recomputed in-kernel) straight into ``w_param.grad``.
+    Returns False (nothing done) when the parameter has no dense channels-last fp32 .grad to accumulate into."""
+    if not (USE_FUSED_3X3 and DIRECT_PARAM_GRADS and _direct_grad_ok(w_param)
+            and w_param.grad.permute(0, 2, 3, 1).is_contiguous() and tuple(w_param.shape) == (32, 128, 3, 3)
+            and dy.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and z.is_contiguous(memory_format=CL)):
+        return False
+    B, C, H, W = z.shape
+    pd, S, Co, lddy = _rows(dy)
+    assert Co == 32 and S == B * H * W
+    check(_lib.lib().mcl_dense_conv3x3_wrw(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(),
+                                           m2.data_ptr(), r2.data_ptr(), w_param.grad.data_ptr(), _stream()),
+          "mcl_dense_conv3x3_wrw")
+    return True
+
+
 def _fused_3x3_ok(z: Tensor, w16: Tensor) -> bool:
     return (USE_FUSED_3X3 and z.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16
             and tuple(w16.shape) == (32, 128, 3, 3) and w16.permute(0, 2, 3, 1).is_contiguous()
@@ -429,10 +445,17 @@ class DenseBlockFn(torch.autograd.Function):
             cin = C0 + l * growth
             dy = gbuf[:, cin:cin + growth].contiguous(memory_format=CL)
             m2, v2, r2 = bn2_stats[l]
+            dw2_done = False
             if a2.numel() == 0:   # fused forward: a2 = relu(bn2(z)) was never stored
-                a2 = torch.empty_like(z, memory_format=CL)
-                bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-            da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
+                dw2_done = dense_conv3x3_wrw(dy, z, g2, b2, m2, r2, w2)
+                if not dw2_done:
+                    a2 = torch.empty_like(z, memory_format=CL)
+                    bn_act_fwd(z, g2, b2, m2, r2, True, a2)
+            if dw2_done:
+                # data gradient only: the transposed convolution is MIOpen's backward-data kernel and needs no input
+                da2, dw2 = F.conv_transpose2d(dy, w2c, padding=1), None
+            else:
+                da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
             dz = torch.empty_like(z, memory_format=CL)
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
@@ -446,7 +469,7 @@ class DenseBlockFn(torch.autograd.Function):
             dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
                                   stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
             gw1 = dw1[1] if isinstance(dw1, tuple) else _wgrad(w1, dw1)
-            grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, _wgrad(w2, dw2)]
+            grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None if dw2_done else _wgrad(w2, dw2)]
         return (gbuf[:, :C0], None, *grads)
 
 
