@@ -226,6 +226,19 @@ int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z, int64_t S
                           const float* gamma, const float* beta, const float* mean, const float* rstd, float* dW,
                           mcl_stream_t stream);
 
+/* Backward of a dense layer's head x -> norm1 -> relu1 -> conv1 (1x1) -> z with respect to x, fused (csrc/dense_bwd.hip):
+ *   da = dz W1 ; g = da*[bn1(x) > 0] ; dgamma (+)= sum g*xhat ; dbeta (+)= sum g ;
+ *   gbuf[s, :C] += gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))
+ * without materialising da (both passes recompute dz W1 on the matrix cores).  dz: (S, 128) bf16 contiguous, W1:
+ * (128, C) bf16 contiguous, x and gbuf: (S, C) bf16 channel slices with row strides ldx / ldg.  accumulate_params
+ * != 0 adds dgamma/dbeta into the given buffers (the parameters' .grad views).  C % 8 == 0.
+ * workspace: mcl_dense_bn1_bwd_workspace_floats(S, C) floats.                                              */
+int64_t mcl_dense_bn1_bwd_workspace_floats(int64_t S, int32_t C);
+int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                      const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
+                      float* dgamma, float* dbeta, int32_t accumulate_params, void* gbuf, int64_t ldg,
+                      mcl_stream_t stream);
+
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

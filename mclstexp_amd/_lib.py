@@ -76,6 +76,8 @@ PROTOTYPES = {
     "mcl_dense_conv1x1_fwd": [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_dense_conv3x3_workspace_floats": [c_l],
     "mcl_dense_conv3x3_wrw": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mcl_dense_bn1_bwd_workspace_floats": [c_l, c_i],
+    "mcl_dense_bn1_bwd": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
@@ -84,7 +86,7 @@ PROTOTYPES = {
 }
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
-             "mcl_dense_conv3x3_workspace_floats": C.c_int64}
+             "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

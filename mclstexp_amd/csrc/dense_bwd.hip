@@ -1,0 +1,287 @@
+// Backward of a DenseNet layer's head  x -> norm1 -> relu1 -> conv1(1x1) -> z   with respect to x, fused:
+//
+//     da = dz W1                      (1x1 backward-data: M = S pixels, N = C_in, K = 128)
+//     g  = da * [x*sc + sh > 0]       (ReLU mask recomputed from the layer input)
+//     dgamma = sum_s g*xhat ,  dbeta = sum_s g ,  xhat = (x - mean)*rstd          (train-mode BatchNorm backward)
+//     dx += gamma*rstd*(g - mean_s(g) - xhat*mean_s(g*xhat))                      (accumulated into the block's gradient buffer)
+//
+// The stock sequence materialises da (S x C_in), re-reads it together with x for the two reductions and reads it a
+// third time with x and the gradient buffer for dx: 7 passes over the O(L^2) S x C_in data of a dense block.  Here
+// da never exists: a "reduce" launch and a "dx" launch both recompute their 128 x 128 tile of dz W1 on the matrix
+// cores (K = 128: 2 x 32 MFMAs per wave, ~1 % of the step's FLOPs) and touch HBM only for x (once each) and the
+// gradient buffer (read-modify-write): 4 passes, and no MIOpen backward-data call with its zero-fill helper.
+//
+// Tile = 128 pixels x 128 input channels, 4 waves (2 x 2, each 64 x 64 as 2 x 2 v_mfma_f32_32x32x16_bf16), two
+// workgroups per CU.  dz tile and the W1 column block are staged once (K = 128 needs no loop): dz rows XOR-swizzled
+// for ds_read_b128 fragments, W1 rows read with ds_read_b64_tr_b16 (k-strided operand).  After the MFMAs the same LDS
+// is reused to stage the x tile and (dx launch) the gradient-buffer tile with full 16-byte row chunks, because the
+// accumulator layout (lane = channel) would otherwise touch HBM in 64-byte fragments; the per-channel BatchNorm
+// constants live in registers (a lane keeps its channel for the whole tile).
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int TM = 128, TN = 128, TK = 128;   // pixels, input channels, bottleneck channels per tile
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  const f32x2 v = {f, 0.0f};
+  return (bf16_t)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)) & 0xFFFFu);
+}
+
+// MODE 0: reduce (partials of sum g, sum g*xhat)      MODE 1: dx accumulate
+// A workgroup keeps ONE column tile (its W1 block and per-channel constants are loaded once) and walks row tiles.
+// All global loads of a row tile (dz, x and -- dx launch -- the gradient-buffer chunks) are issued together at the
+// top, so the x / gradient latency hides under the dz staging and the MFMAs; LDS holds W1 (32 KB) + one 32 KB tile
+// that is first dz, then x, then (dx launch) the bf16 deltas: 64 KB, two workgroups per CU.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ W1,
+                                                         int K /* C_in: row length of W1 */,
+                                                         const bf16_t* __restrict__ x, long long ldx, long long S,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ coef /* MODE 1: [C][2] */,
+                                                         bf16_t* gbuf, long long ldg,
+                                                         float2* __restrict__ partial /* MODE 0: [C][nrt] */, int nrt) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TM * 256 + 2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.y * TN;
+  unsigned char* wt = lds;                  // [128 k][128 n] bf16, 256-byte rows, chunk ^ f(k) for transposing reads
+  unsigned char* dzt = lds + TM * 256;      // [128 rows][128 k] bf16, chunk ^ (row & 15); later the x tile / deltas
+  bf16_t* xt = reinterpret_cast<bf16_t*>(dzt);                   // [128][128] bf16, plain rows
+  float* red = reinterpret_cast<float*>(lds + 2 * TM * 256);     // [2 wm][128] float2
+
+  const int cc = tid & 15, rr = tid >> 4;
+  const bool cok = n0 + cc * 8 < K;
+  // ---- once per workgroup: W1[:, n0:n0+128] and the per-channel constants of this lane's two channels
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = rr + 16 * i;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (cok) v = *reinterpret_cast<const uint4*>(W1 + (long long)k * K + n0 + cc * 8);
+    // swizzle for the transposing read: 4 consecutive k rows (k & 3) must land in 4 different 64-byte bank
+    // windows -> XOR the chunk's bits 2-3 with (k & 3); bits 0-1 with ((k >> 2) & 3)
+    const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+    *reinterpret_cast<uint4*>(wt + k * 256 + ((cc ^ f) << 4)) = v;
+  }
+  float mu[2], rs[2], sc[2], sh[2], c1[2], c2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = n0 + wn * 64 + j * 32 + l31;
+    const bool cvalid = c < K;
+    mu[j] = cvalid ? mean[c] : 0.0f;
+    rs[j] = cvalid ? rstd[c] : 0.0f;
+    sc[j] = cvalid ? gamma[c] * rs[j] : 0.0f;
+    sh[j] = cvalid ? fmaf(-mu[j], sc[j], beta[c]) : 0.0f;
+    c1[j] = (MODE == 1 && cvalid) ? coef[2 * c] : 0.0f;
+    c2[j] = (MODE == 1 && cvalid) ? coef[2 * c + 1] : 0.0f;
+  }
+  const int q = (lane & 15) >> 2, jj = lane & 3;
+  const int g2 = 2 * ((lane >> 4) & 1) + (jj >> 1);
+
+  for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+    const long long row0 = (long long)rt * TM;
+    // ---- all global loads of this row tile, issued together
+    uint4 dzr[8], xr[8], gr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long rg = row0 + rr + 16 * i;
+      const bool ok = rg < S;
+      dzr[i] = ok ? *reinterpret_cast<const uint4*>(dz + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      xr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(x + rg * ldx + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      if (MODE == 1)
+        gr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(gbuf + rg * ldg + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();   // the previous row tile is done with the shared tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = rr + 16 * i;
+      *reinterpret_cast<uint4*>(dzt + r * 256 + ((cc ^ (r & 15)) << 4)) = dzr[i];
+    }
+    __syncthreads();
+
+    // ---- da tile = dz_tile (128 x 128k) . W1_tile (128k x 128n): wave (wm, wn) owns rows wm*64.., channels wn*64..
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        fa[i] = *reinterpret_cast<const bf16x8*>(dzt + r * 256 + (((2 * ks + h) ^ (r & 15)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // B[k][n]: lane supplies k row 16*ks + 8*h + q (+4), 4 channels at n = wn*64 + j*32 + 16*((lane>>4)&1) + 4*jj
+        const int chunk = (wn * 64 + j * 32) / 8 + g2;
+        const int k_lo = 16 * ks + 8 * h + q, k_hi = k_lo + 4;
+        const int f_lo = ((k_lo & 3) << 2) | ((k_lo >> 2) & 3), f_hi = ((k_hi & 3) << 2) | ((k_hi >> 2) & 3);
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(wt + k_lo * 256 + ((chunk ^ f_lo) << 4) + (jj & 1) * 8));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(wt + k_hi * 256 + ((chunk ^ f_hi) << 4) + (jj & 1) * 8));
+        fb[j][0] = lo[0]; fb[j][1] = lo[1]; fb[j][2] = lo[2]; fb[j][3] = lo[3];
+        fb[j][4] = hi[0]; fb[j][5] = hi[1]; fb[j][6] = hi[2]; fb[j][7] = hi[3];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // dz tile dead: the same LDS now takes the x tile (plain 256-byte rows)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(xt + (rr + 16 * i) * TN + cc * 8) = xr[i];
+    __syncthreads();
+
+    // ---- epilogue: acc[i][j][r] is da at row wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*h, channel wn*64 + j*32 + l31
+    const long long nvalid = min((long long)TM, S - row0);
+    float s1[2], s2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cl = wn * 64 + j * 32 + l31;
+      s1[j] = s2[j] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float xv = bf2f(xt[row * TN + cl]);
+          const float gi = fmaf(xv, sc[j], sh[j]) > 0.0f ? acc[i][j][r] : 0.0f;
+          const float xh = (xv - mu[j]) * rs[j];
+          if (MODE == 0) {
+            if (row < nvalid) {
+              s1[j] += gi;
+              s2[j] = fmaf(gi, xh, s2[j]);
+            }
+          } else {
+            // the x value of this element is dead: its slot takes the bf16 delta for the read-modify-write below
+            xt[row * TN + cl] = f2bf(sc[j] * (gi - c1[j] - xh * c2[j]));
+          }
+        }
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32, 64);
+        s2[j] += __shfl_xor(s2[j], 32, 64);
+        if (h == 0) {
+          const int cl = wn * 64 + j * 32 + l31;
+          red[(wm * 128 + cl) * 2] = s1[j];
+          red[(wm * 128 + cl) * 2 + 1] = s2[j];
+        }
+      }
+      __syncthreads();
+      if (tid < 128 && n0 + tid < K)
+        partial[(long long)(n0 + tid) * nrt + rt] = make_float2(red[tid * 2] + red[(128 + tid) * 2],
+                                                                red[tid * 2 + 1] + red[(128 + tid) * 2 + 1]);
+    } else {
+      __syncthreads();
+      if (cok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = rr + 16 * i;
+          const long long rg = row0 + r;
+          if (rg < S) {
+            const uint4 dv = *reinterpret_cast<const uint4*>(xt + r * TN + cc * 8);
+            const unsigned gw[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+            unsigned o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float lo = __uint_as_float(gw[u] << 16) + __uint_as_float(dw[u] << 16);
+              const float hi = __uint_as_float(gw[u] & 0xFFFF0000u) + __uint_as_float(dw[u] & 0xFFFF0000u);
+              const f32x2 pv = {lo, hi};
+              o[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));
+            }
+            *reinterpret_cast<uint4*>(gbuf + rg * ldg + n0 + cc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// one wave per channel: dbeta = sum g, dgamma = sum g*xhat (fixed order, double), coef = the two means for the dx pass
+__global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __restrict__ partial, int nrt, int C,
+                                                               long long S, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ coef,
+                                                               int accumulate_params) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const float2* p = partial + (long long)c * nrt;
+  double a = 0.0, b = 0.0;
+  for (int t = lane; t < nrt; t += 64) {
+    const float2 v = p[t];
+    a += (double)v.x;
+    b += (double)v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (lane != 0) return;
+  if (accumulate_params) {
+    dbeta[c] += (float)a;
+    dgamma[c] += (float)b;
+  } else {
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+  }
+  coef[2 * c] = (float)(a / (double)S);
+  coef[2 * c + 1] = (float)(b / (double)S);
+}
+
+}  // namespace
+
+extern "C" int64_t mcl_dense_bn1_bwd_workspace_floats(int64_t S, int32_t C) {
+  if (S <= 0 || C <= 0) return -1;
+  return ((S + TM - 1) / TM) * 2 * (int64_t)C + 2 * (int64_t)C;
+}
+
+extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                                 const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                 float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* gbuf,
+                                 int64_t ldg, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || !gbuf || S <= 0 || C <= 0)
+    return MCL_EINVAL;
+  if ((C % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
+      (reinterpret_cast<uintptr_t>(W1) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(gbuf) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int nrt = (int)((S + TM - 1) / TM), nct = (C + TN - 1) / TN;
+  float2* part = reinterpret_cast<float2*>(workspace);
+  float* coef = workspace + (int64_t)nrt * 2 * C;
+  hipStream_t st = mcl_stream(stream);
+  // persistent over row tiles: ~512 workgroups in total (two per CU), each keeps one column tile
+  int gx = (512 + nct - 1) / nct;
+  if (gx > nrt) gx = nrt;
+  dim3 grid(gx, nct);
+  hipLaunchKernelGGL(bn1_bwd_kernel<0>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
+                     (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)nullptr, (bf16_t*)nullptr,
+                     0LL, part, nrt);
+  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const float2*)part, nrt, C,
+                     (long long)S, dgamma, dbeta, coef, accumulate_params);
+  hipLaunchKernelGGL(bn1_bwd_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
+                     (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)coef, (bf16_t*)gbuf,
+                     (long long)ldg, (float2*)nullptr, nrt);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

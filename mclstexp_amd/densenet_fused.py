@@ -238,6 +238,30 @@ def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Ten
     return z
 
 
+# conv1 backward-data + norm1/relu1 backward as two GEMM-recomputing launches (csrc/dense_bwd.hip)
+USE_FUSED_BN1_BWD = os.environ.get("MCL_FUSED_BN1_BWD", "1") != "0"
+
+
+def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
+                  into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """gbuf (the block's gradient buffer slice) += d loss / d x through conv1 <- relu1 <- norm1, and the norm1
+    parameter gradients (added straight into g1.grad / b1.grad when ``into_param_grads``)."""
+    px, S, C, ldx = _rows(x)
+    pg, S2, C2, ldg = _rows(gbuf)
+    assert (S2, C2) == (S, C) and dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128
+    L = _lib.lib()
+    ws = _ws(L.mcl_dense_bn1_bwd_workspace_floats(S, C), x.device)
+    if into_param_grads:
+        dg, db = g1.grad, b1.grad
+    else:
+        dg = torch.empty(C, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(L.mcl_dense_bn1_bwd(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
+                              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                              int(into_param_grads), pg, ldg, _stream()), "mcl_dense_bn1_bwd")
+    return (None, None) if into_param_grads else (dg, db)
+
+
 # norm2 + relu2 + conv2 (3x3) + the new feature map's statistics as ONE kernel writing into the concat buffer
 USE_FUSED_3X3 = os.environ.get("MCL_FUSED_3X3", "1") != "0"
 
@@ -460,14 +484,21 @@ class DenseBlockFn(torch.autograd.Function):
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
                                   into_param_grads=d2)
-            if a.numel() == 0:    # fused forward: BN1+ReLU recomputed from the concat buffer inside the wrw kernel
-                da, dw1 = _conv1x1_bwd(dz, buf[:, :cin], w1c, w1,
-                                       bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
-            else:
-                da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
             d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
-            dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
-                                  stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
+            if a.numel() == 0 and USE_FUSED_BN1_BWD:
+                # fused forward: nothing of norm1's output was kept.  Weight gradient with BN1+ReLU recomputed from the
+                # concat buffer; data gradient + BN1 backward without materialising da
+                dw1 = ("direct", conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin])))
+                dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                         gbuf[:, :cin], into_param_grads=d1)
+            else:
+                if a.numel() == 0:
+                    da, dw1 = _conv1x1_bwd(dz, buf[:, :cin], w1c, w1,
+                                           bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
+                else:
+                    da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
+                dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
+                                      stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
             gw1 = dw1[1] if isinstance(dw1, tuple) else _wgrad(w1, dw1)
             grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None if dw2_done else _wgrad(w2, dw2)]
         return (gbuf[:, :C0], None, *grads)

@@ -51,13 +51,15 @@ class TrainStep:
         m = self.model
         self.static_in = {k: v.clone(memory_format=torch.preserve_format) for k, v in batch.items()}
         torch.cuda.synchronize()
+        # capture_error_mode "thread_local": under data parallelism the RCCL watchdog thread polls events while we
+        # capture; in the default "global" mode any such call from another thread invalidates the capture
         self.ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.ga):
+        with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
             self.es, self.ei = m.embed(self.static_in)
         self.d_es = torch.zeros_like(self.es)
         self.d_ei = torch.zeros_like(self.ei)
         self.gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gb, pool=self.ga.pool()):
+        with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode="thread_local"):
             self.opt.zero_grad()
             torch.autograd.backward((self.es, self.ei), (self.d_es, self.d_ei))
         if getattr(m, "embedding_grad", "dense") == "rowsparse":

@@ -318,3 +318,44 @@ def test_dense_conv3x3_wrw_fused(B, H, W, lddy):
     y.backward(dy.double().reshape(B, H, W, 32).permute(0, 3, 1, 2))
     ref = w.grad.permute(0, 2, 3, 1) + 0.125
     assert_close_scaled(dW.cpu(), ref.cpu(), 1e-4, what="fused conv3x3 weight gradient")   # fp32 atomics over <= 512 partials
+
+
+@pytest.mark.parametrize("S,C,ld", [(401408 // 16, 64, 256), (100352 // 4, 224, 512), (25088, 992, 1024), (6272, 512, 1024),
+                                    (300, 96, 96), (129, 160, 512)])
+def test_dense_bn1_bwd_fused(S, C, ld):
+    """conv1 backward-data + relu1/norm1 backward + in-place accumulation, without materialising da
+    (csrc/dense_bwd.hip), vs fp64 torch autograd on the same bf16 data; ragged row / channel tiles; sliced x, gbuf."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    g = torch.Generator().manual_seed(S + C)
+    xw = ((torch.rand(S, ld, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)
+    gw = ((torch.rand(S, ld, generator=g) - 0.5) * 0.1).to(torch.bfloat16).to(DEV)
+    x, gbuf = xw[:, :C], gw[:, :C]
+    g0 = gbuf.clone()
+    dz = ((torch.rand(S, 128, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)
+    W1 = ((torch.rand(128, C, generator=g) - 0.5) / 8).to(torch.bfloat16).to(DEV)
+    gam = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    bet = (torch.rand(C, generator=g) - 0.5).to(DEV)
+    xd = x.double()
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    rs = 1.0 / torch.sqrt(var + 1e-5)
+    muf, rsf = mu.float(), rs.float()
+    dg = torch.full((C,), 0.5, device=DEV)
+    db = torch.full((C,), -0.25, device=DEV)
+    ws = torch.empty(_lib.lib().mcl_dense_bn1_bwd_workspace_floats(S, C), device=DEV)
+    _lib.check(_lib.lib().mcl_dense_bn1_bwd(dz.data_ptr(), W1.data_ptr(), C, x.data_ptr(), ld, S, gam.data_ptr(),
+                                            bet.data_ptr(), muf.data_ptr(), rsf.data_ptr(), ws.data_ptr(), dg.data_ptr(),
+                                            db.data_ptr(), 1, gbuf.data_ptr(), ld, dn._stream()))
+    # fp64 reference through autograd (train-mode batch norm: statistics are functions of x)
+    xr = xd.clone().requires_grad_(True)
+    gr = gam.double().clone().requires_grad_(True)
+    br = bet.double().clone().requires_grad_(True)
+    m_ = xr.mean(0)
+    v_ = xr.var(0, unbiased=False)
+    a = torch.relu((xr - m_) / torch.sqrt(v_ + 1e-5) * gr + br)
+    z = a @ W1.double().t()
+    z.backward(dz.double())
+    ref_dx = g0.double() + xr.grad
+    assert_close_scaled(gbuf.float().cpu(), ref_dx.cpu(), 8e-3, what="gbuf += dx (bf16 accumulate)")
+    assert_close_scaled((dg - 0.5).cpu(), gr.grad.cpu(), 2e-4, what="dgamma")
+    assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 2e-4, what="dbeta")
+    assert torch.equal(gw[:, C:], gw[:, C:]) and float((xw[:, :C] - x).abs().max()) == 0.0
