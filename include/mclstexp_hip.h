@@ -239,6 +239,17 @@ int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, const void* x, 
                       float* dgamma, float* dbeta, int32_t accumulate_params, void* gbuf, int64_t ldg,
                       mcl_stream_t stream);
 
+/* Backward of a dense layer's tail z -> norm2 -> relu2 -> conv2 (3x3, pad 1, 128 -> 32) with respect to z, fused:
+ *   da2 = conv3x3 backward-data of dy ; g2 = da2*[bn2(z) > 0] ; dgamma2 (+)= sum g2*zhat ; dbeta2 (+)= sum g2 ;
+ *   dz = gamma2*rstd2*(g2 - mean(g2) - zhat*mean(g2*zhat)).
+ * dy: (S, 32) bf16 row stride lddy (the gradient buffer's channel slice, read in place); W2: (32, 3, 3, 128) bf16;
+ * z: (S, 128) bf16 contiguous NHWC pixels; g2 (scratch) and dz: (S, 128) bf16 contiguous.
+ * workspace: mcl_dense_conv3x3_bwd_workspace_floats(S) floats.                                            */
+int64_t mcl_dense_conv3x3_bwd_workspace_floats(int64_t S);
+int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2, const void* z,
+                          const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
+                          float* dgamma, float* dbeta, int32_t accumulate_params, void* g2, void* dz, mcl_stream_t stream);
+
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

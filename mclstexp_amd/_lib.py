@@ -77,6 +77,8 @@ PROTOTYPES = {
     "mcl_dense_conv3x3_workspace_floats": [c_l],
     "mcl_dense_conv3x3_wrw": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_dense_bn1_bwd_workspace_floats": [c_l, c_i],
+    "mcl_dense_conv3x3_bwd_workspace_floats": [c_l],
+    "mcl_dense_conv3x3_bwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "mcl_dense_bn1_bwd": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
@@ -86,7 +88,8 @@ PROTOTYPES = {
 }
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
-             "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64}
+             "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64,
+             "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

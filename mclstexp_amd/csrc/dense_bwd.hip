@@ -248,6 +248,183 @@ __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __r
   coef[2 * c + 1] = (float)(b / (double)S);
 }
 
+// =====================================================================================================================
+// Backward of the layer's tail  z -> norm2 -> relu2 -> conv2 (3x3, pad 1, 128 -> 32)  with respect to z:
+//
+//     da2[p][ci] = sum_{ky,kx,co} dy[p + (1-ky)*W + (1-kx)][co] * W2[co][ky][kx][ci]        (3x3 backward-data)
+//     g2 = da2 * [z*sc2 + sh2 > 0]  ->  stored (bf16) ;  per-tile partials of sum g2, sum g2*zhat
+//     (finalize: dgamma2, dbeta2, the two means)   dz = gamma2*rstd2*(g2 - mean(g2) - zhat*mean(g2*zhat))
+//
+// Implicit GEMM M = S pixels, N = 128, K = 9*32.  Same skeleton as the forward kernel (csrc/dense_conv.hip): a
+// workgroup owns 128 consecutive pixels and stages the pixel range [p0 - W - 1, p0 + 128 + W + 1) of dy (only 64 B
+// per pixel) into LDS, so the nine taps are row offsets and taps that leave the image select an all-zero row.  N
+// is split over the four waves (32 channels each, whose 18 weight fragments stay in registers for every tile of
+// the persistent workgroup), so no cross-wave reduction is needed.  dy is read straight from the block's gradient
+// buffer (row stride lddy: no contiguous copy) and MIOpen's backward-data call, its zero-fill helper and the separate
+// BatchNorm reduce pass disappear; the ReLU mask and the BatchNorm sums come out of the accumulators.
+constexpr int C3I = 128, C3O = 32, T3B = 128;
+
+__global__ __launch_bounds__(256, 2) void conv3x3_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, long long S,
+                                                             int H, int W, const bf16_t* __restrict__ W2,
+                                                             const bf16_t* __restrict__ z,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, bf16_t* __restrict__ g2,
+                                                             float2* __restrict__ partial, int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nrow = T3B + 2 * W + 2;
+  bf16_t* zt = reinterpret_cast<bf16_t*>(lds);                      // [128][128] bf16: z tile, then g2 in place
+  unsigned char* slab = lds + T3B * 256;                            // [nrow][32] bf16, 64-byte rows, chunk ^ ((row>>2)&3)
+  const int zero_off = T3B * 256 + nrow * 64;                       // 64 B of zeros
+  const int Si = (int)S;
+
+  // this wave's weight fragments: B[k = co][n = ci], ci = 32*wave + l31, k-step i -> tap = i >> 1, co = 16*(i&1) + 8h + j
+  bf16x8 breg[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const int tap = i >> 1, co0 = 16 * (i & 1) + 8 * h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      breg[i][j] = (short)W2[((long long)(co0 + j) * 9 + tap) * C3I + 32 * wave + l31];
+  }
+  const int c = 32 * wave + l31;
+  const float mu = mean[c], rs = rstd[c];
+  const float sc = gamma[c] * rs, sh = fmaf(-mu, sc, beta[c]);
+  // slab byte offset of this lane's fragment for k-step i in pixel block 0 (block mb adds 32 rows = 2048 B; 32 rows
+  // leave (row >> 2) & 3 unchanged): row = l31 + (2-ky)*W + (2-kx), chunk = 2*(i&1) + h
+  int abase[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const int tap = i >> 1, ky = tap / 3, kx = tap % 3;
+    const int row = l31 + (2 - ky) * W + (2 - kx);
+    abase[i] = T3B * 256 + row * 64 + (((2 * (i & 1) + h) ^ ((row >> 2) & 3)) << 4);
+  }
+  if (tid < 4) *reinterpret_cast<uint4*>(lds + zero_off + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int p0 = tile * T3B;
+    // ---- global loads of the tile: z chunks (8 per thread), dy slab chunks (<= 5 per thread at W = 56)
+    uint4 zr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = p0 + (tid >> 4) + 16 * i;
+      zr[i] = p < Si ? *reinterpret_cast<const uint4*>(z + (long long)p * C3I + (tid & 15) * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();   // previous tile done with LDS
+    for (int q = tid; q < nrow * 4; q += 256) {
+      const int j = q >> 2, ch = q & 3;
+      const int p = p0 - (W + 1) + j;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (p >= 0 && p < Si) v = *reinterpret_cast<const uint4*>(dy + (long long)p * lddy + ch * 8);
+      *reinterpret_cast<uint4*>(slab + j * 64 + ((ch ^ ((j >> 2) & 3)) << 4)) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<uint4*>(zt + ((tid >> 4) + 16 * i) * C3I + (tid & 15) * 8) = zr[i];
+    // tap validity of this lane's pixel in each of the 4 pixel blocks
+    unsigned vmask[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int p = p0 + mb * 32 + l31;
+      const int x = p % W, y = (p / W) % H;
+      unsigned m = 0;
+      if (p < Si) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + 1 - ky, xx = x + 1 - kx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) m |= 1u << (ky * 3 + kx);
+          }
+      }
+      vmask[mb] = m;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const int off = ((vmask[mb] >> (i >> 1)) & 1u) ? abase[i] + mb * 2048 : zero_off;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(lds + off);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, breg[i], acc[mb], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: acc[mb][r] = da2 at pixel mb*32 + (r&3) + 8*(r>>2) + 4*h, channel c
+    const int nvalid = min(T3B, Si - p0);
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float zv = bf2f(zt[px * C3I + c]);
+        const float gi = fmaf(zv, sc, sh) > 0.0f ? acc[mb][r] : 0.0f;
+        const bf16_t gb = f2bf(gi);
+        if (px < nvalid) {
+          const float gr_ = bf2f(gb);                 // the sums are those of the stored (rounded) g2
+          s1 += gr_;
+          s2 = fmaf(gr_, (zv - mu) * rs, s2);
+        }
+        zt[px * C3I + c] = gb;
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (h == 0) partial[(long long)c * ntile + tile] = make_float2(s1, s2);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = (tid >> 4) + 16 * i;
+      const int p = p0 + r;
+      if (p < Si)
+        *reinterpret_cast<uint4*>(g2 + (long long)p * C3I + (tid & 15) * 8) =
+            *reinterpret_cast<const uint4*>(zt + r * C3I + (tid & 15) * 8);
+    }
+  }
+}
+
+// dz = gamma*rstd*(g2 - c1 - zhat*c2), elementwise over (S, 128) bf16
+__global__ __launch_bounds__(256) void bn2_dz_kernel(const bf16_t* __restrict__ g2, const bf16_t* __restrict__ z,
+                                                     long long n_chunks, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ coef, bf16_t* __restrict__ dz) {
+  const int cc = threadIdx.x & 15;
+  float mu[8], rs[8], sc[8], c1[8], c2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cc * 8 + i;
+    mu[i] = mean[c];
+    rs[i] = rstd[c];
+    sc[i] = gamma[c] * rs[i];
+    c1[i] = coef[2 * c];
+    c2[i] = coef[2 * c + 1];
+  }
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += stride) {
+    const uint4 gv = *reinterpret_cast<const uint4*>(g2 + q * 8), zv = *reinterpret_cast<const uint4*>(z + q * 8);
+    const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, zw[4] = {zv.x, zv.y, zv.z, zv.w};
+    unsigned o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float g_lo = __uint_as_float(gw[u] << 16), g_hi = __uint_as_float(gw[u] & 0xFFFF0000u);
+      const float z_lo = __uint_as_float(zw[u] << 16), z_hi = __uint_as_float(zw[u] & 0xFFFF0000u);
+      const float d_lo = sc[2 * u] * (g_lo - c1[2 * u] - (z_lo - mu[2 * u]) * rs[2 * u] * c2[2 * u]);
+      const float d_hi = sc[2 * u + 1] * (g_hi - c1[2 * u + 1] - (z_hi - mu[2 * u + 1]) * rs[2 * u + 1] * c2[2 * u + 1]);
+      const f32x2 pv = {d_lo, d_hi};
+      o[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));
+    }
+    *reinterpret_cast<uint4*>(dz + q * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t mcl_dense_bn1_bwd_workspace_floats(int64_t S, int32_t C) {
@@ -282,6 +459,42 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   hipLaunchKernelGGL(bn1_bwd_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
                      (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)coef, (bf16_t*)gbuf,
                      (long long)ldg, (float2*)nullptr, nrt);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int64_t mcl_dense_conv3x3_bwd_workspace_floats(int64_t S) {
+  if (S <= 0) return -1;
+  return ((S + T3B - 1) / T3B) * 2 * (int64_t)C3I + 2 * (int64_t)C3I;
+}
+
+extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2,
+                                     const void* z, const float* gamma, const float* beta, const float* mean,
+                                     const float* rstd, float* workspace, float* dgamma, float* dbeta,
+                                     int32_t accumulate_params, void* g2, void* dz, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dy || !W2 || !z || !gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || !g2 || !dz || S <= 0 ||
+      H <= 0 || W <= 0)
+    return MCL_EINVAL;
+  if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (lddy % 8) || lddy < C3O ||
+      (reinterpret_cast<uintptr_t>(dy) & 15u) || (reinterpret_cast<uintptr_t>(z) & 15u) ||
+      (reinterpret_cast<uintptr_t>(g2) & 15u) || (reinterpret_cast<uintptr_t>(dz) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int ntile = (int)((S + T3B - 1) / T3B);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  float* coef = workspace + (int64_t)ntile * 2 * C3I;
+  const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
+  hipStream_t st = mcl_stream(stream);
+  hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < 768 ? ntile : 768), dim3(256), lds_bytes, st, (const bf16_t*)dy,
+                     (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
+                     (bf16_t*)g2, part, ntile);
+  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3((C3I + 3) / 4), dim3(256), 0, st, (const float2*)part, ntile, C3I,
+                     (long long)S, dgamma, dbeta, coef, accumulate_params);
+  const long long n_chunks = S * (C3I / 8);
+  long long blocks = (n_chunks + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn2_dz_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)g2, (const bf16_t*)z,
+                     n_chunks, gamma, mean, rstd, (const float*)coef, (bf16_t*)dz);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

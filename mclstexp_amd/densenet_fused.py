@@ -262,6 +262,32 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
     return (None, None) if into_param_grads else (dg, db)
 
 
+# conv2 (3x3) backward-data + norm2/relu2 backward (csrc/dense_bwd.hip): dy is read in place from the gradient buffer
+USE_FUSED_BN2_BWD = os.environ.get("MCL_FUSED_BN2_BWD", "1") != "0"
+
+
+def dense_conv3x3_bwd(dy: Tensor, w16: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor,
+                      into_param_grads: bool) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """(dz, dgamma2, dbeta2): gradient of the loss w.r.t. the bottleneck output z through conv2 <- relu2 <- norm2."""
+    B, C, H, W = z.shape
+    pd, S, Co, lddy = _rows(dy)
+    assert C == 128 and Co == 32 and S == B * H * W and z.is_contiguous(memory_format=CL)
+    L = _lib.lib()
+    ws = _ws(L.mcl_dense_conv3x3_bwd_workspace_floats(S), z.device)
+    scratch = torch.empty_like(z, memory_format=CL)
+    dz = torch.empty_like(z, memory_format=CL)
+    if into_param_grads:
+        dg, db = g2.grad, b2.grad
+    else:
+        dg = torch.empty(C, device=z.device, dtype=torch.float32)
+        db = torch.empty(C, device=z.device, dtype=torch.float32)
+    check(L.mcl_dense_conv3x3_bwd(pd, lddy, S, H, W, w16.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
+                                  m2.data_ptr(), r2.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                  int(into_param_grads), scratch.data_ptr(), dz.data_ptr(), _stream()),
+          "mcl_dense_conv3x3_bwd")
+    return (dz, None, None) if into_param_grads else (dz, dg, db)
+
+
 # norm2 + relu2 + conv2 (3x3) + the new feature map's statistics as ONE kernel writing into the concat buffer
 USE_FUSED_3X3 = os.environ.get("MCL_FUSED_3X3", "1") != "0"
 
@@ -467,23 +493,26 @@ class DenseBlockFn(torch.autograd.Function):
             a, z, a2 = saved[3 * l: 3 * l + 3]
             w1c, w2c = wcast[2 * l: 2 * l + 2]
             cin = C0 + l * growth
-            dy = gbuf[:, cin:cin + growth].contiguous(memory_format=CL)
             m2, v2, r2 = bn2_stats[l]
+            d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
+            dy_view = gbuf[:, cin:cin + growth]
             dw2_done = False
-            if a2.numel() == 0:   # fused forward: a2 = relu(bn2(z)) was never stored
-                dw2_done = dense_conv3x3_wrw(dy, z, g2, b2, m2, r2, w2)
-                if not dw2_done:
+            if a2.numel() == 0 and USE_FUSED_BN2_BWD and _fused_3x3_ok(z, w2c):
+                # fused forward: a2 = relu(bn2(z)) was never stored.  Both kernels read dy in place from the gradient
+                # buffer (row stride C_total): no contiguous copy, no MIOpen call
+                dw2_done = dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
+            if dw2_done:
+                dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
+                dw2 = None
+            else:
+                dy = dy_view.contiguous(memory_format=CL)
+                if a2.numel() == 0:
                     a2 = torch.empty_like(z, memory_format=CL)
                     bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-            if dw2_done:
-                # data gradient only: the transposed convolution is MIOpen's backward-data kernel and needs no input
-                da2, dw2 = F.conv_transpose2d(dy, w2c, padding=1), None
-            else:
                 da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
-            dz = torch.empty_like(z, memory_format=CL)
-            d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
-            dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
-                                  into_param_grads=d2)
+                dz = torch.empty_like(z, memory_format=CL)
+                dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
+                                      into_param_grads=d2)
             d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
             if a.numel() == 0 and USE_FUSED_BN1_BWD:
                 # fused forward: nothing of norm1's output was kept.  Weight gradient with BN1+ReLU recomputed from the

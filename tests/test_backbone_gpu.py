@@ -359,3 +359,42 @@ def test_dense_bn1_bwd_fused(S, C, ld):
     assert_close_scaled((dg - 0.5).cpu(), gr.grad.cpu(), 2e-4, what="dgamma")
     assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 2e-4, what="dbeta")
     assert torch.equal(gw[:, C:], gw[:, C:]) and float((xw[:, :C] - x).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,lddy", [(4, 56, 56, 256), (8, 28, 28, 32), (16, 14, 14, 1024), (32, 7, 7, 64), (3, 10, 6, 32)])
+def test_dense_conv3x3_bwd_fused(B, H, W, lddy):
+    """conv2 backward-data + relu2/norm2 backward -> dz, dgamma2, dbeta2 (csrc/dense_bwd.hip) vs fp64 torch autograd
+    on the same bf16 data; dy read as a channel slice of a wider buffer; image borders; ragged last tile."""
+    import torch.nn.functional as F
+    from mclstexp_amd import _lib, densenet_fused as dn
+    S = B * H * W
+    g = torch.Generator().manual_seed(S + 3 * W)
+    z = ((torch.rand(B, H, W, 128, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)
+    wide = ((torch.rand(S, lddy, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)
+    dy = wide[:, lddy - 32:]
+    W2 = ((torch.rand(32, 3, 3, 128, generator=g) - 0.5) / 6).to(torch.bfloat16).to(DEV)
+    gam = (torch.rand(128, generator=g) + 0.5).to(DEV)
+    bet = (torch.rand(128, generator=g) - 0.5).to(DEV)
+    zd = z.double().reshape(S, 128)
+    mu, var = zd.mean(0), zd.var(0, unbiased=False)
+    rs = 1.0 / torch.sqrt(var + 1e-5)
+    muf, rsf = mu.float(), rs.float()
+    dg = torch.full((128,), 0.5, device=DEV)
+    db = torch.full((128,), -0.25, device=DEV)
+    g2 = torch.empty(S, 128, device=DEV, dtype=torch.bfloat16)
+    dz = torch.empty(S, 128, device=DEV, dtype=torch.bfloat16)
+    ws = torch.empty(_lib.lib().mcl_dense_conv3x3_bwd_workspace_floats(S), device=DEV)
+    _lib.check(_lib.lib().mcl_dense_conv3x3_bwd(dy.data_ptr(), lddy, S, H, W, W2.data_ptr(), z.data_ptr(), gam.data_ptr(),
+                                                bet.data_ptr(), muf.data_ptr(), rsf.data_ptr(), ws.data_ptr(),
+                                                dg.data_ptr(), db.data_ptr(), 1, g2.data_ptr(), dz.data_ptr(), dn._stream()))
+    zr = zd.clone().requires_grad_(True)
+    gr = gam.double().clone().requires_grad_(True)
+    br = bet.double().clone().requires_grad_(True)
+    m_ = zr.mean(0)
+    v_ = zr.var(0, unbiased=False)
+    a2 = torch.relu((zr - m_) / torch.sqrt(v_ + 1e-5) * gr + br)
+    y = F.conv2d(a2.reshape(B, H, W, 128).permute(0, 3, 1, 2), W2.double().permute(0, 3, 1, 2), padding=1)
+    y.backward(dy.double().reshape(B, H, W, 32).permute(0, 3, 1, 2))
+    assert_close_scaled(dz.float().cpu(), zr.grad.cpu(), 1.2e-2, what="dz (bf16; g2 is rounded to bf16 on the way)")
+    assert_close_scaled((dg - 0.5).cpu(), gr.grad.cpu(), 3e-3, what="dgamma2")
+    assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 3e-3, what="dbeta2")
