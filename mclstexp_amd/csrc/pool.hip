@@ -1,0 +1,194 @@
+// Pooling layers of the DenseNet stem / transitions on channels-last bf16 (torchvision: pool0 = MaxPool2d(3, 2, 1),
+// transition.pool = AvgPool2d(2, 2); /root/reference/model.py:75-76 via torchvision).  ATen's NHWC pooling
+// backward kernels run at ~1 TB/s on these shapes; these are plain HBM-streaming kernels, one thread per 16-byte
+// channel chunk (8 channels) of one pixel.
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = {f[2 * i], f[2 * i + 1]};
+    w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// y[n, oy, ox, c] = mean of the 2x2 window (H, W even); fp32 accumulation, one rounding
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N,
+                                                           int H, int W, int C8) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = (long long)N * OH * OW * C8;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int c8 = (int)(q % C8);
+    const long long op = q / C8;
+    const int ox = (int)(op % OW), oy = (int)((op / OW) % OH), n = (int)(op / ((long long)OW * OH));
+    const long long base = (((long long)n * H + 2 * oy) * W + 2 * ox) * C8 + c8;
+    float a[8], b[8], c[8], d[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + base * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(x + (base + C8) * 8), b);
+    unpack8(*reinterpret_cast<const uint4*>(x + (base + (long long)W * C8) * 8), c);
+    unpack8(*reinterpret_cast<const uint4*>(x + (base + (long long)W * C8 + C8) * 8), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.25f * ((a[i] + b[i]) + (c[i] + d[i]));
+    *reinterpret_cast<uint4*>(y + q * 8) = pack8(o);
+  }
+}
+
+// dx[n, y, x, c] = dy[n, y/2, x/2, c] / 4
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N,
+                                                           int H, int W, int C8) {
+  const int OH = H / 2, OW = W / 2;
+  const long long total = (long long)N * H * W * C8;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int c8 = (int)(q % C8);
+    const long long p = q / C8;
+    const int xx = (int)(p % W), yy = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + ((((long long)n * OH + yy / 2) * OW + xx / 2) * C8 + c8) * 8), g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] *= 0.25f;
+    *reinterpret_cast<uint4*>(dx + q * 8) = pack8(g);
+  }
+}
+
+// MaxPool2d(3, stride 2, pad 1): y = max over the window (padding = -inf)
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N,
+                                                             int H, int W, int OH, int OW, int C8) {
+  const long long total = (long long)N * OH * OW * C8;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int c8 = (int)(q % C8);
+    const long long op = q / C8;
+    const int ox = (int)(op % OW), oy = (int)((op / OW) % OH), n = (int)(op / ((long long)OW * OH));
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          float v[8];
+          unpack8(*reinterpret_cast<const uint4*>(x + ((((long long)n * H + iy) * W + ix) * C8 + c8) * 8), v);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+        }
+      }
+    *reinterpret_cast<uint4*>(y + q * 8) = pack8(m);
+  }
+}
+
+// dx[n, iy, ix, c] = sum over the (<= 4) windows that contain the pixel AND whose FIRST maximum (row-major window
+// order, ATen's tie rule) is this pixel, of dy.  Gather form: deterministic, no atomics; the maxima are recomputed
+// from x and the pooled y instead of storing indices.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                             const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                             int N, int H, int W, int OH, int OW, int C8) {
+  const long long total = (long long)N * H * W * C8;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int c8 = (int)(q % C8);
+    const long long p = q / C8;
+    const int ix = (int)(p % W), iy = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+    float xv[8], acc[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + q * 8), xv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+    // windows oy with 2*oy-1 <= iy <= 2*oy+1  <=>  iy/2 <= oy <= (iy+1)/2   (iy >= 0)
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        const long long oq = ((((long long)n * OH + oy) * OW + ox) * C8 + c8) * 8;
+        float mv[8], gv[8];
+        unpack8(*reinterpret_cast<const uint4*>(y + oq), mv);
+        unpack8(*reinterpret_cast<const uint4*>(dy + oq), gv);
+        // is this pixel the first element of the window equal to the maximum?
+        bool first[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) first[i] = xv[i] == mv[i];
+        const int wy = iy - (2 * oy - 1), wx = ix - (2 * ox - 1);      // position inside the window
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            if (ky * 3 + kx >= wy * 3 + wx) continue;                  // only earlier positions can pre-empt
+            const int jy = 2 * oy - 1 + ky, jx = 2 * ox - 1 + kx;
+            if (jy < 0 || jy >= H || jx < 0 || jx >= W) continue;
+            float ov[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + ((((long long)n * H + jy) * W + jx) * C8 + c8) * 8), ov);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) first[i] = first[i] && !(ov[i] == mv[i]);
+          }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += first[i] ? gv[i] : 0.0f;
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + q * 8) = pack8(acc);
+  }
+}
+
+inline bool ok16(const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline unsigned blocks_for(long long total) {
+  long long b = (total + 255) / 256;
+  return (unsigned)(b > 16384 ? 16384 : b);
+}
+
+}  // namespace
+
+extern "C" int mcl_avgpool2_nhwc_bf16(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t backward,
+                                      mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!ok16(x) || !ok16(y) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
+  if ((H & 1) || (W & 1) || (C % 8)) return MCL_EUNSUPPORTED;
+  const int C8 = C / 8;
+  if (!backward) {
+    const long long total = (long long)N * (H / 2) * (W / 2) * C8;
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
+                       (bf16_t*)y, N, H, W, C8);
+  } else {   // x = dy (N, H/2, W/2, C), y = dx (N, H, W, C)
+    const long long total = (long long)N * H * W * C8;
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
+                       (bf16_t*)y, N, H, W, C8);
+  }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
+                                            mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!ok16(x) || !ok16(y) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
+  if (C % 8) return MCL_EUNSUPPORTED;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 8);
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
+                     (bf16_t*)y, N, H, W, OH, OW, C / 8);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd(const void* x, const void* y, const void* dy, void* dx, int32_t N, int32_t H,
+                                            int32_t W, int32_t C, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!ok16(x) || !ok16(y) || !ok16(dy) || !ok16(dx) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
+  if (C % 8) return MCL_EUNSUPPORTED;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
+                     (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

@@ -565,6 +565,65 @@ def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats) -> Tuple[Tensor, 
     return buf, stats
 
 
+# --------------------------------------------------------------------------- pooling (csrc/pool.hip)
+USE_HIP_POOLS = os.environ.get("MCL_HIP_POOLS", "1") != "0"
+
+
+def _pool_ok(x: Tensor, even: bool) -> bool:
+    return (USE_HIP_POOLS and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=CL) and (not even or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    """nn.AvgPool2d(2, 2) of the transitions on channels-last bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=x.dtype, memory_format=CL)
+        check(_lib.lib().mcl_avgpool2_nhwc_bf16(x.data_ptr(), y.data_ptr(), B, H, W, C, 0, _stream()), "mcl_avgpool2")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = dy.contiguous(memory_format=CL)
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
+        check(_lib.lib().mcl_avgpool2_nhwc_bf16(dy.data_ptr(), dx.data_ptr(), B, H, W, C, 1, _stream()), "mcl_avgpool2")
+        return dx
+
+
+class MaxPool3s2Fn(torch.autograd.Function):
+    """nn.MaxPool2d(3, stride=2, padding=1) (pool0) on channels-last bf16; arg-max recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=x.dtype, memory_format=CL)
+        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "mcl_maxpool")
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dy = dy.contiguous(memory_format=CL)
+        dx = torch.empty_like(x, memory_format=CL)
+        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C,
+                                                      _stream()), "mcl_maxpool bwd")
+        return dx
+
+
+def max_pool_3s2(x: Tensor) -> Tensor:
+    return MaxPool3s2Fn.apply(x) if _pool_ok(x, False) else F.max_pool2d(x, 3, 2, 1)
+
+
+def avg_pool_2(x: Tensor) -> Tensor:
+    return AvgPool2Fn.apply(x) if _pool_ok(x, True) else F.avg_pool2d(x, 2, 2)
+
+
 def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
     """Train-mode forward of torchvision-layout DenseNet ``features`` (conv0 ... norm5), returning the
     (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly)."""
@@ -575,7 +634,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                  padding=features.conv0.padding)
     x = _bn_train(x, features.norm0, True, rec)
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = max_pool_3s2(x.contiguous(memory_format=CL))
     i = 1
     out = None
     while hasattr(features, f"denseblock{i}"):
@@ -586,7 +645,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
             a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
             rec.add(tr.norm, stats.mean, stats.var, n)
             x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
-            x = F.avg_pool2d(x, 2, 2)
+            x = avg_pool_2(x.contiguous(memory_format=CL))
         else:
             out = BNActFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd, False)
             rec.add(features.norm5, stats.mean, stats.var, n)

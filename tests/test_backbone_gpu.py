@@ -398,3 +398,32 @@ def test_dense_conv3x3_bwd_fused(B, H, W, lddy):
     assert_close_scaled(dz.float().cpu(), zr.grad.cpu(), 1.2e-2, what="dz (bf16; g2 is rounded to bf16 on the way)")
     assert_close_scaled((dg - 0.5).cpu(), gr.grad.cpu(), 3e-3, what="dgamma2")
     assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 3e-3, what="dbeta2")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 64, 112, 112), (3, 64, 17, 9), (2, 128, 56, 56), (5, 8, 6, 10)])
+def test_pool_kernels(B, C, H, W):
+    """csrc/pool.hip vs ATen on the same channels-last bf16 data: MaxPool2d(3,2,1) forward bit-exact and backward
+    with ATen's first-maximum tie rule (ReLU outputs are full of ties at 0); AvgPool2d(2,2) forward/backward."""
+    import torch.nn.functional as F
+    from mclstexp_amd import densenet_fused as dn
+    g = torch.Generator().manual_seed(B * H + W)
+    x = torch.relu(torch.rand(B, C, H, W, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    xm = x.clone().requires_grad_(True)
+    ym = dn.max_pool_3s2(xm)
+    assert torch.equal(ym.float(), yr.detach()), "max pool forward"
+    dy = (torch.rand(yr.shape, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    yr.backward(dy.float())
+    ym.backward(dy)
+    assert_close(xm.grad.float().cpu(), xr.grad.to(torch.bfloat16).float().cpu(), 1e-2, what="max pool backward")
+    if H % 2 == 0 and W % 2 == 0:
+        xa = x.float().requires_grad_(True)
+        ya = F.avg_pool2d(xa, 2, 2)
+        xb = x.clone().requires_grad_(True)
+        yb = dn.avg_pool_2(xb)
+        assert_close(yb.detach().float().cpu(), ya.detach().cpu(), 4e-3, rtol=4e-3, what="avg pool forward")
+        d2 = (torch.rand(ya.shape, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+        ya.backward(d2.float())
+        yb.backward(d2)
+        assert_close(xb.grad.float().cpu(), xa.grad.cpu(), 2e-3, what="avg pool backward")
