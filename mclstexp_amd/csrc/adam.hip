@@ -6,6 +6,16 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector type (the non-temporal builtins reject HIP's float4 class)
+__device__ __forceinline__ float4 nt_load4(const float* q) {
+  const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void nt_store4(float* q, float4 a) {
+  const f32x4 t = {a.x, a.y, a.z, a.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(q));
+}
+
 struct AdamC {
   float lr_over_bc1, beta1, beta2, omb1, omb2, eps, wd, rsqrt_bc2;  // omb = 1 - beta, rounded from double
 };
@@ -70,9 +80,9 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
           const int r = r0 + k;
           ok[k] = r < n_rows;
           const long long base = (long long)(ok[k] ? r : r0) * cols;
-          pp[k] = __builtin_nontemporal_load(reinterpret_cast<const float4*>(p + base) + i);
-          mm[k] = __builtin_nontemporal_load(reinterpret_cast<const float4*>(m + base) + i);
-          vv[k] = __builtin_nontemporal_load(reinterpret_cast<const float4*>(v + base) + i);
+          pp[k] = nt_load4(p + base + 4 * i);
+          mm[k] = nt_load4(m + base + 4 * i);
+          vv[k] = nt_load4(v + base + 4 * i);
           const int slot = ok[k] ? row_slot[r] : -1;
           gg[k] = slot >= 0 ? reinterpret_cast<const float4*>(rg + (long long)slot * ldrg)[i]
                             : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -85,9 +95,9 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
           adam1(pp[k].z, gg[k].z, mm[k].z, vv[k].z, c);
           adam1(pp[k].w, gg[k].w, mm[k].w, vv[k].w, c);
           const long long base = (long long)(r0 + k) * cols;
-          __builtin_nontemporal_store(pp[k], reinterpret_cast<float4*>(p + base) + i);
-          __builtin_nontemporal_store(mm[k], reinterpret_cast<float4*>(m + base) + i);
-          __builtin_nontemporal_store(vv[k], reinterpret_cast<float4*>(v + base) + i);
+          nt_store4(p + base + 4 * i, pp[k]);
+          nt_store4(m + base + 4 * i, mm[k]);
+          nt_store4(v + base + 4 * i, vv[k]);
         }
       }
     }
