@@ -421,6 +421,21 @@ def _conv_bwd(dy, x, w, padding):
                                                [True, True, False])
 
 
+# The two weight-gradient kernels of a layer are independent of its data-gradient chain (they only add into .grad):
+# issue them on a side stream so they overlap the latency-bound backward-data / BatchNorm-backward launches (under
+# HIP-graph capture this becomes a parallel branch of the graph).  Joined at the end of every layer.
+USE_SIDE_STREAM = os.environ.get("MCL_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device) -> torch.cuda.Stream:
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = s
+    return s
+
+
 class DenseBlockFn(torch.autograd.Function):
     """A whole torchvision ``_DenseBlock`` (forward AND hand-scheduled backward).
 
@@ -497,10 +512,19 @@ class DenseBlockFn(torch.autograd.Function):
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dy_view = gbuf[:, cin:cin + growth]
             dw2_done = False
-            if a2.numel() == 0 and USE_FUSED_BN2_BWD and _fused_3x3_ok(z, w2c):
+            fused2 = a2.numel() == 0 and USE_FUSED_BN2_BWD and _fused_3x3_ok(z, w2c)
+            fused1 = a.numel() == 0 and USE_FUSED_BN1_BWD
+            main = torch.cuda.current_stream()
+            side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
+            if fused2:
                 # fused forward: a2 = relu(bn2(z)) was never stored.  Both kernels read dy in place from the gradient
                 # buffer (row stride C_total): no contiguous copy, no MIOpen call
-                dw2_done = dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
+                if side is not None:
+                    side.wait_stream(main)                      # this layer's slice of gbuf is final
+                    with torch.cuda.stream(side):
+                        dw2_done = dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
+                else:
+                    dw2_done = dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
             if dw2_done:
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 dw2 = None
@@ -514,12 +538,20 @@ class DenseBlockFn(torch.autograd.Function):
                 dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
                                       into_param_grads=d2)
             d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
-            if a.numel() == 0 and USE_FUSED_BN1_BWD:
+            if fused1:
                 # fused forward: nothing of norm1's output was kept.  Weight gradient with BN1+ReLU recomputed from the
                 # concat buffer; data gradient + BN1 backward without materialising da
-                dw1 = ("direct", conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin])))
+                bn1 = (g1, b1, stats.mean[:cin], stats.rstd[:cin])
+                if side is not None and dw2_done:
+                    side.wait_stream(main)                      # dz is ready
+                    with torch.cuda.stream(side):
+                        dw1 = ("direct", conv1x1_wrw(dz, buf[:, :cin], w1, bn=bn1))
+                else:
+                    dw1 = ("direct", conv1x1_wrw(dz, buf[:, :cin], w1, bn=bn1))
                 dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                          gbuf[:, :cin], into_param_grads=d1)
+                if side is not None:
+                    main.wait_stream(side)                      # join: dz / dy may be released or overwritten now
             else:
                 if a.numel() == 0:
                     da, dw1 = _conv1x1_bwd(dz, buf[:, :cin], w1c, w1,
