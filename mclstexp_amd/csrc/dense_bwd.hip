@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
     for (int j = 0; j < 2; ++j) {
       const int cl = wn * 64 + j * 32 + l31;
       s1[j] = s2[j] = 0.0f;
+      // dx = sc*(g - c1 - xhat*c2) = sc*g + (ka*x + kb);   sum g*xhat = rs*(sum g*x - mu*sum g)
+      const float ka = -sc[j] * c2[j] * rs[j], kb = fmaf(-ka, mu[j], -sc[j] * c1[j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -164,17 +166,17 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
           const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float xv = bf2f(xt[row * TN + cl]);
           const float gi = fmaf(xv, sc[j], sh[j]) > 0.0f ? acc[i][j][r] : 0.0f;
-          const float xh = (xv - mu[j]) * rs[j];
           if (MODE == 0) {
             if (row < nvalid) {
               s1[j] += gi;
-              s2[j] = fmaf(gi, xh, s2[j]);
+              s2[j] = fmaf(gi, xv, s2[j]);
             }
           } else {
             // the x value of this element is dead: its slot takes the bf16 delta for the read-modify-write below
-            xt[row * TN + cl] = f2bf(sc[j] * (gi - c1[j] - xh * c2[j]));
+            xt[row * TN + cl] = f2bf(fmaf(sc[j], gi, fmaf(ka, xv, kb)));
           }
         }
+      if (MODE == 0) s2[j] = rs[j] * fmaf(-mu[j], s1[j], s2[j]);
     }
     if (MODE == 0) {
 #pragma unroll
@@ -217,16 +219,17 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
   }
 }
 
-// one wave per channel: dbeta = sum g, dgamma = sum g*xhat (fixed order, double), coef = the two means for the dx pass
+// one WORKGROUP per channel: dbeta = sum g, dgamma = sum g*xhat (fixed order, double), coef = the two means for the
+// dx pass.  On the critical path between the reduce and dx launches of every layer.
 __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __restrict__ partial, int nrt, int C,
                                                                long long S, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ coef,
                                                                int accumulate_params) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
+  __shared__ double red[2][4];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float2* p = partial + (long long)c * nrt;
   double a = 0.0, b = 0.0;
-  for (int t = lane; t < nrt; t += 64) {
+  for (int t = threadIdx.x; t < nrt; t += 256) {
     const float2 v = p[t];
     a += (double)v.x;
     b += (double)v.y;
@@ -236,7 +239,14 @@ __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __r
     a += __shfl_xor(a, o, 64);
     b += __shfl_xor(b, o, 64);
   }
-  if (lane != 0) return;
+  if (lane == 0) {
+    red[0][wave] = a;
+    red[1][wave] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  b = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   if (accumulate_params) {
     dbeta[c] += (float)a;
     dgamma[c] += (float)b;
@@ -454,7 +464,7 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   hipLaunchKernelGGL(bn1_bwd_kernel<0>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
                      (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)nullptr, (bf16_t*)nullptr,
                      0LL, part, nrt);
-  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, (const float2*)part, nrt, C,
+  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float2*)part, nrt, C,
                      (long long)S, dgamma, dbeta, coef, accumulate_params);
   hipLaunchKernelGGL(bn1_bwd_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
                      (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)coef, (bf16_t*)gbuf,
@@ -488,7 +498,7 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
   hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < 768 ? ntile : 768), dim3(256), lds_bytes, st, (const bf16_t*)dy,
                      (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
                      (bf16_t*)g2, part, ntile);
-  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3((C3I + 3) / 4), dim3(256), 0, st, (const float2*)part, ntile, C3I,
+  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C3I), dim3(256), 0, st, (const float2*)part, ntile, C3I,
                      (long long)S, dgamma, dbeta, coef, accumulate_params);
   const long long n_chunks = S * (C3I / 8);
   long long blocks = (n_chunks + 255) / 256;

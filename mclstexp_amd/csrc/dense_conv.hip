@@ -226,16 +226,17 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   }
 }
 
-// one wave per channel: merge per-tile (sum, M2) pairs (Chan et al.), in double, fixed order
+// one WORKGROUP per channel: merge per-tile (sum, M2) pairs (Chan et al.), in double, fixed order.  (A wave per
+// channel walks up to 3136 partials in 49 dependent steps; the kernel sits on the critical path twice per layer.)
 __global__ __launch_bounds__(256) void tile_stats_finalize_kernel(const float2* __restrict__ partial, int nblk, int C,
                                                                   long long S, int BM, float eps,
                                                                   float* __restrict__ mean, float* __restrict__ var,
                                                                   float* __restrict__ rstd) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (c >= C) return;
+  __shared__ double red[2][4];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float2* p = partial + (long long)c * nblk;
   double sum = 0.0, q = 0.0;   // q = sum_t (M2_t + sum_t^2 / n_t)
-  for (int t = lane; t < nblk; t += 64) {
+  for (int t = threadIdx.x; t < nblk; t += 256) {
     const float2 v = p[t];
     const double nt = (double)min((long long)BM, S - (long long)t * BM);
     sum += (double)v.x;
@@ -246,7 +247,14 @@ __global__ __launch_bounds__(256) void tile_stats_finalize_kernel(const float2* 
     sum += __shfl_xor(sum, o, 64);
     q += __shfl_xor(q, o, 64);
   }
-  if (lane != 0) return;
+  if (lane == 0) {
+    red[0][wave] = sum;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   const double n = (double)S, m = sum / n;
   double v = (q - sum * sum / n) / n;
   if (v < 0.0) v = 0.0;
@@ -287,7 +295,7 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   else if (wm == 2) MCL_LAUNCH(2);
   else MCL_LAUNCH(1);
 #undef MCL_LAUNCH
-  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3((BN + 3) / 4), dim3(256), 0, st, (const float2*)part, nblk, BN,
+  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(BN), dim3(256), 0, st, (const float2*)part, nblk, BN,
                      (long long)S, bm, eps, zmean, zvar, zrstd);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
@@ -524,7 +532,7 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
   float2* part = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, st, (const bf16_t*)z, (long long)S, H, W,
                      gamma, beta, mean, rstd, (const bf16_t*)W2, (bf16_t*)out, (long long)ldo, part, ntile);
-  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3((C3_OUT + 3) / 4), dim3(256), 0, st, (const float2*)part, ntile,
+  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(C3_OUT), dim3(256), 0, st, (const float2*)part, ntile,
                      C3_OUT, (long long)S, T3, eps, ymean, yvar, yrstd);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
