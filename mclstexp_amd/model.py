@@ -211,6 +211,22 @@ class _ContrastiveBase(nn.Module):
         self.last: Dict[str, Tensor] = {}
         self.sparse_grads: Dict[str, ops.RowSparseGrad] = {}
 
+    # The spot branch (embedding add, spot Transformer, projection head: ~85 small latency-bound launches forward +
+    # backward) shares nothing with the image branch until the loss: run it on a side stream so it overlaps the
+    # DenseNet kernels.  Autograd replays each branch's backward on the stream its forward ran on, and under HIP-graph
+    # capture the fork/join becomes a parallel branch of both graphs.
+    overlap_branches = True
+    _branch_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+    def _branch_stream(self, device) -> Optional["torch.cuda.Stream"]:
+        if not (self.overlap_branches and device.type == "cuda"):
+            return None
+        s = _ContrastiveBase._branch_streams.get(device.index)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            _ContrastiveBase._branch_streams[device.index] = s
+        return s
+
     def _encode_image(self, encoder: nn.Module, image: Tensor) -> Tensor:
         if isinstance(encoder, nn.Identity):
             return image
@@ -311,13 +327,25 @@ class mclSTExp_Attention(_ContrastiveBase):
         self.spot_projection = ProjectionHead(embedding_dim=spot_dim, projection_dim=projection_dim)
         self._init_common(temperature, compute, backbone_dtype, embedding_grad, process_group, infonce)
 
-    def embed(self, batch):
-        ops.set_compute(self.compute)
-        image_features = self._encode_image(self.image_encoder, batch["image"])
-        image_embeddings = self.image_projection(image_features)
+    def _embed_spots(self, batch):
         spot_features = self._spot_features(batch).unsqueeze(dim=0)        # (1, B, G): batch is the sequence
         spot_embeddings = self.spot_encoder(spot_features)
-        spot_embeddings = self.spot_projection(spot_embeddings).squeeze(dim=0)
+        return self.spot_projection(spot_embeddings).squeeze(dim=0)
+
+    def embed(self, batch):
+        ops.set_compute(self.compute)
+        side = self._branch_stream(batch["expression"].device)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                spot_embeddings = self._embed_spots(batch)
+        image_features = self._encode_image(self.image_encoder, batch["image"])
+        image_embeddings = self.image_projection(image_features)
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            spot_embeddings = self._embed_spots(batch)
         return spot_embeddings, image_embeddings
 
     def forward(self, batch):
