@@ -253,13 +253,15 @@ int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, in
 /* Pooling layers of the DenseNet stem / transitions on channels-last bf16 (C % 8 == 0, 16-byte aligned, dense NHWC).
  * mcl_avgpool2_nhwc_bf16: AvgPool2d(2, 2); backward == 0: x (N,H,W,C) -> y (N,H/2,W/2,C); backward != 0: x is dy
  *   (N,H/2,W/2,C) and y receives dx (N,H,W,C) = dy/4.  H, W even.
- * mcl_maxpool3s2_*: MaxPool2d(3, stride 2, padding 1); the backward recomputes the arg-max from x and the pooled y
- *   (first maximum in row-major window order, ATen's tie rule) and GATHERS dy: deterministic, no atomics.  */
+ * mcl_maxpool3s2_*: MaxPool2d(3, stride 2, padding 1); the forward also records idx (one byte per output element:
+ *   window position of the first maximum in row-major order, ATen's tie rule); the backward GATHERS dy through it:
+ *   deterministic, no atomics.                                                                             */
 int mcl_avgpool2_nhwc_bf16(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t backward,
                            mcl_stream_t stream);
-int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, mcl_stream_t stream);
-int mcl_maxpool3s2_nhwc_bf16_bwd(const void* x, const void* y, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
-                                 int32_t C, mcl_stream_t stream);
+int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 mcl_stream_t stream);
+int mcl_maxpool3s2_nhwc_bf16_bwd(const void* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 mcl_stream_t stream);
 
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */

@@ -79,8 +79,8 @@ PROTOTYPES = {
     "mcl_dense_bn1_bwd_workspace_floats": [c_l, c_i],
     "mcl_dense_conv3x3_bwd_workspace_floats": [c_l],
     "mcl_avgpool2_nhwc_bf16": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "mcl_maxpool3s2_nhwc_bf16_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "mcl_maxpool3s2_nhwc_bf16_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_maxpool3s2_nhwc_bf16_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_maxpool3s2_nhwc_bf16_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_dense_conv3x3_bwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "mcl_dense_bn1_bwd": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],

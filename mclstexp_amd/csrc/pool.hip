@@ -66,17 +66,23 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16_t* __restr
   }
 }
 
-// MaxPool2d(3, stride 2, pad 1): y = max over the window (padding = -inf)
-__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N,
-                                                             int H, int W, int OH, int OW, int C8) {
+// MaxPool2d(3, stride 2, pad 1): y = max over the window (padding = -inf); idx = window position (ky*3 + kx) of the
+// FIRST maximum in row-major window order (ATen's tie rule: strict > while scanning), one byte per element
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                             unsigned char* __restrict__ idx, int N, int H, int W,
+                                                             int OH, int OW, int C8) {
   const long long total = (long long)N * OH * OW * C8;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
     const int c8 = (int)(q % C8);
     const long long op = q / C8;
     const int ox = (int)(op % OW), oy = (int)((op / OW) % OH), n = (int)(op / ((long long)OW * OH));
     float m[8];
+    unsigned am[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+    for (int i = 0; i < 8; ++i) {
+      m[i] = -INFINITY;
+      am[i] = 0;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -86,17 +92,24 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
           float v[8];
           unpack8(*reinterpret_cast<const uint4*>(x + ((((long long)n * H + iy) * W + ix) * C8 + c8) * 8), v);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+          for (int i = 0; i < 8; ++i)
+            if (v[i] > m[i]) {      // strict: the first maximum wins; the first valid element beats -inf
+              m[i] = v[i];
+              am[i] = ky * 3 + kx;
+            }
         }
       }
     *reinterpret_cast<uint4*>(y + q * 8) = pack8(m);
+    uint2 pk;
+    pk.x = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+    pk.y = am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24);
+    *reinterpret_cast<uint2*>(idx + q * 8) = pk;
   }
 }
 
-// dx[n, iy, ix, c] = sum over the (<= 4) windows that contain the pixel AND whose FIRST maximum (row-major window
-// order, ATen's tie rule) is this pixel, of dy.  Gather form: deterministic, no atomics; the maxima are recomputed
-// from x and the pooled y instead of storing indices.
-__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+// dx[n, iy, ix, c] = sum of dy over the (<= 4) windows that contain the pixel and whose recorded arg-max is this
+// pixel.  Gather form: deterministic, no atomics.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const unsigned char* __restrict__ idx,
                                                              const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
                                                              int N, int H, int W, int OH, int OW, int C8) {
   const long long total = (long long)N * H * W * C8;
@@ -104,36 +117,24 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const bf16_t* __res
     const int c8 = (int)(q % C8);
     const long long p = q / C8;
     const int ix = (int)(p % W), iy = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
-    float xv[8], acc[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + q * 8), xv);
+    float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
     // windows oy with 2*oy-1 <= iy <= 2*oy+1  <=>  iy/2 <= oy <= (iy+1)/2   (iy >= 0)
     for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
-      if (oy < 0 || oy >= OH) continue;
+      if (oy >= OH) continue;
       for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-        if (ox < 0 || ox >= OW) continue;
+        if (ox >= OW) continue;
         const long long oq = ((((long long)n * OH + oy) * OW + ox) * C8 + c8) * 8;
-        float mv[8], gv[8];
-        unpack8(*reinterpret_cast<const uint4*>(y + oq), mv);
+        const uint2 pk = *reinterpret_cast<const uint2*>(idx + oq);
+        const unsigned me = (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));   // my position in that window
+        float gv[8];
         unpack8(*reinterpret_cast<const uint4*>(dy + oq), gv);
-        // is this pixel the first element of the window equal to the maximum?
-        bool first[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) first[i] = xv[i] == mv[i];
-        const int wy = iy - (2 * oy - 1), wx = ix - (2 * ox - 1);      // position inside the window
-        for (int ky = 0; ky < 3; ++ky)
-          for (int kx = 0; kx < 3; ++kx) {
-            if (ky * 3 + kx >= wy * 3 + wx) continue;                  // only earlier positions can pre-empt
-            const int jy = 2 * oy - 1 + ky, jx = 2 * ox - 1 + kx;
-            if (jy < 0 || jy >= H || jx < 0 || jx >= W) continue;
-            float ov[8];
-            unpack8(*reinterpret_cast<const uint4*>(x + ((((long long)n * H + jy) * W + jx) * C8 + c8) * 8), ov);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) first[i] = first[i] && !(ov[i] == mv[i]);
-          }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += first[i] ? gv[i] : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+          if (((pk.x >> (8 * i)) & 0xFFu) == me) acc[i] += gv[i];
+          if (((pk.y >> (8 * i)) & 0xFFu) == me) acc[4 + i] += gv[4 + i];
+        }
       }
     }
     *reinterpret_cast<uint4*>(dx + q * 8) = pack8(acc);
@@ -167,28 +168,29 @@ extern "C" int mcl_avgpool2_nhwc_bf16(const void* x, void* y, int32_t N, int32_t
   return MCL_OK;
 }
 
-extern "C" int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
-                                            mcl_stream_t stream) {
+extern "C" int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W,
+                                            int32_t C, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!ok16(x) || !ok16(y) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
+  if (!ok16(x) || !ok16(y) || !idx || (reinterpret_cast<uintptr_t>(idx) & 7u) || N <= 0 || H <= 0 || W <= 0 || C <= 0)
+    return MCL_EINVAL;
   if (C % 8) return MCL_EUNSUPPORTED;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * OH * OW * (C / 8);
   hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
-                     (bf16_t*)y, N, H, W, OH, OW, C / 8);
+                     (bf16_t*)y, (unsigned char*)idx, N, H, W, OH, OW, C / 8);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
 
-extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd(const void* x, const void* y, const void* dy, void* dx, int32_t N, int32_t H,
+extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd(const void* idx, const void* dy, void* dx, int32_t N, int32_t H,
                                             int32_t W, int32_t C, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!ok16(x) || !ok16(y) || !ok16(dy) || !ok16(dx) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
+  if (!idx || !ok16(dy) || !ok16(dx) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
   if (C % 8) return MCL_EUNSUPPORTED;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * H * W * (C / 8);
-  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
-                     (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8);
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream),
+                     (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

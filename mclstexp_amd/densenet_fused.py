@@ -633,18 +633,21 @@ class MaxPool3s2Fn(torch.autograd.Function):
     def forward(ctx, x):
         B, C, H, W = x.shape
         y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=x.dtype, memory_format=CL)
-        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "mcl_maxpool")
-        ctx.save_for_backward(x, y)
+        idx = torch.empty((B, y.shape[2], y.shape[3], C), device=x.device, dtype=torch.uint8)
+        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), B, H, W, C, _stream()),
+              "mcl_maxpool")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, H, W)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y = ctx.saved_tensors
-        B, C, H, W = x.shape
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
         dy = dy.contiguous(memory_format=CL)
-        dx = torch.empty_like(x, memory_format=CL)
-        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C,
-                                                      _stream()), "mcl_maxpool bwd")
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
+        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()),
+              "mcl_maxpool bwd")
         return dx
 
 
