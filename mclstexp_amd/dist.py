@@ -257,16 +257,28 @@ class GradReducer:
     def __init__(self, pg):
         self.pg = pg
 
-    def reduce(self, optimizer) -> None:
+    def reduce(self, optimizer, async_flat: bool = False):
+        """Sums gradients over ranks.  ``async_flat``: the (large) flat-bucket all-reduce is only ENQUEUED and its
+        work handles are returned -- the caller overlaps it with independent work (the position-table update, which
+        needs no flat gradient) and waits before the flat Adam step: ``optimizer.step(wait=handles)``.  The small
+        table-row all-gather is issued first so that it does not queue behind the big all-reduce on the
+        communicator's stream."""
         if hasattr(optimizer, "ensure_flat"):
             optimizer.ensure_flat()
+        if async_flat and hasattr(optimizer, "prefetch_table_rows"):
+            optimizer.prefetch_table_rows()
         flat_ids = set()
+        handles = []
         if hasattr(optimizer, "flat_grads"):
             for g in optimizer.flat_grads():
-                _all_reduce_sum(g, self.pg)
+                if async_flat and not _host_staged(g, self.pg):
+                    handles.append(td.all_reduce(g, op=td.ReduceOp.SUM, group=self.pg, async_op=True))
+                else:
+                    _all_reduce_sum(g, self.pg)
             flat_ids = optimizer.flat_param_ids()
         for group in optimizer.param_groups:
             for p in group["params"]:
                 if id(p) in flat_ids or p.grad is None:
                     continue
                 _all_reduce_sum(p.grad, self.pg)
+        return handles

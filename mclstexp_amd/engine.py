@@ -41,10 +41,21 @@ class TrainStep:
         loss = self.model(batch)
         self.opt.zero_grad()
         loss.backward()
-        if self.reducer is not None:
-            self.reducer.reduce(self.opt)
-        self.opt.step()
+        self._reduce_and_step()
         return loss.detach()
+
+    def _reduce_and_step(self) -> None:
+        """Data parallel: the 63 MB flat-gradient all-reduce is enqueued asynchronously and overlaps the HBM-bound
+        position-table update (which needs only the small row exchange issued just before it)."""
+        if self.reducer is None:
+            self.opt.step()
+            return
+        if hasattr(self.opt, "prefetch_table_rows"):
+            handles = self.reducer.reduce(self.opt, async_flat=True)
+            self.opt.step(wait=handles)
+        else:
+            self.reducer.reduce(self.opt)
+            self.opt.step()
 
     # ------------------------------------------------------------------ capture
     def _capture(self, batch) -> None:
@@ -91,7 +102,5 @@ class TrainStep:
         self.d_es.copy_(d_es)
         self.d_ei.copy_(d_ei)
         self.gb.replay()
-        if self.reducer is not None:
-            self.reducer.reduce(self.opt)
-        self.opt.step()
+        self._reduce_and_step()
         return loss

@@ -129,8 +129,17 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     p.grad.zero_()
 
+    def prefetch_table_rows(self) -> None:
+        """Data parallel: run the (small) all-gather of the table gradient rows now, ahead of a large asynchronous
+        all-reduce, so that the table update can overlap it."""
+        if self._sink is not None and "dout" in self._sink:
+            self._gathered()
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, wait=None):
+        """``wait``: work handles of an asynchronous flat-gradient all-reduce (dist.GradReducer.reduce(async_flat=
+        True)); the position tables -- which do not depend on it -- are updated first, then the handles are waited for
+        and the flat bucket is updated."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -139,6 +148,7 @@ class FusedAdam(torch.optim.Optimizer):
         t = self._step_count
         L = _lib.lib()
         st = ops._stream()
+        deferred = []
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
@@ -148,8 +158,7 @@ class FusedAdam(torch.optim.Optimizer):
             f = self._flat[gi]
             flat_ids = {id(p) for p in f["params"]}
             if f["n"] > 0:
-                check(L.mcl_adam_step(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
-                                      f["n"], lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_step")
+                deferred.append((f, lr, b1, b2, eps, wd, bc1, bc2))      # after the tables / the pending all-reduce
             for p in group["params"]:
                 if id(p) in flat_ids:
                     continue
@@ -169,6 +178,11 @@ class FusedAdam(torch.optim.Optimizer):
                 check(L.mcl_adam_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
                                       state["exp_avg_sq"].data_ptr(), p.numel(), lr, b1, b2, eps, wd, bc1, bc2, st),
                       "mcl_adam_step")
+        for h in (wait or []):
+            h.wait()
+        for f, lr, b1, b2, eps, wd, bc1, bc2 in deferred:
+            check(L.mcl_adam_step(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
+                                  f["n"], lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_step")
         if self._sink is not None:
             if self._sink.get("static"):
                 # graph-captured backward: dout/ix/iy are static buffers refreshed by every replay
