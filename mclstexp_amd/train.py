@@ -49,6 +49,10 @@ def generate_args(argv=None):
                         help='MFMA operand type of the hand kernels (f32 = reference numerics)')
     parser.add_argument('--backbone_dtype', type=str, default='bf16', choices=['f32', 'bf16'],
                         help='autocast dtype of the delegated image backbone')
+    parser.add_argument('--infonce', type=str, default='exact', choices=['exact', 'fused'],
+                        help='exact = fp32 logits (reference numerics); fused = flash-style bf16 MFMA kernel')
+    parser.add_argument('--hip_graphs', action='store_true',
+                        help='replay forward / backward from HIP graphs (engine.TrainStep) instead of eager launches')
     parser.add_argument('--save_dir', type=str, default='', help='if set: torch.save(state_dict) per fold (train.py:87-95)')
     parser.add_argument('--log_every', type=int, default=10, help='loss.item() sync period (reference: every step)')
     return parser.parse_args(argv)
@@ -69,20 +73,26 @@ class SyntheticLoader:
             yield synth.make_batch(a.batch_size, a.dim, image_hw=a.image_size, seed=s, rank=self.rank)
 
 
-def train(model, train_dataLoader: Iterable, optimizer, epoch: int, log_every: int = 1, reducer=None):
+def train(model, train_dataLoader: Iterable, optimizer, epoch: int, log_every: int = 1, reducer=None, stepper=None):
     """train.py:30-42.  ``log_every`` > 1 relaxes the reference's per-step ``loss.item()`` device sync
-    (the meter then samples every log_every-th step); 1 reproduces the reference exactly."""
+    (the meter then samples every log_every-th step); 1 reproduces the reference exactly.  ``stepper``: an
+    engine.TrainStep that performs the same forward / zero_grad / backward / step from captured HIP graphs."""
     loss_meter = AvgMeter()
     step = 0
     for batch in train_dataLoader:
         batch = {k: v.cuda(non_blocking=True) for k, v in batch.items() if
                  k == "image" or k == "expression" or k == "position"}
-        loss = model(batch)
-        optimizer.zero_grad()
-        loss.backward()
-        if reducer is not None:
-            reducer.reduce(optimizer)
-        optimizer.step()
+        if stepper is not None:
+            if batch["image"].dtype == torch.float32 and getattr(model, "backbone_dtype", None) is not None:
+                batch["image"] = batch["image"].contiguous(memory_format=torch.channels_last)
+            loss = stepper(batch)
+        else:
+            loss = model(batch)
+            optimizer.zero_grad()
+            loss.backward()
+            if reducer is not None:
+                reducer.reduce(optimizer)
+            optimizer.step()
         step += 1
         if step % log_every == 0:
             count = batch["image"].size(0)
@@ -114,15 +124,20 @@ def main(argv=None):
                                    image_dim=args.image_embedding_dim, projection_dim=args.projection_dim,
                                    heads_num=args.heads_num, heads_dim=args.heads_dim, head_layers=args.heads_layers,
                                    dropout=args.dropout, compute=args.compute, backbone_dtype=bb,
-                                   embedding_grad="rowsparse", process_group=pg if world > 1 else None)
+                                   embedding_grad="rowsparse", process_group=pg if world > 1 else None,
+                                   infonce=args.infonce)
         model.to(device)
         if bb is not None:
             model.to(memory_format=torch.channels_last)
         optimizer = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(model)   # train.py:118-120
         reducer = mdist.GradReducer(pg) if world > 1 else None
+        stepper = None
+        if args.hip_graphs:
+            from .engine import TrainStep
+            stepper = TrainStep(model, optimizer, reducer, graphs=True)
         for epoch in range(args.max_epochs):
             model.train()
-            meter = train(model, loader, optimizer, epoch, args.log_every, reducer)
+            meter = train(model, loader, optimizer, epoch, args.log_every, reducer, stepper)
             if rank == 0:
                 print(f"fold {i} epoch {epoch} train_loss {meter.avg:.4f} lr {get_lr(optimizer)}")
         save_model(args, model, rank)
