@@ -112,7 +112,10 @@ __device__ __forceinline__ void dma_piece(const Dma& d, int t, int col0n, unsign
   const unsigned chunk = d.base_l ^ (unsigned)(((t & 1) << 3) | ((t >> 1) & 3));
   const int n = d.wave * d.ppw + t;          // piece = tile rows 2n, 2n+1 (ppw is 16 or 8: (2n + h) & 15 == 2t + h)
   const int gcol = col0n + 2 * n + d.h;
-  const unsigned char* rowp = gcol >= d.C ? d.alt : d.gbase + (size_t)gcol * d.ldb_bytes;
+  // row pointer without a per-piece 64-bit multiply: (col0n + 2*wave*ppw + h) * ld is per lane and tile, the piece
+  // adds the wave-uniform 2*t*ld
+  const unsigned char* rowp =
+      gcol >= d.C ? d.alt : d.gbase + (long long)(col0n + 2 * d.wave * d.ppw + d.h) * d.ldb_bytes + (long long)(2 * t) * d.ldb_bytes;
   glds16(rowp + (chunk << 4), __builtin_amdgcn_readfirstlane(dst_tile + n * 1024));
 }
 __device__ __forceinline__ void dma_stat(const Dma& d, int col0n, unsigned dst_stat) {
@@ -420,14 +423,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
     const unsigned dst_tile = lds_base + (buf ^ 1) * TILE_B;                                                      \
     const unsigned dst_stat = lds_base + 2 * TILE_B + (buf ^ 1) * STAT_STRIDE;                                    \
     const int dcol = my_r + diag_off - col0; /* tile column of this row's positive pair */                        \
+    /* launder the lane constant of the DMA source address: otherwise the per-piece offsets are hoisted out of */ \
+    /* the tile loop, spilled, and every reload's compiler-inserted vmcnt(0) drains the hand-placed DMA        */ \
+    Dma dl = d;                                                                                                   \
+    asm volatile("" : "+v"(dl.base_l), "+v"(dl.h), "+v"(dl.wave));                                                \
     f32x16 T0, T1;                                                                                                \
     EGradPair<FIXV> eg;                                                                                           \
     if (BWD) {                                                                                                    \
       f32x16 T2, T3;                                                                                              \
       stage_aa<true, 0, -1, FIXV, PPW, 0, 1>(lds, a1, bfrag, T0, T1, T0, T1, col0, dcol, cls_off, eg, w0, w1,    \
-                                              run_m, run_l, c, d, col0n, dst_tile, dst_stat);                     \
+                                              run_m, run_l, c, dl, col0n, dst_tile, dst_stat);                     \
       stage_aa<true, 2, 0, FIXV, 0, 2, -1>(lds, a1, bfrag, T2, T3, T0, T1, col0, dcol, cls_off, eg, w0, w1,   \
-                                               run_m, run_l, c, d, col0n, dst_tile, dst_stat);                    \
+                                               run_m, run_l, c, dl, col0n, dst_tile, dst_stat);                    \
       stage_bb<0, 2, FIXV, 3>(lds, a2, w0, w1, acc, T2, T3, col0, dcol, cls_off, eg, w2, w3, c);                  \
       stage_bb<2, -1, FIXV, -1>(lds, a2, w2, w3, acc, T2, T3, col0, dcol, cls_off, eg, w2, w3, c);                \
       /* keep the loop-carried accumulators in the AGPR half across the back edge */                            \
@@ -435,9 +442,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
       asm volatile("" : "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]));                                \
     } else {                                                                                                      \
       stage_aa<false, 0, 2, FIXV, PPW, -1, -1>(lds, a1, bfrag, T0, T1, Tp2, Tp3, col0 - TC, dcol, cls_off, eg,   \
-                                                w0, w1, run_m, run_l, c, d, col0n, dst_tile, dst_stat);           \
+                                                w0, w1, run_m, run_l, c, dl, col0n, dst_tile, dst_stat);           \
       stage_aa<false, 2, 0, FIXV, 0, -1, -1>(lds, a1, bfrag, Tp2, Tp3, T0, T1, col0, dcol, cls_off, eg, w0,   \
-                                                 w1, run_m, run_l, c, d, col0n, dst_tile, dst_stat);              \
+                                                 w1, run_m, run_l, c, dl, col0n, dst_tile, dst_stat);              \
     }                                                                                                             \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
     __syncthreads();                                                                                              \
