@@ -286,6 +286,32 @@ int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t co
 /* row_slot maintenance: set row_slot[owner_idx[b]] = b for owners (fill != 0) or back to -1.    */
 int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill, mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- inference-time retrieval
+ * Replaces, on the device, the reference's find_matches() + weighting loop:
+ *   evel_her2st.py:74-84,174-187 (top 200, L1 distance), evel_cscc.py:74-84,197-215 (top 600, values returned,
+ *   L2 distance), evel_visium.py:94-104,193-205 (top 200, L2 distance).
+ * mcl_l2_normalize_rows: y[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12)   (F.normalize(p=2, dim=-1)).
+ *   The similarity matrix itself is mcl_gemm(query_n, key_n^T) with MCL_COMPUTE_F32.
+ * mcl_topk_rows: torch.topk(sim, k) along each row of sim (rows x n, leading dimension ld): values (rows x k) best
+ *   first and int64 indices; exact selection (radix select on the fp32 bit patterns), equal values ordered by
+ *   ascending index.  k <= mcl_topk_rows_max_k() (2048), k <= n.
+ * mcl_knn_weighted_average: per query i with neighbours idx = indices[i,:] (k of them):
+ *     a_j = || spot_key[idx_j,:] - query[i,:] ||_ord   (ord = 1 or 2, UN-normalised embeddings, fp32)
+ *     w_j = a_j^-2 / sum_j a_j^-2
+ *     emb_pred[i,:]  = sum_j w_j spot_key[idx_j,:]        (n_query x dim,   may be NULL)
+ *     expr_pred[i,:] = sum_j w_j expression_key[idx_j,:]  (n_query x genes, may be NULL)
+ *   (np.average(..., weights=w)); the weighted sums accumulate in fp64.  An exact match (a_j = 0) yields a NaN row,
+ *   as numpy's inf/inf does.                                                                     */
+int mcl_l2_normalize_rows(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t dim,
+                          mcl_stream_t stream);
+int mcl_topk_rows_max_k(void);
+int mcl_topk_rows(const float* sim, int64_t ld, int32_t rows, int32_t n, int32_t k, float* values, int64_t* indices,
+                  mcl_stream_t stream);
+int mcl_knn_weighted_average(const float* spot_key, int64_t ldk, const float* expression_key, int64_t lde,
+                             const float* query, int64_t ldq, const int64_t* indices, int32_t n_query, int32_t k,
+                             int32_t dim, int32_t genes, int32_t ord, float* emb_pred, float* expr_pred,
+                             mcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,10 @@ PROTOTYPES = {
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
+    "mcl_l2_normalize_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
+    "mcl_topk_rows_max_k": [],
+    "mcl_topk_rows": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
+    "mcl_knn_weighted_average": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
 }
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,

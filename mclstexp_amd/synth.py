@@ -122,3 +122,24 @@ def make_batch(batch: int, spot_dim: int, image_dim: Optional[int] = None, image
     elif image_hw is not None:
         out["image"] = uniform_tensor("image" + tag, (batch, 3, image_hw, image_hw), 0.0, 1.0, seed)
     return out
+
+
+def make_retrieval_case(n_keys: int, n_query: int, dim: int = 256, genes: int = 785, clusters: int = 24,
+                        seed: int = 0, duplicates: int = 0) -> Dict[str, np.ndarray]:
+    """Synthetic inference-time retrieval problem in the layout the reference's eval scripts hold after their
+    transposes (evel_her2st.py:158-172): ``spot_key`` (N, dim) and ``image_query`` (Q, dim) un-normalised
+    projection-head outputs (cluster centre + noise, so the cosine top-k is structured like real embeddings),
+    ``expression_key`` (N, genes) log-normalised expression (~60 % zeros).  ``duplicates`` > 0 makes the last
+    ``duplicates`` keys exact copies of key 0 (ties in the similarity)."""
+    cen = uniform_tensor("retr.centres", (clusters, dim), -1.0, 1.0, seed).numpy()
+    kc = np.floor(uniform_tensor("retr.key_cluster", (n_keys,), 0.0, float(clusters), seed).numpy()).astype(np.int64)
+    qc = np.floor(uniform_tensor("retr.query_cluster", (n_query,), 0.0, float(clusters), seed).numpy()).astype(np.int64)
+    key = cen[kc] + 0.8 * uniform_tensor("retr.key_noise", (n_keys, dim), -1.0, 1.0, seed).numpy()
+    qry = cen[qc] + 0.8 * uniform_tensor("retr.query_noise", (n_query, dim), -1.0, 1.0, seed).numpy()
+    u = uniform_tensor("retr.expression", (n_keys, genes), 0.0, 1.0, seed).numpy()
+    expr = np.where(u < 0.6, np.float32(0.0), (u - np.float32(0.6)) * np.float32(10.0)).astype(np.float32)
+    key = key.astype(np.float32)
+    if duplicates:
+        key[n_keys - duplicates:] = key[0]
+    return {"spot_key": np.ascontiguousarray(key), "image_query": np.ascontiguousarray(qry.astype(np.float32)),
+            "expression_key": np.ascontiguousarray(expr)}

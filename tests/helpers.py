@@ -49,3 +49,44 @@ def assert_close_scaled(a, b, rel=1e-5, floor=1e-12, what=""):
     tensor's magnitude, not with each element's)."""
     b64 = np.asarray(b, dtype=np.float64)
     assert_close(a, b, rel * float(np.abs(b64).max() if b64.size else 0.0) + floor, what=what)
+
+
+# --------------------------------------------------------------------------- retrieval (SURVEY §8 f1)
+RETRIEVAL_CASES = {"her2st": 1, "cscc": 2, "visium": 2, "small_k1": 2}   # name -> ord of the distance norm
+
+
+def load_retrieval_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"retrieval_{name}.npz"))
+    N, Q, G, k, seed, dup = [int(v) for v in z["meta"]]
+    case = synth.make_retrieval_case(N, Q, 256, G, seed=seed, duplicates=dup)
+    return z, case, dict(N=N, Q=Q, G=G, top_k=k, ord=RETRIEVAL_CASES[name])
+
+
+def check_topk(indices, sim64, tol=2e-6, values=None, what="topk"):
+    """Tolerance-aware top-k check against float64 similarities ``sim64`` (Q,N).
+
+    Exact wherever the float64 values are separated by more than ``tol`` (fp32 products and sums of 256
+    terms differ between implementations by ~1e-7, so elements closer than that to the k-th value or to
+    each other may legitimately swap):  every selected element is >= k-th value - tol, every element
+    > k-th value + tol is selected, rows are sorted best-first within tol, no index repeats.
+    Returns the number of rows whose index SET equals the float64 one exactly."""
+    indices = np.asarray(indices)
+    q, k = indices.shape
+    exact_rows = 0
+    for i in range(q):
+        row = sim64[i]
+        idx = indices[i]
+        assert len(set(idx.tolist())) == k, f"{what}: row {i} repeats an index"
+        assert idx.min() >= 0 and idx.max() < row.shape[0], f"{what}: row {i} index out of range"
+        order = np.argsort(-row, kind="stable")
+        kth = row[order[k - 1]]
+        got = row[idx]
+        assert got.min() >= kth - tol, f"{what}: row {i} selected {got.min():.9f} < k-th {kth:.9f}"
+        must = np.nonzero(row > kth + tol)[0]
+        missing = np.setdiff1d(must, idx)
+        assert missing.size == 0, f"{what}: row {i} misses {missing[:5]} (clearly above the k-th value)"
+        assert (np.diff(got) <= tol).all(), f"{what}: row {i} not sorted best-first"
+        if values is not None:
+            assert np.abs(np.asarray(values[i], dtype=np.float64) - got).max() <= tol, f"{what}: row {i} values"
+        exact_rows += int(set(order[:k].tolist()) == set(idx.tolist()))
+    return exact_rows

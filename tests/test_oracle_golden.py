@@ -108,3 +108,28 @@ def test_densenet_restatement_shapes():
     net.train()
     y2 = torch.nn.functional.adaptive_avg_pool2d(net(x), (1, 1)).flatten(1)
     assert_close(y.detach().numpy(), y2.detach().numpy(), 1e-4, what="densenet module vs functional")
+
+
+# --------------------------------------------------------------------------- retrieval
+from oracle import ref_retrieval  # noqa: E402
+from helpers import RETRIEVAL_CASES, check_topk, load_retrieval_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(RETRIEVAL_CASES))
+def test_retrieval_oracle_matches_reference_fixture(name):
+    """oracle/ref_retrieval.py against the outputs of the reference's own find_matches / weighting loops."""
+    z, case, meta = load_retrieval_golden(name)
+    values, indices = ref_retrieval.find_matches(case["spot_key"], case["image_query"], top_k=meta["top_k"])
+    sim64 = ref_retrieval.similarity_f64(case["spot_key"], case["image_query"])
+    # same torch build, same ops: expected to agree exactly; the tolerance-aware check documents what
+    # "equal" means should a BLAS change reorder the fp32 sums
+    check_topk(indices, sim64, values=values, what=f"{name} oracle")
+    check_topk(z["indices"], sim64, what=f"{name} reference")
+    assert (indices == z["indices"]).mean() > 0.999
+    if "values" in z.files:
+        assert_close(values, z["values"], 1e-6, what="values")
+    # the weighting loop on the REFERENCE's indices: pure numpy, must agree to rounding
+    emb, expr = ref_retrieval.weighted_prediction(case["spot_key"], case["expression_key"], case["image_query"],
+                                                  z["indices"], ord=meta["ord"])
+    assert_close(emb, z["emb_pred"], 1e-12, 1e-12, what="emb_pred")
+    assert_close(expr, z["expr_pred"], 1e-12, 1e-12, what="expr_pred")

@@ -1,0 +1,191 @@
+"""Inference-time retrieval on the MI355X against the reference's own outputs
+(tests/golden/retrieval_*.npz) and the numpy oracle (oracle/ref_retrieval.py).  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import RETRIEVAL_CASES, assert_close, assert_close_scaled, check_topk, load_retrieval_golden
+from mclstexp_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from mclstexp_amd import _lib, retrieval
+    _lib.lib()  # must load: no fallback
+    return retrieval
+
+
+def _cpu_topk(sim: np.ndarray, k: int):
+    """Exact reference ordering on a GIVEN fp32 matrix: value descending, index ascending among equals."""
+    order = np.lexsort((np.arange(sim.shape[1])[None, :].repeat(sim.shape[0], 0), -sim.astype(np.float64)), axis=1)
+    idx = order[:, :k]
+    return np.take_along_axis(sim, idx, axis=1), idx
+
+
+# ------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("rows,dim", [(1, 256), (33, 256), (257, 100), (5, 7)])
+def test_l2_normalize_rows(rt, rows, dim):
+    g = torch.Generator().manual_seed(rows * 1000 + dim)
+    x = torch.randn(rows, dim, generator=g) * 3
+    x[0] = 0.0                                        # zero row: F.normalize's eps clamp -> zeros, not NaN
+    y = rt.l2_normalize(x.to(DEV)).cpu()
+    ref = torch.nn.functional.normalize(x.double(), p=2, dim=-1)
+    assert_close(y, ref, 2e-7, what="l2_normalize")
+    assert torch.equal(y[0], torch.zeros(dim))
+
+
+TOPK_SHAPES = [(1, 1, 1), (3, 7, 7), (4, 100, 1), (9, 1000, 200), (5, 3001, 600), (2, 100003, 2048), (6, 513, 512)]
+
+
+@pytest.mark.parametrize("rows,n,k", TOPK_SHAPES)
+def test_topk_rows_exact_on_given_matrix(rt, rows, n, k):
+    """Selection on a given fp32 matrix has no rounding: values AND indices must equal the CPU ordering bit for bit."""
+    g = torch.Generator().manual_seed(n + k)
+    sim = (torch.rand(rows, n, generator=g) * 2 - 1)
+    if rows > 1:
+        sim[1] = sim[1] * 1e-3 + 0.75               # narrow value range (what cosine rows look like)
+    sim_np = sim.numpy()
+    v, i = rt.topk_rows(sim.to(DEV), k)
+    rv, ri = _cpu_topk(sim_np, k)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(v.cpu().numpy(), rv)
+
+
+def test_topk_rows_ties_specials_and_strides(rt):
+    n, k = 5000, 300
+    g = torch.Generator().manual_seed(7)
+    base = torch.rand(8, n, generator=g)
+    base[0] = 0.5                                                       # all equal: lowest k indices
+    base[1] = torch.floor(base[1] * 8) / 8                              # 8 distinct values: ties across the k-th
+    base[2, ::3] = -base[2, ::3]                                        # mixed signs
+    base[3, 10] = float("inf"); base[3, 20] = float("-inf"); base[3, 30] = 0.0; base[3, 31] = -0.0
+    base[4] = -base[4] - 5.0                                            # all negative
+    base[5] = torch.floor(base[5] * 2)                                  # two values
+    base[6, :] = 1.0; base[6, 4000:] = 2.0                              # winners at the end + ties at the front
+    base[7] = base[7] * 1e-30                                           # tiny magnitudes (exponent-dominated keys)
+    wide = torch.zeros(8, n + 13)
+    wide[:, :n] = base
+    wide[:, n:] = 9.0                                                   # beyond n: must never be read as data
+    v, i = rt.topk_rows(wide.to(DEV)[:, :n], k)                         # leading dimension n + 13
+    rv, ri = _cpu_topk(base.numpy(), k)
+    # -0.0 == 0.0 for torch.topk but not for the integer keys: compare that row by value only
+    vi, ii = v.cpu().numpy(), i.cpu().numpy()
+    for r in range(8):
+        assert np.array_equal(vi[r], rv[r]), f"row {r} values"
+        if r != 3:
+            assert np.array_equal(ii[r], ri[r]), f"row {r} indices"
+    assert ii[0].tolist() == list(range(k))
+    assert ii[3, 0] == 10 and 20 not in ii[3].tolist()
+
+
+def test_topk_rows_argument_errors(rt):
+    sim = torch.zeros(2, 10, device=DEV)
+    with pytest.raises(RuntimeError):
+        rt.topk_rows(sim, 11)
+    with pytest.raises(RuntimeError):
+        rt.topk_rows(torch.zeros(2, 5000, device=DEV), 4000)           # > mcl_topk_rows_max_k()
+    with pytest.raises(RuntimeError):
+        rt.topk_rows(torch.zeros(2, 10), 3)                              # CPU tensor: no fallback
+
+
+# ------------------------------------------------------------------ against the reference's outputs
+@pytest.mark.parametrize("name", sorted(RETRIEVAL_CASES))
+def test_find_matches_against_reference_fixture(rt, name):
+    from oracle import ref_retrieval
+    z, case, meta = load_retrieval_golden(name)
+    sim64 = ref_retrieval.similarity_f64(case["spot_key"], case["image_query"])
+    values, indices = rt.find_matches(case["spot_key"], case["image_query"], top_k=meta["top_k"], return_values=True)
+    assert indices.dtype == np.int64 and indices.shape == z["indices"].shape
+    # tolerance-aware exactness (tests/helpers.check_topk): 2e-6 on cosine values, fp32 sums of 256 products
+    exact_rows = check_topk(indices, sim64, tol=2e-6, values=values, what=name)
+    assert exact_rows >= int(0.9 * meta["Q"]), f"only {exact_rows}/{meta['Q']} rows match the fp64 sets exactly"
+    # and directly against the reference's indices: identical except where fp32 near-ties reorder
+    assert (indices == z["indices"]).mean() > 0.97
+    if "values" in z.files:
+        assert_close(values, z["values"], 1e-6, what="top-k similarities (evel_cscc returns them)")
+    assert np.array_equal(rt.find_matches(case["spot_key"], case["image_query"], top_k=meta["top_k"]), indices)
+
+
+@pytest.mark.parametrize("name", sorted(RETRIEVAL_CASES))
+def test_weighted_average_against_reference_fixture(rt, name):
+    """The weighting loop on the reference's own indices: fp32 inputs, fp64 accumulation on the device; the
+    reference's numpy accumulates fp32 products pairwise, so 5e-6 of the row's largest value is the bar."""
+    z, case, meta = load_retrieval_golden(name)
+    emb, expr = rt.weighted_average_device(case["spot_key"], case["expression_key"], case["image_query"],
+                                           z["indices"], ord=meta["ord"])
+    assert_close_scaled(emb.cpu().numpy(), z["emb_pred"], 5e-6, what="matched_spot_embeddings_pred")
+    assert_close_scaled(expr.cpu().numpy(), z["expr_pred"], 5e-6, what="matched_spot_expression_pred")
+    # embeddings only (expression_key=None)
+    emb2, none = rt.weighted_average_device(case["spot_key"], None, case["image_query"], z["indices"], ord=meta["ord"])
+    assert none is None and torch.equal(emb2, emb)
+
+
+@pytest.mark.parametrize("name", ["her2st", "cscc"])
+def test_predict_expression_end_to_end(rt, name):
+    z, case, meta = load_retrieval_golden(name)
+    out = rt.predict_expression(case["spot_key"], case["expression_key"], case["image_query"], top_k=meta["top_k"],
+                                ord=meta["ord"])
+    assert out["matched_spot_expression_pred"].dtype == np.float64
+    same = np.array([set(a.tolist()) == set(b.tolist()) for a, b in zip(out["indices"], z["indices"])])
+    assert same.mean() >= 0.9
+    assert_close_scaled(out["matched_spot_expression_pred"][same], z["expr_pred"][same], 5e-6, what="expr_pred")
+    assert_close_scaled(out["matched_spot_embeddings_pred"][same], z["emb_pred"][same], 5e-6, what="emb_pred")
+    # a near-tie swap at rank k exchanges one of k neighbours with an almost equally distant one
+    assert_close_scaled(out["matched_spot_expression_pred"], z["expr_pred"], 2e-2, what="expr_pred (all rows)")
+
+
+def test_exact_match_gives_nan_row_like_numpy(rt):
+    from oracle import ref_retrieval
+    case = synth.make_retrieval_case(400, 6, 256, 31, seed=9)
+    q = case["image_query"].copy()
+    q[2] = case["spot_key"][17]                                         # distance 0 -> 1/0 -> inf/inf
+    _, idx = ref_retrieval.find_matches(case["spot_key"], q, top_k=20)
+    with np.errstate(all="ignore"):
+        ref_emb, ref_expr = ref_retrieval.weighted_prediction(case["spot_key"], case["expression_key"], q, idx, ord=2)
+    emb, expr = rt.weighted_average_device(case["spot_key"], case["expression_key"], q, idx, ord=2)
+    assert np.isnan(ref_expr[2]).all() and torch.isnan(expr[2]).all() and torch.isnan(emb[2]).all()
+    keep = [0, 1, 3, 4, 5]
+    assert_close_scaled(expr.cpu().numpy()[keep], ref_expr[keep], 5e-6, what="other rows")
+
+
+def test_duplicate_keys_tie_order(rt):
+    """Exact duplicates among the keys (ties in the similarity): the copies are interchangeable for the reference
+    (torch.topk's tie order is unspecified); here they come out in ascending index order, deterministically."""
+    case = synth.make_retrieval_case(1200, 9, 256, 11, seed=5, duplicates=40)
+    q = case["image_query"].copy()
+    q[0] = case["spot_key"][0] * 1.5                                    # cosine 1 with key 0 and its 40 copies
+    v, i = rt.find_matches(case["spot_key"], q, top_k=30, return_values=True)
+    dup = [0] + list(range(1160, 1200))
+    assert i[0].tolist() == dup[:30]
+    v2, i2 = rt.find_matches(case["spot_key"], q, top_k=30, return_values=True)
+    assert np.array_equal(i, i2) and np.array_equal(v, v2)
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+def test_topk_properties_at_scale(rt):
+    n, q, k, p = 65536, 512, 600, 256
+    g = torch.Generator(device=DEV).manual_seed(3)
+    keys = torch.randn(n, p, device=DEV, generator=g)
+    query = torch.randn(q, p, device=DEV, generator=g) + 0.5 * keys[:q]
+    v, i = rt.find_matches_device(keys, query, k)
+    sim = rt.cosine_similarity_matrix(rt.l2_normalize(query), rt.l2_normalize(keys))
+    assert (v[:, 1:] <= v[:, :-1]).all()                                           # best first
+    assert torch.equal(torch.gather(sim, 1, i), v)                                 # values are the matrix entries
+    assert ((sim > v[:, -1:]).sum(1) <= k - 1).all() and ((sim >= v[:, -1:]).sum(1) >= k).all()   # exact k-th
+    assert (torch.sort(i, 1).values[:, 1:] != torch.sort(i, 1).values[:, :-1]).all()              # no repeats
+    assert (i[:, 0] == torch.arange(q, device=DEV)).all()                          # the planted neighbour wins
+    # permuting the keys permutes the answer
+    perm = torch.randperm(n, device=DEV, generator=g)
+    v2, i2 = rt.find_matches_device(keys[perm], query, k)
+    assert torch.equal(v2, v)
+    assert torch.equal(torch.sort(perm[i2], 1).values, torch.sort(i, 1).values)
+    # weighted average: weights are a convex combination -> prediction inside the neighbours' range; constant
+    # expression is reproduced
+    expr = torch.full((n, 40), 2.5, device=DEV)
+    emb, ex = rt.weighted_average_device(keys, expr, query, i, ord=2)
+    assert_close(ex.cpu().numpy(), np.full((q, 40), 2.5), 1e-6, what="constant expression")
+    nb = keys[i[:4]]                                                               # (4, k, p)
+    assert (emb[:4] <= nb.max(1).values + 1e-5).all() and (emb[:4] >= nb.min(1).values - 1e-5).all()
