@@ -189,3 +189,31 @@ def test_topk_properties_at_scale(rt):
     assert_close(ex.cpu().numpy(), np.full((q, 40), 2.5), 1e-6, what="constant expression")
     nb = keys[i[:4]]                                                               # (4, k, p)
     assert (emb[:4] <= nb.max(1).values + 1e-5).all() and (emb[:4] >= nb.min(1).values - 1e-5).all()
+
+
+# ------------------------------------------------------------------ embedding extraction (evel_her2st.py:41-69)
+def test_get_embeddings_matches_reference_fixture_and_oracle(rt):
+    """Eval-mode, no_grad sub-module calls in the reference's order.  First batch = the golden case (embeddings
+    produced by the reference's own classes), second batch ragged (B = 5) against the oracle."""
+    from helpers import load_golden, oracle_forward
+    from mclstexp_amd.model import mclSTExp_Attention
+    z, meta = load_golden("b8_g785")
+    G, D, L = meta["G"], meta["D"], meta["layers"]
+    params = synth.make_params(G, D, 256, 8, 64, L, seed=0)
+    m = mclSTExp_Attention("identity", meta["T"], D, G, 256, 8, 64, L)
+    m.load_state_dict(params, strict=True)
+    m.to(DEV)
+    b0 = synth.make_batch(meta["B"], G, image_dim=D, seed=0)
+    b1 = synth.make_batch(5, G, image_dim=D, seed=3)
+    img, spot = rt.get_embeddings(m, [b0, b1])
+    assert not m.training and not img.requires_grad
+    assert img.shape == (meta["B"] + 5, 256) and spot.shape == (meta["B"] + 5, 256)
+    assert_close(img[:meta["B"]].cpu(), z["image_embeddings"], 2e-5, what="image_embeddings (reference fixture)")
+    assert_close(spot[:meta["B"]].cpu(), z["spot_embeddings"], 2e-5, what="spot_embeddings (reference fixture)")
+    with torch.no_grad():
+        ref = oracle_forward(params, b1, meta)
+    assert_close(img[meta["B"]:].cpu(), ref["image_embeddings"], 2e-5, what="image_embeddings (oracle, ragged)")
+    assert_close(spot[meta["B"]:].cpu(), ref["spot_embeddings"], 2e-5, what="spot_embeddings (oracle, ragged)")
+    # and straight into the retrieval: every spot retrieves itself first among its own embeddings
+    idx = rt.find_matches(spot, spot, top_k=3)
+    assert idx[:, 0].tolist() == list(range(meta["B"] + 5))
