@@ -202,7 +202,8 @@ int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda
  * norm2's statistics):   z[s][n] = sum_k relu(x[s][k]*g[k]*rstd[k] + beta[k] - mean[k]*g[k]*rstd[k]) * W[n][k],
  * n < 128;  zmean/zvar (biased)/zrstd = batch statistics of the bf16-rounded z.  x: (S, K) bf16 row stride ldx
  * (a channel slice of the block's concat buffer), W: (128, K) bf16 contiguous, z: (S, 128) bf16 row stride ldz.
- * K % 8 == 0, K <= 1024.  workspace: mcl_dense_conv1x1_workspace_floats(S) floats.                        */
+ * K % 8 == 0, K <= 1024.  workspace: mcl_dense_conv1x1_workspace_floats(S) floats.  zmean = zvar = zrstd = NULL:
+ * no statistics (inference, where mean/rstd are the running statistics of norm1 and norm2 uses its own).       */
 int64_t mcl_dense_conv1x1_workspace_floats(int64_t S);
 int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int32_t K, const float* gamma, const float* beta,
                           const float* mean, const float* rstd, const void* W, void* z, int64_t ldz, float* workspace,
@@ -213,7 +214,8 @@ int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int32_t K, cons
  *   y[p][co] = sum_{ky,kx,ci} relu(bn2(z))[p + (ky-1)*W + (kx-1)][ci] * W2[co][ky][kx][ci]   (zero outside the image)
  * z: (S, 128) bf16 contiguous NHWC pixels (S = B*H*W), W2: (32, 3, 3, 128) bf16 (a channels-last (32,128,3,3)
  * weight), out: bf16 with row stride ldo (the block buffer's channel slice), ymean/yvar (biased)/yrstd = batch
- * statistics of the bf16-rounded y.  workspace: mcl_dense_conv3x3_workspace_floats(S) floats.            */
+ * statistics of the bf16-rounded y (all three NULL: none, inference).  workspace:
+ * mcl_dense_conv3x3_workspace_floats(S) floats.                                                           */
 int64_t mcl_dense_conv3x3_workspace_floats(int64_t S);
 int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_t W, const float* gamma, const float* beta,
                           const float* mean, const float* rstd, const void* W2, void* out, int64_t ldo,

@@ -182,6 +182,13 @@ class ImageEncoder(_PooledSequential):
         y = F.adaptive_avg_pool2d(y.float(), (1, 1))
         return y.view(y.size(0), -1)
 
+    def forward_eval_fused(self, x, act_dtype=torch.bfloat16):
+        """Eval-mode (running statistics) forward on the fused kernels: the inference path of evel_her2st.py:50."""
+        from .densenet_fused import densenet_features_eval
+        y = densenet_features_eval(self.model[0], x, act_dtype)
+        y = F.adaptive_avg_pool2d(y.float(), (1, 1))
+        return y.view(y.size(0), -1)
+
 
 class ImageEncoder_Resnet(_PooledSequential):
     """ResNet-50, model.py:88-101.  Output (B, 2048)."""

@@ -278,8 +278,9 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
                                      int64_t ldz, float* workspace, float eps, float* zmean, float* zvar,
                                      float* zrstd, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!x || !gamma || !beta || !mean || !rstd || !W || !z || !workspace || !zmean || !zvar || !zrstd || S <= 0 || K <= 0)
-    return MCL_EINVAL;
+  if (!x || !gamma || !beta || !mean || !rstd || !W || !z || !workspace || S <= 0 || K <= 0) return MCL_EINVAL;
+  const bool want_stats = zmean || zvar || zrstd;   // all three or none (inference: BN2 uses running statistics)
+  if (want_stats && (!zmean || !zvar || !zrstd)) return MCL_EINVAL;
   if ((K % 8) || K > 1024 || (ldx % 8) || (ldz % 8) || ldz < BN || (reinterpret_cast<uintptr_t>(x) & 15u) ||
       (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(z) & 15u))
     return MCL_EUNSUPPORTED;
@@ -295,8 +296,9 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   else if (wm == 2) MCL_LAUNCH(2);
   else MCL_LAUNCH(1);
 #undef MCL_LAUNCH
-  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(BN), dim3(256), 0, st, (const float2*)part, nblk, BN,
-                     (long long)S, bm, eps, zmean, zvar, zrstd);
+  if (want_stats)
+    hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(BN), dim3(256), 0, st, (const float2*)part, nblk, BN,
+                       (long long)S, bm, eps, zmean, zvar, zrstd);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
@@ -512,9 +514,10 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
                                      int64_t ldo, float* workspace, float eps, float* ymean, float* yvar, float* yrstd,
                                      mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!z || !gamma || !beta || !mean || !rstd || !W2 || !out || !workspace || !ymean || !yvar || !yrstd || S <= 0 ||
-      H <= 0 || W <= 0)
+  if (!z || !gamma || !beta || !mean || !rstd || !W2 || !out || !workspace || S <= 0 || H <= 0 || W <= 0)
     return MCL_EINVAL;
+  const bool want_stats = ymean || yvar || yrstd;   // all three or none
+  if (want_stats && (!ymean || !yvar || !yrstd)) return MCL_EINVAL;
   if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (ldo % 8) || ldo < C3_OUT || (reinterpret_cast<uintptr_t>(z) & 15u) ||
       (reinterpret_cast<uintptr_t>(W2) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return MCL_EUNSUPPORTED;
@@ -532,8 +535,9 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
   float2* part = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, st, (const bf16_t*)z, (long long)S, H, W,
                      gamma, beta, mean, rstd, (const bf16_t*)W2, (bf16_t*)out, (long long)ldo, part, ntile);
-  hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(C3_OUT), dim3(256), 0, st, (const float2*)part, ntile,
-                     C3_OUT, (long long)S, T3, eps, ymean, yvar, yrstd);
+  if (want_stats)
+    hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(C3_OUT), dim3(256), 0, st, (const float2*)part, ntile,
+                       C3_OUT, (long long)S, T3, eps, ymean, yvar, yrstd);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -224,7 +224,7 @@ USE_FUSED_1X1 = os.environ.get("MCL_FUSED_1X1", "1") != "0"
 
 
 def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, w16: Tensor, eps2: float,
-                      zmean: Tensor, zvar: Tensor, zrstd: Tensor) -> Tensor:
+                      zmean: Optional[Tensor], zvar: Optional[Tensor], zrstd: Optional[Tensor]) -> Tensor:
     """z = conv1x1(relu(bn(x)), w16) and z's batch statistics.  x: channel slice of the concat buffer (bf16
     channels-last), w16: (128, C_in, 1, 1) bf16 whose storage is (128, C_in) row-major."""
     px, S, K, ldx = _rows(x)
@@ -232,9 +232,10 @@ def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Ten
     z = torch.empty((B, 128, H, W), device=x.device, dtype=torch.bfloat16, memory_format=CL)
     L = _lib.lib()
     ws = _ws(L.mcl_dense_conv1x1_workspace_floats(S), x.device)
+    nz = (lambda t: None if t is None else t.data_ptr())
     check(L.mcl_dense_conv1x1_fwd(px, ldx, S, K, g1.data_ptr(), b1.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                  w16.data_ptr(), z.data_ptr(), 128, ws.data_ptr(), eps2, zmean.data_ptr(),
-                                  zvar.data_ptr(), zrstd.data_ptr(), _stream()), "mcl_dense_conv1x1_fwd")
+                                  w16.data_ptr(), z.data_ptr(), 128, ws.data_ptr(), eps2, nz(zmean),
+                                  nz(zvar), nz(zrstd), _stream()), "mcl_dense_conv1x1_fwd")
     return z
 
 
@@ -293,16 +294,17 @@ USE_FUSED_3X3 = os.environ.get("MCL_FUSED_3X3", "1") != "0"
 
 
 def dense_conv3x3_fwd(z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor, w16: Tensor, out: Tensor, eps: float,
-                      ymean: Tensor, yvar: Tensor, yrstd: Tensor) -> None:
+                      ymean: Optional[Tensor], yvar: Optional[Tensor], yrstd: Optional[Tensor]) -> None:
     """out (a 32-channel slice of the concat buffer) = conv3x3(relu(bn2(z)), w16), plus its batch statistics."""
     B, C, H, W = z.shape
     po, S, Co, ldo = _rows(out)
     assert C == 128 and Co == 32 and z.is_contiguous(memory_format=CL) and S == B * H * W
     L = _lib.lib()
     ws = _ws(L.mcl_dense_conv3x3_workspace_floats(S), z.device)
+    nz = (lambda t: None if t is None else t.data_ptr())
     check(L.mcl_dense_conv3x3_fwd(z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(), m2.data_ptr(), r2.data_ptr(),
-                                  w16.data_ptr(), po, ldo, ws.data_ptr(), eps, ymean.data_ptr(), yvar.data_ptr(),
-                                  yrstd.data_ptr(), _stream()), "mcl_dense_conv3x3_fwd")
+                                  w16.data_ptr(), po, ldo, ws.data_ptr(), eps, nz(ymean), nz(yvar),
+                                  nz(yrstd), _stream()), "mcl_dense_conv3x3_fwd")
 
 
 def dense_conv3x3_wrw(dy: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor, w_param: Tensor) -> bool:
@@ -686,4 +688,62 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
             rec.add(features.norm5, stats.mean, stats.var, n)
         i += 1
     rec.flush()
+    return out
+
+
+# --------------------------------------------------------------------------- inference (eval mode, running statistics)
+@torch.no_grad()
+def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """Eval-mode forward of torchvision-layout DenseNet ``features`` (what ``model.image_encoder`` computes for
+    /root/reference/evel_her2st.py:50) on the same fused kernels as training: every BatchNorm is the affine map of
+    its RUNNING statistics, applied inside the convolution prologues, so a dense layer is two launches (no statistics,
+    no finalize) and nothing but the concat buffers and the 128-channel bottleneck outputs touches HBM."""
+    if not x.is_cuda:
+        raise RuntimeError("densenet_features_eval: input is on the CPU; the fused backbone path is GPU-only")
+    if act_dtype != torch.bfloat16:
+        raise RuntimeError("densenet_features_eval: the fused kernels are bf16")
+    bns = [m for m in features.modules() if isinstance(m, nn.BatchNorm2d)]
+    # rstd of every BatchNorm in three multi-tensor launches
+    rstd = torch._foreach_add([bn.running_var.float() for bn in bns], [float(bn.eps) for bn in bns])
+    torch._foreach_sqrt_(rstd)
+    torch._foreach_reciprocal_(rstd)
+    rs = {id(bn): r for bn, r in zip(bns, rstd)}
+
+    def affine(t: Tensor, bn: nn.BatchNorm2d, relu: bool) -> Tensor:
+        t = t.contiguous(memory_format=CL)
+        out = torch.empty_like(t, memory_format=CL)
+        bn_act_fwd(t, bn.weight, bn.bias, bn.running_mean, rs[id(bn)], relu, out)
+        return out
+
+    x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
+    x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
+                 padding=features.conv0.padding)
+    x = max_pool_3s2(affine(x, features.norm0, True))
+    i = 1
+    out = None
+    while hasattr(features, f"denseblock{i}"):
+        layers = list(getattr(features, f"denseblock{i}").values())
+        growth = layers[0].conv2.out_channels
+        B, C0, H, W = x.shape
+        buf = torch.empty((B, C0 + len(layers) * growth, H, W), device=x.device, dtype=act_dtype, memory_format=CL)
+        buf[:, :C0].copy_(x)
+        for l, ly in enumerate(layers):
+            cin = C0 + l * growth
+            w1c, w2c = _weight(ly.conv1.weight, act_dtype), _weight(ly.conv2.weight, act_dtype)
+            if growth == 32 and _fused_1x1_ok(buf, w1c) and w1c.shape[0] == 128:
+                z = dense_conv1x1_fwd(buf[:, :cin], ly.norm1.weight, ly.norm1.bias, ly.norm1.running_mean,
+                                      rs[id(ly.norm1)], w1c, ly.norm2.eps, None, None, None)
+                dense_conv3x3_fwd(z, ly.norm2.weight, ly.norm2.bias, ly.norm2.running_mean, rs[id(ly.norm2)], w2c,
+                                  buf[:, cin:cin + growth], ly.norm1.eps, None, None, None)
+            else:
+                a = affine(buf[:, :cin], ly.norm1, True)
+                z = affine(_conv1x1_fwd(a, w1c), ly.norm2, True)
+                buf[:, cin:cin + growth].copy_(F.conv2d(z, w2c, padding=1))
+        if hasattr(features, f"transition{i}"):
+            tr = getattr(features, f"transition{i}")
+            a = affine(buf, tr.norm, True)
+            x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
+        else:
+            out = affine(buf, features.norm5, False)
+        i += 1
     return out

@@ -233,6 +233,9 @@ class _ContrastiveBase(nn.Module):
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and encoder.training
                 and image.is_cuda and torch.is_grad_enabled()):
             return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
+        if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and not encoder.training
+                and image.is_cuda and self.backbone_dtype == torch.bfloat16 and not torch.is_grad_enabled()):
+            return encoder.forward_eval_fused(image, torch.bfloat16)      # inference: running statistics
         if self.backbone_dtype is not None and self.backbone_dtype != torch.float32:
             if image.dim() == 4:
                 image = image.contiguous(memory_format=torch.channels_last)
@@ -240,6 +243,14 @@ class _ContrastiveBase(nn.Module):
                 feats = encoder(image)
             return feats.float()
         return encoder(image)
+
+    def encode_image(self, image: Tensor) -> Tensor:
+        """``self.image_encoder(image)`` through the execution path this model is configured for (fused bf16 kernels
+        when ``backbone_dtype`` is bf16, else the plain module) -- what retrieval.get_embeddings calls."""
+        enc = getattr(self, "image_encoder", None)
+        if enc is None:
+            enc = self.image_ecode
+        return self._encode_image(enc, image)
 
     def _spot_features(self, batch) -> Tensor:
         sink = self.sparse_grads if (self.embedding_grad == "rowsparse" and torch.is_grad_enabled()) else None

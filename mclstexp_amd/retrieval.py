@@ -162,7 +162,8 @@ def get_embeddings(model, loader: Iterable[Dict[str, Tensor]]) -> Tuple[Tensor, 
     dev = next(model.parameters()).device
     img_out, spot_out = [], []
     for batch in loader:
-        image_features = model.image_encoder(batch["image"].to(dev))
+        image = batch["image"].to(dev)
+        image_features = model.encode_image(image) if hasattr(model, "encode_image") else model.image_encoder(image)
         img_out.append(model.image_projection(image_features))
         spot_feature = batch["expression"].to(dev)
         x = batch["position"][:, 0].long().to(dev)

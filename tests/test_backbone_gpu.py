@@ -116,6 +116,48 @@ def test_fused_densenet_as_accurate_as_module_path(dtype):
             assert_close_scaled(c.cpu(), b64.cpu(), 1e-4 if dtype == torch.float32 else 3e-2, floor=1e-6, what=n)
 
 
+def test_fused_densenet_eval_mode_running_statistics():
+    """Inference path (evel_her2st.py:50: ``model.image_encoder(...)`` in eval mode): the fused kernels with every
+    BatchNorm folded to the affine map of its running statistics must be as close to an fp64 eval run of the same
+    module as the stock bf16-autocast module path is."""
+    base = _make()
+    with torch.no_grad():
+        for m in base.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):      # non-trivial running statistics
+                g = torch.Generator().manual_seed(m.num_features)
+                m.running_mean.copy_(torch.rand(m.num_features, generator=g) * 0.4 - 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.25)
+    ref64 = copy.deepcopy(base).double().to(DEV).eval()
+    ref = copy.deepcopy(base).to(DEV).eval()
+    fus = copy.deepcopy(base).to(DEV).eval()
+    before = {n: b.clone() for n, b in fus.named_buffers()}
+    for shape in [(5, 3, 96, 96), (2, 3, 224, 224)]:
+        x = _rand(*shape, seed=shape[0]).to(DEV)
+        with torch.no_grad():
+            y64 = ref64(x.double())
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y_ref = ref(x.contiguous(memory_format=torch.channels_last)).float()
+            y = fus.forward_eval_fused(x)
+        assert y.shape == y64.shape and y.dtype == torch.float32
+        scale = y64.abs().max().item()
+        e_ref = (y_ref.double() - y64).abs().max().item() / scale
+        e_fus = (y.double() - y64).abs().max().item() / scale
+        print(f"eval {shape}: features err stock-bf16 {e_ref:.2e} fused {e_fus:.2e}")
+        assert e_fus <= 2.0 * e_ref + 1e-5, (e_fus, e_ref)
+        assert e_fus < 5e-2
+    for n, b in fus.named_buffers():                     # eval mode must not touch the running statistics
+        assert torch.equal(b, before[n]), n
+    # the model routes eval-mode / no_grad image encoding to this path when its backbone dtype is bf16
+    from mclstexp_amd.model import mclSTExp_Attention
+    m = mclSTExp_Attention("densenet121", 1.0, 1024, 171, 256, 8, 64, 1, backbone_dtype=torch.bfloat16).to(DEV).eval()
+    m.image_encoder.load_state_dict(fus.state_dict())
+    with torch.no_grad():
+        # not bit-equal run to run: MIOpen's transition 1x1 convolutions (512->256 @28^2, 1024->512 @14^2) are
+        # split-K with atomics (tools/diag_determinism.py); every hand-written kernel on the path is deterministic
+        a, b = m.encode_image(x), fus.forward_eval_fused(x)
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+
+
 def test_model_uses_fused_backbone_and_matches_unfused():
     from mclstexp_amd import synth
     from mclstexp_amd.model import mclSTExp_Attention
@@ -156,35 +198,32 @@ def test_direct_param_grads_and_bf16_shadow():
     m.to(DEV).train()
     opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
     batch = {k: v.to(DEV) for k, v in synth.make_batch(8, G, image_hw=96, seed=0).items()}
-    # step 1 builds the flat bucket (plain hand-over: .grad does not exist yet); a second backward lets MIOpen
-    # settle its solver choices (its first-call search may pick a different algorithm than later calls)
-    loss = m(batch); opt.zero_grad(); loss.backward(); opt.step()
-    loss = m(batch); opt.zero_grad(); loss.backward()
-    grads = []
-    for direct in (True, False, False):
-        dn.DIRECT_PARAM_GRADS = direct
-        try:
-            loss = m(batch)
-            opt.zero_grad()
-            loss.backward()
-        finally:
-            dn.DIRECT_PARAM_GRADS = True
-        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if n.startswith("image_encoder")})
+    # MIOpen's default fp32 solvers use atomics and alternate between calls (tools/diag_direct.py: run-to-run
+    # deviations of several % on individual tensors of this chaotic random-init net, in discrete patterns); with
+    # its deterministic solvers every kernel on the path is reproducible and the two hand-overs must agree exactly
+    # up to the order of ONE fp32 addition per element
+    det = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    try:
+        # step 1 builds the flat bucket (plain hand-over: .grad does not exist yet)
+        loss = m(batch); opt.zero_grad(); loss.backward(); opt.step()
+        grads = []
+        for direct in (True, False, True):
+            dn.DIRECT_PARAM_GRADS = direct
+            try:
+                loss = m(batch)
+                opt.zero_grad()
+                loss.backward()
+            finally:
+                dn.DIRECT_PARAM_GRADS = True
+            grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if n.startswith("image_encoder")})
+    finally:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = det
 
-    def worst(x, y, tail):
-        w = 0.0
-        for n in x:
-            if tail and not ("denseblock4" in n or "norm5" in n):
-                continue
-            w = max(w, ((x[n] - y[n]).abs().max() / (y[n].abs().max() + 1e-20)).item())
-        return w
-    # Self-calibrating: MIOpen's weight-gradient kernels use atomics (and its solver choice can change between
-    # calls), so two IDENTICAL backward passes already differ, amplified through 120 BN layers.  The hand-over
-    # (direct accumulation vs autograd) must not differ by more than a few times that run-to-run noise.
-    noise_tail, noise_all = worst(grads[1], grads[2], True), worst(grads[1], grads[2], False)
-    d_tail, d_all = worst(grads[0], grads[1], True), worst(grads[0], grads[1], False)
-    assert d_tail <= 4.0 * noise_tail + 2e-2, (d_tail, noise_tail)
-    assert d_all <= 4.0 * noise_all + 0.1, (d_all, noise_all)      # a missed or doubled gradient would be O(1)
+    def worst(x, y):
+        return max(((x[n] - y[n]).abs().max() / (y[n].abs().max() + 1e-20)).item() for n in x)
+    assert worst(grads[0], grads[2]) == 0.0                      # the direct path is reproducible
+    assert worst(grads[0], grads[1]) <= 1e-6, worst(grads[0], grads[1])   # a missed or doubled gradient would be O(1)
     # shadow views follow the parameters
     opt.step()
     for n, p in m.named_parameters():
