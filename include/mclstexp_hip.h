@@ -265,6 +265,20 @@ int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, void* idx, int32_t N, i
 int mcl_maxpool3s2_nhwc_bf16_bwd(const void* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                  mcl_stream_t stream);
 
+/* DenseNet transition (torchvision _Transition: norm -> relu -> conv1x1 -> AvgPool2d(2,2)) with the pool moved in
+ * front of the (linear, per-pixel) convolution:  p = avgpool2x2(relu(bn(x))), bf16 NHWC, x (N*H*W, C) with row stride
+ * ldx, p (N*H/2*W/2, C) with row stride ldy; H, W even.  The convolution then runs on p (mcl_dense_conv1x1_fwd with an
+ * identity prologue), a quarter of the pixels.
+ * Backward: dp = gradient of p (pooled rows, row stride lddp); every pixel receives dp[pooled pixel]/4 through the
+ * relu mask and the full train-mode BatchNorm backward: dgamma/dbeta (accumulated into when accumulate_params != 0)
+ * and dx (written, row stride lddx).  workspace: mcl_bn_workspace_floats(N*H*W, C, 1) floats.                  */
+int mcl_bn_act_avgpool_fwd(const void* x, int64_t ldx, int32_t N, int32_t H, int32_t W, int32_t C, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, void* y, int64_t ldy,
+                           mcl_stream_t stream);
+int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* x, int64_t ldx, int32_t N, int32_t H, int32_t W,
+                           int32_t C, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                           float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx,
+                           int64_t lddx, mcl_stream_t stream);
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

@@ -193,14 +193,74 @@ __global__ __launch_bounds__(NTH) void act_fwd_kernel(const T* __restrict__ x, l
   }
 }
 
+// Transition prologue (torchvision _Transition: norm -> relu -> conv1x1 -> AvgPool2d(2, 2)).  The 1x1 convolution is
+// linear and per pixel, so it commutes with the average pool: p = avgpool(relu(bn(x))) is formed HERE (S*C read,
+// S/4*C written) and the convolution then runs on a quarter of the pixels.  Rows of y are pooled pixels.
 template <typename T>
+__global__ __launch_bounds__(NTH) void act_avgpool_fwd_kernel(const T* __restrict__ x, long long ldx, long long SP,
+                                                              int H, int W, int C, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, T* __restrict__ y,
+                                                              long long ldy, int rows_per_block) {
+  constexpr int V = Vec<T>::V;
+  const int cvn_all = C / V;
+  const int tile0 = blockIdx.y * NTH;
+  const int cvn = min(cvn_all - tile0, NTH);
+  const int rpi = NTH / cvn;
+  const int t = threadIdx.x;
+  if (t >= rpi * cvn) return;
+  const int cv = tile0 + t % cvn, rloc = t / cvn;
+  float sc[V], sh[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = cv * V + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = fmaf(-mean[c], sc[i], beta[c]);
+  }
+  const int OW = W >> 1, OH = H >> 1;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(SP, r0 + rows_per_block);
+  for (long long r = r0 + rloc; r < r1; r += rpi) {
+    const int ox = (int)(r % OW);
+    const long long tt = r / OW;
+    const int oy = (int)(tt % OH);
+    const long long n = tt / OH;
+    const long long base = ((n * H + 2 * oy) * W + 2 * ox);
+    float a[V], b[V], c[V], d[V];
+    Vec<T>::load(x + base * ldx + (long long)cv * V, a);
+    Vec<T>::load(x + (base + 1) * ldx + (long long)cv * V, b);
+    Vec<T>::load(x + (base + W) * ldx + (long long)cv * V, c);
+    Vec<T>::load(x + (base + W + 1) * ldx + (long long)cv * V, d);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float va = fmaxf(fmaf(a[i], sc[i], sh[i]), 0.0f), vb = fmaxf(fmaf(b[i], sc[i], sh[i]), 0.0f);
+      const float vc = fmaxf(fmaf(c[i], sc[i], sh[i]), 0.0f), vd = fmaxf(fmaf(d[i], sc[i], sh[i]), 0.0f);
+      a[i] = 0.25f * ((va + vb) + (vc + vd));
+    }
+    Vec<T>::store(y + r * ldy + (long long)cv * V, a);
+  }
+}
+
+// POOL: dy is the gradient of the 2x2-average-pooled activation (rows = pooled pixels); the gradient reaching
+// pixel r of the (n, H, W) map is dy[pooled(r)] / 4 (transition: norm -> relu -> avgpool, see bn_act_avgpool_fwd)
+__device__ __forceinline__ long long pooled_row(long long r, int H, int W) {
+  const int xw = (int)(r % W);
+  const long long t = r / W;
+  const int yh = (int)(t % H);
+  const long long n = t / H;
+  return (n * (H >> 1) + (yh >> 1)) * (W >> 1) + (xw >> 1);
+}
+
+template <typename T, bool POOL = false>
 __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict__ dy, long long lddy,
                                                              const T* __restrict__ x, long long ldx, long long S,
                                                              int C, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, int relu,
-                                                             float* __restrict__ partial, int rows_per_block) {
+                                                             float* __restrict__ partial, int rows_per_block,
+                                                             int H = 0, int W = 0) {
   constexpr int V = Vec<T>::V;
   __shared__ float smem[NTH * 2 * V];
   const int cvn_all = C / V;
@@ -228,9 +288,10 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
     for (long long r = r0 + rloc; r < r1; r += rpi) {
       float f[V], g[V];
       Vec<T>::load(x + r * ldx + (long long)cv * V, f);
-      Vec<T>::load(dy + r * lddy + (long long)cv * V, g);
+      Vec<T>::load(dy + (POOL ? pooled_row(r, H, W) : r) * lddy + (long long)cv * V, g);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
+        if (POOL) g[i] *= 0.25f;
         const float gi = (relu && fmaf(f[i], sc[i], sh[i]) <= 0.0f) ? 0.0f : g[i];
         s1[i] += gi;
         s2[i] = fmaf(gi, (f[i] - mu[i]) * rs[i], s2[i]);
@@ -279,7 +340,7 @@ __global__ __launch_bounds__(256) void act_bwd_finalize_kernel(const float* __re
   coef[2 * c + 1] = (float)(b / (double)S);
 }
 
-template <typename T>
+template <typename T, bool POOL = false>
 __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ dy, long long lddy,
                                                          const T* __restrict__ x, long long ldx, long long S, int C,
                                                          const float* __restrict__ gamma,
@@ -287,7 +348,7 @@ __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, int relu,
                                                          const float* __restrict__ coef, T* dx, long long lddx,
-                                                         int accumulate, int rows_per_block) {
+                                                         int accumulate, int rows_per_block, int H = 0, int W = 0) {
   constexpr int V = Vec<T>::V;
   const int cvn_all = C / V;
   const int tile0 = blockIdx.y * NTH;
@@ -312,10 +373,11 @@ __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ d
   for (long long r = r0 + rloc; r < r1; r += rpi) {
     float f[V], g[V], o[V];
     Vec<T>::load(x + r * ldx + (long long)cv * V, f);
-    Vec<T>::load(dy + r * lddy + (long long)cv * V, g);
+    Vec<T>::load(dy + (POOL ? pooled_row(r, H, W) : r) * lddy + (long long)cv * V, g);
     if (accumulate) Vec<T>::load(dx + r * lddx + (long long)cv * V, o);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
+      if (POOL) g[i] *= 0.25f;
       const float gi = (relu && fmaf(f[i], sc[i], sh[i]) <= 0.0f) ? 0.0f : g[i];
       const float xh = (f[i] - mu[i]) * rs[i];
       const float d = sc[i] * (gi - c1[i] - xh * c2[i]);
@@ -447,6 +509,49 @@ extern "C" int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64
                        (const float*)x, (long long)ldx, (long long)S, C, gamma, beta, mean, rstd, relu, coef,
                        (float*)dx, (long long)lddx, accumulate, rpb);
   }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_bn_act_avgpool_fwd(const void* x, int64_t ldx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                      const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                      void* y, int64_t ldy, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!gamma || !beta || !mean || !rstd || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
+  if ((H & 1) || (W & 1) || !ok_layout(x, ldx, C, 1) || !ok_layout(y, ldy, C, 1)) return MCL_EUNSUPPORTED;
+  const long long SP = (long long)N * (H / 2) * (W / 2);
+  int nblk, rpb, tiles;
+  plan(SP, C, 1, &nblk, &rpb, &tiles);
+  hipLaunchKernelGGL(act_avgpool_fwd_kernel<bf16_t>, dim3(nblk, tiles), dim3(NTH), 0, mcl_stream(stream),
+                     (const bf16_t*)x, (long long)ldx, SP, H, W, C, gamma, beta, mean, rstd, (bf16_t*)y,
+                     (long long)ldy, rpb);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* x, int64_t ldx, int32_t N, int32_t H,
+                                      int32_t W, int32_t C, const float* gamma, const float* beta, const float* mean,
+                                      const float* rstd, float* workspace, float* dgamma, float* dbeta,
+                                      int32_t accumulate_params, void* dx, int64_t lddx, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || N <= 0 || H <= 0 || W <= 0 || C <= 0)
+    return MCL_EINVAL;
+  if ((H & 1) || (W & 1) || !ok_layout(dp, lddp, C, 1) || !ok_layout(x, ldx, C, 1) || !ok_layout(dx, lddx, C, 1))
+    return MCL_EUNSUPPORTED;
+  const long long S = (long long)N * H * W;
+  int nblk, rpb, tiles;
+  plan(S, C, 1, &nblk, &rpb, &tiles);
+  dim3 grid(nblk, tiles);
+  hipStream_t st = mcl_stream(stream);
+  float* coef = workspace + (long long)nblk * 2 * C;
+  hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, true>), grid, dim3(NTH), 0, st, (const bf16_t*)dp,
+                     (long long)lddp, (const bf16_t*)x, (long long)ldx, S, C, gamma, beta, mean, rstd, 1, workspace, rpb,
+                     H, W);
+  hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nblk, C, S, dgamma,
+                     dbeta, coef, accumulate_params);
+  hipLaunchKernelGGL((act_bwd_dx_kernel<bf16_t, true>), grid, dim3(NTH), 0, st, (const bf16_t*)dp, (long long)lddp,
+                     (const bf16_t*)x, (long long)ldx, S, C, gamma, beta, mean, rstd, 1, coef, (bf16_t*)dx,
+                     (long long)lddx, 0, rpb, H, W);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -448,14 +448,18 @@ class DenseBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, meta, *params):
-        stats, eps1, eps2, growth, bn2_stats = meta
+        stats, eps1, eps2, growth, bn2_stats = meta[:5]
+        prefilled = len(meta) > 5 and meta[5]       # stats[:C0] already hold x0's statistics (TransitionFn)
         L = len(params) // 6
         B, C0, H, W = x0.shape
         Ct = C0 + L * growth
         dev, dt = x0.device, x0.dtype
         buf = torch.empty((B, Ct, H, W), device=dev, dtype=dt, memory_format=CL)
         x0 = x0.contiguous(memory_format=CL)
-        bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
+        if prefilled:
+            buf[:, :C0].copy_(x0)
+        else:
+            bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
         saved = []
         wcast = []
         for l in range(L):
@@ -578,18 +582,23 @@ def _bn_train(x: Tensor, bn: nn.BatchNorm2d, relu: bool, rec: _RunningStats) -> 
     return BNActFn.apply(x, bn.weight, bn.bias, mean, rstd, relu)
 
 
-def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats) -> Tuple[Tensor, _BlockStats]:
+def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats, stats: Optional[_BlockStats] = None
+                ) -> Tuple[Tensor, _BlockStats]:
+    """``stats``: a _BlockStats whose first C0 entries already hold the statistics of ``x`` (produced by the
+    transition's convolution epilogue) -- the block then only copies x into its buffer."""
     layers = list(blk.values())
     growth = layers[0].conv2.out_channels
     C0 = x.shape[1]
     Ct = C0 + len(layers) * growth
-    stats = _BlockStats(Ct, x.device)
+    prefilled = stats is not None
+    if stats is None:
+        stats = _BlockStats(Ct, x.device)
     bott = layers[0].conv1.out_channels
     bn2 = [tuple(torch.empty(bott, device=x.device, dtype=torch.float32) for _ in range(3)) for _ in layers]
     params = []
     for ly in layers:
         params += [ly.norm1.weight, ly.norm1.bias, ly.conv1.weight, ly.norm2.weight, ly.norm2.bias, ly.conv2.weight]
-    meta = (stats, [ly.norm1.eps for ly in layers], [ly.norm2.eps for ly in layers], growth, bn2)
+    meta = (stats, [ly.norm1.eps for ly in layers], [ly.norm2.eps for ly in layers], growth, bn2, prefilled)
     buf = DenseBlockFn.apply(x, meta, *params)
     n = x.shape[0] * x.shape[2] * x.shape[3]
     for i, ly in enumerate(layers):
@@ -661,6 +670,109 @@ def avg_pool_2(x: Tensor) -> Tensor:
     return AvgPool2Fn.apply(x) if _pool_ok(x, True) else F.avg_pool2d(x, 2, 2)
 
 
+# --------------------------------------------------------------------------- transitions
+# torchvision _Transition = norm -> relu -> conv1x1 (C -> C/2) -> AvgPool2d(2, 2).  The convolution is linear and per
+# pixel, so it commutes with the pool: p = avgpool(relu(bn(buf))) is formed first (csrc/bnrelu.hip) and the
+# convolution, its weight gradient and its data gradient all run on a QUARTER of the pixels, on the same kernels as
+# the dense layers' bottleneck convolution (identity BN prologue: p >= 0 so relu(1*p + 0) == p); its epilogue yields
+# the batch statistics the next block's norm1 layers need, so that pass disappears too.
+USE_FUSED_TRANSITION = os.environ.get("MCL_FUSED_TRANSITION", "1") != "0"
+_ident_cache = {}
+
+
+def _identity_bn(device) -> Tuple[Tensor, Tensor]:
+    v = _ident_cache.get(device.index)
+    if v is None:
+        v = (torch.ones(1024, device=device, dtype=torch.float32), torch.zeros(1024, device=device, dtype=torch.float32))
+        _ident_cache[device.index] = v
+    return v
+
+
+def bn_act_avgpool_fwd(x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor) -> Tensor:
+    B, C, H, W = x.shape
+    px, S, _, ld = _rows(x)
+    p = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=x.dtype, memory_format=CL)
+    check(_lib.lib().mcl_bn_act_avgpool_fwd(px, ld, B, H, W, C, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                            rstd.data_ptr(), p.data_ptr(), C, _stream()), "mcl_bn_act_avgpool_fwd")
+    return p
+
+
+def pooled_conv1x1_fwd(p: Tensor, w16: Tensor, eps: float, stats: Optional[_BlockStats]) -> Tensor:
+    """y = conv1x1(p, w16) for C_out a multiple of 128 (one launch per 128 output channels, each with its statistics
+    epilogue writing stats.mean/var/rstd[n0:n0+128]); ``stats`` None: no statistics (inference)."""
+    B, C, H, W = p.shape
+    Co = w16.shape[0]
+    y = torch.empty((B, Co, H, W), device=p.device, dtype=p.dtype, memory_format=CL)
+    one, zero = _identity_bn(p.device)
+    pp, S, _, ldp = _rows(p)
+    L = _lib.lib()
+    ws = _ws(L.mcl_dense_conv1x1_workspace_floats(S), p.device)
+    for n0 in range(0, Co, 128):
+        st = (None, None, None) if stats is None else tuple(t.data_ptr() + 4 * n0 for t in (stats.mean, stats.var, stats.rstd))
+        check(L.mcl_dense_conv1x1_fwd(pp, ldp, S, C, one.data_ptr(), zero.data_ptr(), zero.data_ptr(), one.data_ptr(),
+                                      w16.data_ptr() + 2 * n0 * C, y.data_ptr() + 2 * n0, Co, ws.data_ptr(), eps,
+                                      *st, _stream()), "mcl_dense_conv1x1_fwd (transition)")
+    return y
+
+
+def _transition_ok(buf: Tensor, w: Tensor) -> bool:
+    B, C, H, W = buf.shape
+    return (USE_FUSED_TRANSITION and USE_FUSED_1X1 and buf.is_cuda and buf.dtype == torch.bfloat16 and H % 2 == 0
+            and W % 2 == 0 and C % 8 == 0 and C <= 1024 and w.shape[0] % 128 == 0 and w.shape[1] == C
+            and buf.is_contiguous(memory_format=CL))
+
+
+class TransitionFn(torch.autograd.Function):
+    """(B, C, H, W) block buffer -> (B, C/2, H/2, W/2); meta = (stats of the buffer, _BlockStats of the NEXT block
+    whose first C/2 entries are filled here, eps of the next block's norm1)."""
+
+    @staticmethod
+    def forward(ctx, buf, gamma, beta, w, meta):
+        stats, next_stats, eps_next = meta
+        p = bn_act_avgpool_fwd(buf, gamma, beta, stats.mean, stats.rstd)
+        w16 = _weight(w, buf.dtype)
+        y = pooled_conv1x1_fwd(p, w16, eps_next, next_stats)
+        ctx.save_for_backward(buf, p, w16)
+        ctx.params = (gamma, beta, w)
+        ctx.stats = stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        buf, p, w16 = ctx.saved_tensors
+        gamma, beta, w = ctx.params
+        stats = ctx.stats
+        B, C, H, W = buf.shape
+        Co = w16.shape[0]
+        _rows(dy)                                             # channels-last (possibly channel-sliced) view
+        main = torch.cuda.current_stream()
+        side = _side_stream(buf.device) if USE_SIDE_STREAM else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw = conv1x1_wrw(dy, p, w)                    # dW += dy^T p, straight into w.grad when it exists
+        else:
+            dw = conv1x1_wrw(dy, p, w)
+        dp = torch.mm(_as2d(dy), w16.view(Co, C))             # (S/4, C): plain library GEMM (hipBLASLt)
+        dx = torch.empty_like(buf, memory_format=CL)
+        direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
+        if direct:
+            dg, db = gamma.grad, beta.grad
+        else:
+            dg = torch.empty(C, device=buf.device, dtype=torch.float32)
+            db = torch.empty(C, device=buf.device, dtype=torch.float32)
+        L = _lib.lib()
+        ws = _ws(L.mcl_bn_workspace_floats(B * H * W, C, 1), buf.device)
+        check(L.mcl_bn_act_avgpool_bwd(dp.data_ptr(), C, buf.data_ptr(), C, B, H, W, C, gamma.data_ptr(),
+                                       beta.data_ptr(), stats.mean.data_ptr(), stats.rstd.data_ptr(), ws.data_ptr(),
+                                       dg.data_ptr(), db.data_ptr(), int(direct), dx.data_ptr(), C, _stream()),
+              "mcl_bn_act_avgpool_bwd")
+        if side is not None:
+            main.wait_stream(side)
+        gw = None if dw is None else dw.view_as(w).to(w.dtype)
+        return dx, (None if direct else dg), (None if direct else db), gw, None
+
+
 def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
     """Train-mode forward of torchvision-layout DenseNet ``features`` (conv0 ... norm5), returning the
     (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly)."""
@@ -674,15 +786,24 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     x = max_pool_3s2(x.contiguous(memory_format=CL))
     i = 1
     out = None
+    next_stats = None
     while hasattr(features, f"denseblock{i}"):
-        buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec)
+        buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec, next_stats)
+        next_stats = None
         n = buf.shape[0] * buf.shape[2] * buf.shape[3]
         if hasattr(features, f"transition{i}"):
             tr = getattr(features, f"transition{i}")
-            a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
             rec.add(tr.norm, stats.mean, stats.var, n)
-            x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
-            x = avg_pool_2(x.contiguous(memory_format=CL))
+            nxt = list(getattr(features, f"denseblock{i + 1}").values()) if hasattr(features, f"denseblock{i + 1}") else None
+            if nxt is not None and _transition_ok(buf, tr.conv.weight):
+                co = tr.conv.weight.shape[0]
+                next_stats = _BlockStats(co + len(nxt) * nxt[0].conv2.out_channels, buf.device)
+                x = TransitionFn.apply(buf, tr.norm.weight, tr.norm.bias, tr.conv.weight,
+                                       (stats, next_stats, nxt[0].norm1.eps))
+            else:
+                a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
+                x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
+                x = avg_pool_2(x.contiguous(memory_format=CL))
         else:
             out = BNActFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd, False)
             rec.add(features.norm5, stats.mean, stats.var, n)
@@ -741,8 +862,12 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 buf[:, cin:cin + growth].copy_(F.conv2d(z, w2c, padding=1))
         if hasattr(features, f"transition{i}"):
             tr = getattr(features, f"transition{i}")
-            a = affine(buf, tr.norm, True)
-            x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
+            if _transition_ok(buf, tr.conv.weight):
+                p = bn_act_avgpool_fwd(buf, tr.norm.weight, tr.norm.bias, tr.norm.running_mean, rs[id(tr.norm)])
+                x = pooled_conv1x1_fwd(p, _weight(tr.conv.weight, act_dtype), tr.norm.eps, None)
+            else:
+                a = affine(buf, tr.norm, True)
+                x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
         else:
             out = affine(buf, features.norm5, False)
         i += 1

@@ -466,3 +466,82 @@ def test_pool_kernels(B, C, H, W):
         ya.backward(d2.float())
         yb.backward(d2)
         assert_close(xb.grad.float().cpu(), xa.grad.cpu(), 2e-3, what="avg pool backward")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 24, 24), (3, 512, 6, 10), (1, 1024, 14, 14), (2, 40, 4, 2)])
+def test_transition_kernels(B, C, H, W):
+    """csrc/bnrelu.hip bn_act_avgpool fwd / bwd (transition with the pool moved in front of the convolution) against
+    fp64 autograd of avg_pool2d(relu(batch_norm_train(x))) on the same bf16 data."""
+    import torch.nn.functional as F
+    from mclstexp_amd import _lib, densenet_fused as dn
+    from mclstexp_amd._lib import check
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.rand(C, generator=g) - 0.5).to(DEV)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean = x64.detach().mean(dim=(0, 2, 3))
+    var = x64.detach().var(dim=(0, 2, 3), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    ref = F.avg_pool2d(torch.relu(F.batch_norm(x64, None, None, g64, b64, True, 0.1, 1e-5)), 2, 2)
+    mean32, rstd32 = mean.float(), rstd.float()        # kept alive: the raw-pointer calls below do not own them
+    p = dn.bn_act_avgpool_fwd(x, gamma, beta, mean32, rstd32)
+    assert p.shape == ref.shape
+    assert_close(p.float().cpu(), ref.detach().cpu(), 1e-2, 8e-3, what="avgpool(relu(bn(x)))")
+    dp = (torch.rand(ref.shape, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    ref.backward(dp.double())
+    dx = torch.empty_like(x)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    L = _lib.lib()
+    ws = dn._ws(L.mcl_bn_workspace_floats(B * H * W, C, 1), x.device)
+    check(L.mcl_bn_act_avgpool_bwd(dp.data_ptr(), C, x.data_ptr(), C, B, H, W, C, gamma.data_ptr(), beta.data_ptr(),
+                                   mean32.data_ptr(), rstd32.data_ptr(), ws.data_ptr(), dg.data_ptr(),
+                                   db.data_ptr(), 0, dx.data_ptr(), C, dn._stream()), "mcl_bn_act_avgpool_bwd")
+    assert_close_scaled(dg.cpu(), g64.grad.cpu(), 2e-3, what="dgamma")
+    assert_close_scaled(db.cpu(), b64.grad.cpu(), 2e-3, what="dbeta")
+    assert_close_scaled(dx.float().cpu(), x64.grad.cpu(), 1e-2, what="dx")
+    # accumulate_params: adds onto existing dgamma / dbeta
+    check(L.mcl_bn_act_avgpool_bwd(dp.data_ptr(), C, x.data_ptr(), C, B, H, W, C, gamma.data_ptr(), beta.data_ptr(),
+                                   mean32.data_ptr(), rstd32.data_ptr(), ws.data_ptr(), dg.data_ptr(),
+                                   db.data_ptr(), 1, dx.data_ptr(), C, dn._stream()), "mcl_bn_act_avgpool_bwd")
+    assert_close_scaled(dg.cpu(), 2 * g64.grad.cpu(), 2e-3, what="dgamma accumulated")
+
+
+@pytest.mark.parametrize("B,C,H,W,layers", [(2, 256, 24, 24, 3), (4, 512, 12, 12, 2), (8, 1024, 6, 6, 2)])
+def test_transition_fn_matches_module(B, C, H, W, layers):
+    """TransitionFn (pool first, convolution on a quarter of the pixels, statistics for the next block from the
+    convolution epilogue) against fp64 autograd of the torchvision order norm -> relu -> conv -> pool."""
+    import torch.nn.functional as F
+    from mclstexp_amd import densenet_fused as dn
+    g = torch.Generator().manual_seed(C)
+    buf = (torch.randn(B, C, H, W, generator=g) + 0.2).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    gamma = torch.nn.Parameter((torch.rand(C, generator=g) + 0.5).to(DEV))
+    beta = torch.nn.Parameter((torch.rand(C, generator=g) - 0.5).to(DEV))
+    w = torch.nn.Parameter((torch.randn(C // 2, C, 1, 1, generator=g) * (2.0 / C) ** 0.5).to(DEV))
+    stats = dn._BlockStats(C, buf.device)
+    dn.bn_stats(buf, stats.mean, stats.var, stats.rstd, 1e-5)
+    nxt = dn._BlockStats(C // 2 + 32 * layers, buf.device)
+    xb = buf.clone().requires_grad_(True)
+    y = dn.TransitionFn.apply(xb, gamma, beta, w, (stats, nxt, 1e-5))
+    x64 = buf.double().requires_grad_(True)
+    g64, b64 = gamma.detach().double().requires_grad_(True), beta.detach().double().requires_grad_(True)
+    w64 = w.detach().to(torch.bfloat16).double().requires_grad_(True)
+    ref = F.avg_pool2d(F.conv2d(torch.relu(F.batch_norm(x64, None, None, g64, b64, True, 0.1, 1e-5)), w64), 2, 2)
+    assert_close_scaled(y.detach().float().cpu(), ref.detach().cpu(), 1e-2, what="transition forward")
+    # statistics of the (bf16) output for the next block's norm1 layers
+    yd = y.detach().double()
+    assert_close(nxt.mean[:C // 2].cpu(), yd.mean(dim=(0, 2, 3)).cpu(), 2e-4, 1e-3, what="next-block mean")
+    assert_close(nxt.var[:C // 2].cpu(), yd.var(dim=(0, 2, 3), unbiased=False).cpu(), 1e-5, 2e-3, what="next-block var")
+    assert_close(nxt.rstd[:C // 2].cpu(), torch.rsqrt(yd.var(dim=(0, 2, 3), unbiased=False) + 1e-5).cpu(), 1e-4, 2e-3,
+                 what="next-block rstd")
+    # backward with the gradient arriving as a channel slice of a wider buffer (what DenseBlockFn hands over)
+    wide = (torch.rand(B, C // 2 + 32, H // 2, W // 2, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(
+        memory_format=torch.channels_last)
+    dy = wide[:, :C // 2]
+    y.backward(dy)
+    ref.backward(dy.double())
+    assert_close_scaled(xb.grad.float().cpu(), x64.grad.cpu(), 1.5e-2, what="d buf")
+    assert_close_scaled(gamma.grad.cpu(), g64.grad.cpu(), 5e-3, what="dgamma")
+    assert_close_scaled(beta.grad.cpu(), b64.grad.cpu(), 5e-3, what="dbeta")
+    assert_close_scaled(w.grad.cpu(), w64.grad.cpu(), 5e-3, what="dW")
