@@ -141,7 +141,7 @@ def main():
     bb = torch.bfloat16 if args.backbone_dtype == "bf16" else None
     model = mclSTExp_Attention(args.encoder, 1.0, args.image_dim, args.genes, 256, 8, 64, 2, compute=args.compute,
                                backbone_dtype=bb, embedding_grad="rowsparse",
-                               process_group=pg if world > 1 else None, infonce=args.infonce)
+                               process_group=pg, infonce=args.infonce)
     from mclstexp_amd import densenet_fused
     densenet_fused.USE_MM_1X1 = args.conv1x1 == "mm"
     model.fused_backbone = not args.unfused_backbone
@@ -150,7 +150,8 @@ def main():
         model.to(memory_format=torch.channels_last)
     model.train()
     opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(model)
-    reducer = mdist.GradReducer(pg) if world > 1 else None
+    dist_on = pg is not None            # world > 1, or MCL_FORCE_DIST=1 (size-1 RCCL group: DP code path on one GPU)
+    reducer = mdist.GradReducer(pg) if dist_on else None
 
     # synthetic inputs, resident in HBM before the timed region (4 distinct batches, cycled)
     batches = []
@@ -181,7 +182,7 @@ def main():
             log(f"warm-up step {i}: {time.perf_counter() - tw:.2f} s")
     torch.cuda.synchronize()
     log("timed region")
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     opt.profile_events = []
@@ -190,7 +191,7 @@ def main():
         loss = step(i)
     t_host = time.perf_counter() - t0          # host enqueue time (no sync inside the loop)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -199,7 +200,7 @@ def main():
     final_loss = float(loss.item())
     ev = opt.profile_events
     opt.profile_events = None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())

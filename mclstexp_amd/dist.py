@@ -41,7 +41,9 @@ def init_from_env() -> Tuple[Optional[td.ProcessGroup], int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    if world <= 1:
+    # MCL_FORCE_DIST=1: build the (size-1) RCCL group anyway, so that the complete data-parallel code path --
+    # collectives, reducer, gathered table rows -- can be exercised and profiled on a single-GPU box
+    if world <= 1 and os.environ.get("MCL_FORCE_DIST", "0") != "1":
         return None, 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")

@@ -93,3 +93,63 @@ def test_two_rank_dp_step_on_one_gpu():
     for n in ret[0]["chk"]:
         assert ret[0]["chk"][n] == ret[1]["chk"][n], n
     assert torch.equal(ret[0]["xrows"], ret[1]["xrows"])
+
+
+def _rccl_worker(_index, port, ret):
+    """Size-1 RCCL group: the full data-parallel step (bf16 embedding all-gather, LSE all-gather, async flat
+    all-reduce, gathered table rows, HIP-graph replay around the collectives) on the REAL nccl backend."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      MCL_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("MCL_DIST_BACKEND", None)
+    from mclstexp_amd import dist as mdist, synth
+    from mclstexp_amd.engine import TrainStep
+    from mclstexp_amd.model import mclSTExp_Attention
+    from mclstexp_amd.optim import FusedAdam
+    pg, rank, world = mdist.init_from_env()
+    try:
+        assert pg is not None and torch.distributed.get_backend(pg) == "nccl"
+        G, D, B = 171, 1024, 16
+        out = {}
+        for mode, group in (("dist", pg), ("single", None)):
+            m = mclSTExp_Attention("identity", 1.0, D, G, 256, 8, 64, 2, embedding_grad="rowsparse",
+                                   process_group=group, infonce="fused")
+            m.load_state_dict(synth.make_params(G, D, seed=0))
+            m.cuda().train()
+            opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
+            step = TrainStep(m, opt, mdist.GradReducer(group) if group is not None else None, graphs=True, warmup=2)
+            losses = []
+            for s in range(6):
+                batch = {k: v.cuda() for k, v in synth.make_batch(B, G, image_dim=D, seed=s % 2).items()}
+                losses.append(float(step(batch).item()))
+            out[mode] = (losses, {n: p.detach().double().sum().item() for n, p in m.named_parameters()})
+        ret["out"] = out
+    finally:
+        mdist.shutdown()
+
+
+def test_rccl_size1_group_matches_single_process():
+    # a plain child process (not mp.spawn: tearing a spawned RCCL process down through the multiprocessing manager
+    # stalled for minutes); the child prints its result as JSON and leaves with os._exit
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl1", str(_free_port())], capture_output=True,
+                       text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL1 ")]
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    out = json.loads(line[-1][6:])
+    (l_d, c_d), (l_s, c_s) = out["dist"], out["single"]
+    for a, b in zip(l_d, l_s):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (l_d, l_s)
+    for n in c_s:
+        assert abs(c_d[n] - c_s[n]) <= 1e-5 * max(1.0, abs(c_s[n])), n
+
+
+if __name__ == "__main__" and len(os.sys.argv) == 3 and os.sys.argv[1] == "--rccl1":
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    _ret = {}
+    _rccl_worker(0, int(sys.argv[2]), _ret)
+    print("RCCL1 " + json.dumps(_ret["out"]), flush=True)
+    os._exit(0)
