@@ -279,6 +279,13 @@ int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* x, int64_t 
                            int32_t C, const float* gamma, const float* beta, const float* mean, const float* rstd,
                            float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx,
                            int64_t lddx, mcl_stream_t stream);
+/* DenseNet stem tail norm0 -> relu0 -> pool0 (MaxPool2d(3, 2, 1)) in one pass over the conv0 output x (N,H,W,C) bf16
+ * NHWC contiguous: y (N,OH,OW,C) = maxpool(relu(bn(x))), idx = arg-max byte per pooled element (ky*3+kx, first maximum
+ * in window order).  Backward: mcl_maxpool3s2_nhwc_bf16_bwd(idx, dy) followed by mcl_bn_act_bwd(relu = 1) on x
+ * (fusing the gather into both BatchNorm-backward passes was measured slower: 388 us vs 217 us at 128 x 112^2 x 64). */
+int mcl_bn_act_maxpool_fwd(const void* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, void* y, void* idx,
+                           mcl_stream_t stream);
 /* dst[i] += (float)src[i], i < n, in storage order (src_dtype 0 = fp32, 1 = bf16): adds a low-precision
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);

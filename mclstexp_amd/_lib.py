@@ -91,6 +91,7 @@ PROTOTYPES = {
     "mcl_bn_act_avgpool_fwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "mcl_bn_act_avgpool_bwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,
                                c_p],
+    "mcl_bn_act_maxpool_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_l2_normalize_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mcl_topk_rows_max_k": [],
     "mcl_topk_rows": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],

@@ -252,7 +252,7 @@ __device__ __forceinline__ long long pooled_row(long long r, int H, int W) {
   return (n * (H >> 1) + (yh >> 1)) * (W >> 1) + (xw >> 1);
 }
 
-template <typename T, bool POOL = false>
+template <typename T, int MODE = 0>
 __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict__ dy, long long lddy,
                                                              const T* __restrict__ x, long long ldx, long long S,
                                                              int C, const float* __restrict__ gamma,
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
                                                              const float* __restrict__ rstd, int relu,
                                                              float* __restrict__ partial, int rows_per_block,
                                                              int H = 0, int W = 0) {
+  constexpr bool POOL = MODE == 1;
   constexpr int V = Vec<T>::V;
   __shared__ float smem[NTH * 2 * V];
   const int cvn_all = C / V;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void act_bwd_finalize_kernel(const float* __re
   coef[2 * c + 1] = (float)(b / (double)S);
 }
 
-template <typename T, bool POOL = false>
+template <typename T, int MODE = 0>
 __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ dy, long long lddy,
                                                          const T* __restrict__ x, long long ldx, long long S, int C,
                                                          const float* __restrict__ gamma,
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ d
                                                          const float* __restrict__ rstd, int relu,
                                                          const float* __restrict__ coef, T* dx, long long lddx,
                                                          int accumulate, int rows_per_block, int H = 0, int W = 0) {
+  constexpr bool POOL = MODE == 1;
   constexpr int V = Vec<T>::V;
   const int cvn_all = C / V;
   const int tile0 = blockIdx.y * NTH;
@@ -544,12 +546,12 @@ extern "C" int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* 
   dim3 grid(nblk, tiles);
   hipStream_t st = mcl_stream(stream);
   float* coef = workspace + (long long)nblk * 2 * C;
-  hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, true>), grid, dim3(NTH), 0, st, (const bf16_t*)dp,
+  hipLaunchKernelGGL((act_bwd_reduce_kernel<bf16_t, 1>), grid, dim3(NTH), 0, st, (const bf16_t*)dp,
                      (long long)lddp, (const bf16_t*)x, (long long)ldx, S, C, gamma, beta, mean, rstd, 1, workspace, rpb,
                      H, W);
   hipLaunchKernelGGL(act_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, st, workspace, nblk, C, S, dgamma,
                      dbeta, coef, accumulate_params);
-  hipLaunchKernelGGL((act_bwd_dx_kernel<bf16_t, true>), grid, dim3(NTH), 0, st, (const bf16_t*)dp, (long long)lddp,
+  hipLaunchKernelGGL((act_bwd_dx_kernel<bf16_t, 1>), grid, dim3(NTH), 0, st, (const bf16_t*)dp, (long long)lddp,
                      (const bf16_t*)x, (long long)ldx, S, C, gamma, beta, mean, rstd, 1, coef, (bf16_t*)dx,
                      (long long)lddx, 0, rpb, H, W);
   MCL_CHECK_LAUNCH();

@@ -68,9 +68,15 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16_t* __restr
 
 // MaxPool2d(3, stride 2, pad 1): y = max over the window (padding = -inf); idx = window position (ky*3 + kx) of the
 // FIRST maximum in row-major window order (ATen's tie rule: strict > while scanning), one byte per element
+// BN: the pooled tensor is relu(x*scale + shift) (the DenseNet stem norm0 -> relu0 -> pool0 in one pass: the
+// normalised full-resolution map is never written)
+template <bool BN>
 __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                              unsigned char* __restrict__ idx, int N, int H, int W,
-                                                             int OH, int OW, int C8) {
+                                                             int OH, int OW, int C8, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd) {
   const long long total = (long long)N * OH * OW * C8;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
     const int c8 = (int)(q % C8);
@@ -78,6 +84,15 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
     const int ox = (int)(op % OW), oy = (int)((op / OW) % OH), n = (int)(op / ((long long)OW * OH));
     float m[8];
     unsigned am[8];
+    float sc[8], sh[8];
+    if (BN) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c8 * 8 + i;
+        sc[i] = gamma[c] * rstd[c];
+        sh[i] = fmaf(-mean[c], sc[i], beta[c]);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       m[i] = -INFINITY;
@@ -91,6 +106,10 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
           float v[8];
           unpack8(*reinterpret_cast<const uint4*>(x + ((((long long)n * H + iy) * W + ix) * C8 + c8) * 8), v);
+          if (BN) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.0f);
+          }
 #pragma unroll
           for (int i = 0; i < 8; ++i)
             if (v[i] > m[i]) {      // strict: the first maximum wins; the first valid element beats -inf
@@ -176,8 +195,25 @@ extern "C" int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, void* idx, i
   if (C % 8) return MCL_EUNSUPPORTED;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * OH * OW * (C / 8);
-  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x,
-                     (bf16_t*)y, (unsigned char*)idx, N, H, W, OH, OW, C / 8);
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream),
+                     (const bf16_t*)x, (bf16_t*)y, (unsigned char*)idx, N, H, W, OH, OW, C / 8, nullptr, nullptr, nullptr,
+                     nullptr);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_bn_act_maxpool_fwd(const void* x, int32_t N, int32_t H, int32_t W, int32_t C, const float* gamma,
+                                      const float* beta, const float* mean, const float* rstd, void* y, void* idx,
+                                      mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!ok16(x) || !ok16(y) || !idx || (reinterpret_cast<uintptr_t>(idx) & 7u) || !gamma || !beta || !mean || !rstd ||
+      N <= 0 || H <= 0 || W <= 0 || C <= 0)
+    return MCL_EINVAL;
+  if (C % 8) return MCL_EUNSUPPORTED;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 8);
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream),
+                     (const bf16_t*)x, (bf16_t*)y, (unsigned char*)idx, N, H, W, OH, OW, C / 8, gamma, beta, mean, rstd);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

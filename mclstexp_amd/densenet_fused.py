@@ -662,6 +662,43 @@ class MaxPool3s2Fn(torch.autograd.Function):
         return dx
 
 
+class StemTailFn(torch.autograd.Function):
+    """norm0 -> relu0 -> pool0 of the DenseNet stem as one pass over the conv0 output (csrc/pool.hip, csrc/bnrelu.hip):
+    the normalised full-resolution map is never written (the backward recomputes the ReLU mask from x)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, rstd):
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=x.dtype, memory_format=CL)
+        idx = torch.empty((B, y.shape[2], y.shape[3], C), device=x.device, dtype=torch.uint8)
+        check(_lib.lib().mcl_bn_act_maxpool_fwd(x.data_ptr(), B, H, W, C, gamma.data_ptr(), beta.data_ptr(),
+                                                mean.data_ptr(), rstd.data_ptr(), y.data_ptr(), idx.data_ptr(),
+                                                _stream()), "mcl_bn_act_maxpool_fwd")
+        ctx.save_for_backward(x, idx, mean, rstd)
+        ctx.params = (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, idx, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        B, C, H, W = x.shape
+        dy = dy.contiguous(memory_format=CL)
+        g = torch.empty_like(x, memory_format=CL)           # un-pooled gradient (gather, deterministic)
+        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd(idx.data_ptr(), dy.data_ptr(), g.data_ptr(), B, H, W, C, _stream()),
+              "mcl_maxpool bwd")
+        direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
+        dg, db = bn_act_bwd(g, x, gamma, beta, mean, rstd, True, g, False, into_param_grads=direct)   # dx in place of g
+        return g, dg, db, None, None
+
+
+USE_FUSED_STEM_TAIL = os.environ.get("MCL_FUSED_STEM_TAIL", "1") != "0"
+
+
+def _stem_tail_ok(x: Tensor) -> bool:
+    return USE_FUSED_STEM_TAIL and _pool_ok(x, False) and x.shape[1] <= 2048
+
+
 def max_pool_3s2(x: Tensor) -> Tensor:
     return MaxPool3s2Fn.apply(x) if _pool_ok(x, False) else F.max_pool2d(x, 3, 2, 1)
 
@@ -782,8 +819,16 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
     x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                  padding=features.conv0.padding)
-    x = _bn_train(x, features.norm0, True, rec)
-    x = max_pool_3s2(x.contiguous(memory_format=CL))
+    x = x.contiguous(memory_format=CL)
+    if _stem_tail_ok(x):
+        C0 = x.shape[1]
+        mean0, var0, rstd0 = (torch.empty(C0, device=x.device, dtype=torch.float32) for _ in range(3))
+        bn_stats(x, mean0, var0, rstd0, features.norm0.eps)
+        rec.add(features.norm0, mean0, var0, x.numel() // C0)
+        x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, mean0, rstd0)
+    else:
+        x = _bn_train(x, features.norm0, True, rec)
+        x = max_pool_3s2(x.contiguous(memory_format=CL))
     i = 1
     out = None
     next_stats = None
@@ -839,7 +884,12 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
     x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
     x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                  padding=features.conv0.padding)
-    x = max_pool_3s2(affine(x, features.norm0, True))
+    x = x.contiguous(memory_format=CL)
+    if _stem_tail_ok(x):
+        x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, features.norm0.running_mean,
+                             rs[id(features.norm0)])
+    else:
+        x = max_pool_3s2(affine(x, features.norm0, True))
     i = 1
     out = None
     while hasattr(features, f"denseblock{i}"):

@@ -545,3 +545,37 @@ def test_transition_fn_matches_module(B, C, H, W, layers):
     assert_close_scaled(gamma.grad.cpu(), g64.grad.cpu(), 5e-3, what="dgamma")
     assert_close_scaled(beta.grad.cpu(), b64.grad.cpu(), 5e-3, what="dbeta")
     assert_close_scaled(w.grad.cpu(), w64.grad.cpu(), 5e-3, what="dW")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 112, 112), (3, 64, 17, 9), (1, 8, 6, 10), (2, 128, 48, 48)])
+def test_stem_tail_kernels(B, C, H, W):
+    """norm0 -> relu0 -> pool0 in one pass (forward) and BatchNorm backward with the max-pool gradient gathered on the
+    fly (backward) against fp64 autograd of max_pool2d(relu(batch_norm_train(x)), 3, 2, 1) on the same bf16 data."""
+    import torch.nn.functional as F
+    from mclstexp_amd import densenet_fused as dn
+    g = torch.Generator().manual_seed(C * H + W)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.3 + 0.2).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    gamma = torch.nn.Parameter((torch.rand(C, generator=g) + 0.5).to(DEV))
+    beta = torch.nn.Parameter((torch.rand(C, generator=g) - 0.5).to(DEV))
+    mean, var, rstd = (torch.empty(C, device=DEV) for _ in range(3))
+    dn.bn_stats(x, mean, var, rstd, 1e-5)
+    xs = x.clone().requires_grad_(True)
+    y = dn.StemTailFn.apply(xs, gamma, beta, mean, rstd)
+    # reference: the same op order in fp32 on the bf16 data (ties in the max are decided on fp32 values in both)
+    x32 = x.float().requires_grad_(True)
+    g32, b32 = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    a = torch.relu(F.batch_norm(x32, None, None, g32, b32, True, 0.1, 1e-5))
+    ref = F.max_pool2d(a, 3, 2, 1)
+    assert y.shape == ref.shape
+    assert_close(y.detach().float().cpu(), ref.detach().cpu(), 1e-2, 8e-3, what="maxpool(relu(bn(x)))")
+    dy = (torch.rand(ref.shape, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    ref.backward(dy.float())
+    assert_close_scaled(gamma.grad.cpu(), g32.grad.cpu(), 3e-3, what="dgamma")
+    assert_close_scaled(beta.grad.cpu(), b32.grad.cpu(), 3e-3, what="dbeta")
+    # dx: a different arg-max among near-equal window elements moves single entries; compare in aggregate
+    d = (xs.grad.float() - x32.grad).abs()
+    assert (d > 2e-2 * x32.grad.abs().max()).float().mean().item() < 2e-3
+    # BatchNorm's dx sums to ~0 per channel; what is left is bf16 rounding of the S = B*H*W stored entries
+    tol = 4.0 * (B * H * W) ** 0.5 * 2.0 ** -9 * x32.grad.abs().max().item() + 1e-3
+    assert (xs.grad.float().sum(dim=(0, 2, 3)) - x32.grad.sum(dim=(0, 2, 3))).abs().max().item() <= tol
