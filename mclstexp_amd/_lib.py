@@ -16,7 +16,7 @@ from typing import Optional
 import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmclstexp_hip.so")
+LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
 ABI_VERSION = 1
 
 _lib: Optional[C.CDLL] = None

@@ -323,6 +323,11 @@ constexpr int C3_IN = 128, C3_OUT = 32, T3 = 128;   // channels in / out, pixels
 // Stage slab rows [0, nrow) of 256 B (pixel p0 - (W+1) + j) with BN+ReLU, 16 rows per pass over the workgroup, in
 // batches of NB independent global loads per thread (a load -> transform -> store loop would serialise one full
 // memory latency per pass: the slab is 10-16 passes).
+// independent global loads in flight per thread and batch (measured at cfg2: 8 beats 4 by 2 %, 16 loses 3 %)
+#ifndef MCL_SLAB_NB
+#define MCL_SLAB_NB 8
+#endif
+constexpr int SLAB_NB = MCL_SLAB_NB;
 template <int NB>
 __device__ __forceinline__ void stage_slab(unsigned char* lds, const bf16_t* __restrict__ z, int p0, long long S,
                                            int W, int nrow, int tid, const float (&sc)[8], const float (&sh)[8]) {
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
   __syncthreads();   // the previous tile's epilogue scratch is dead
 
   // ---- stage the slab with BN+ReLU: thread owns chunk column tid & 15 (8 channels) of rows (tid >> 4) + 16*i
-  stage_slab<4>(lds, z, p0, S, W, nrow, tid, sc, sh);
+  stage_slab<SLAB_NB>(lds, z, p0, S, W, nrow, tid, sc, sh);
   if (tid < 16) *reinterpret_cast<uint4*>(zero_row + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
   // per pixel block mb: slab row of tap (0,0) and the 9-bit tap validity of this lane's pixel
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_kernel(const bf16_t* __res
     const int p0 = tile * T3;
     __syncthreads();   // previous tile fully consumed
     // ---- stage: z slab with BN+ReLU, dy tile, validity masks
-    stage_slab<4>(lds, z, p0, S, W, nrow, tid, sc, sh);
+    stage_slab<SLAB_NB>(lds, z, p0, S, W, nrow, tid, sc, sh);
     {
       const int r = tid >> 1, c2 = tid & 1;              // 128 pixels x 4 chunks: two chunks per thread
       const int p = p0 + r;
