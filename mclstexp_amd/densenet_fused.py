@@ -323,6 +323,17 @@ def dense_conv3x3_wrw(dy: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor,
     return True
 
 
+def _wrw3_direct_ok(w_param: Tensor, z: Tensor, dy: Tensor) -> bool:
+    """dense_conv3x3_wrw's precondition (it accumulates straight into w_param.grad)."""
+    return (USE_FUSED_3X3 and DIRECT_PARAM_GRADS and _direct_grad_ok(w_param)
+            and w_param.grad.permute(0, 2, 3, 1).is_contiguous() and tuple(w_param.shape) == (32, 128, 3, 3)
+            and dy.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and z.is_contiguous(memory_format=CL))
+
+
+# "block": one fork per layer, one join per dense block; "layer": fork + join per layer (first version)
+SIDE_MODE = os.environ.get("MCL_SIDE_MODE", "block")
+
+
 def _fused_3x3_ok(z: Tensor, w16: Tensor) -> bool:
     return (USE_FUSED_3X3 and z.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16
             and tuple(w16.shape) == (32, 128, 3, 3) and w16.permute(0, 2, 3, 1).is_contiguous()
@@ -438,6 +449,24 @@ def _side_stream(device) -> torch.cuda.Stream:
     return s
 
 
+# Deferred joins of the side stream.  Every cross-stream edge of the captured graph costs the WAITING stream ~16 us
+# (tools/trace_gaps.py), so the main chain never waits per kernel: side work is forked off with an event, the tensors
+# it reads are parked here (so that the allocator cannot hand their memory out again), and the main stream joins
+# once per dense block / at the stem.
+_side_parked: dict = {}
+
+
+def _side_park(device, *tensors) -> None:
+    _side_parked.setdefault(device.index, []).extend(tensors)
+
+
+def _side_join(device) -> None:
+    parked = _side_parked.get(device.index)
+    if parked:
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+        parked.clear()
+
+
 class DenseBlockFn(torch.autograd.Function):
     """A whole torchvision ``_DenseBlock`` (forward AND hand-scheduled backward).
 
@@ -522,6 +551,27 @@ class DenseBlockFn(torch.autograd.Function):
             fused1 = a.numel() == 0 and USE_FUSED_BN1_BWD
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
+            if side is not None and SIDE_MODE == "block" and _wrw3_direct_ok(w2, z, dy_view):
+                # Main chain first, ONE fork per layer, ONE join per block.  Every cross-stream edge of the captured graph
+                # costs the waiting side ~16 us (tools/trace_gaps.py): the per-layer fork + join of the first version
+                # left the GPU idle for 2.4 ms/step.  Here the critical chain (conv3x3_bwd -> bn2_dz -> bn1_bwd) never
+                # waits: the two atomics-bound weight-gradient kernels of the layer start on the side stream once dz
+                # exists (event) and are joined only at the end of the block; dz stays referenced until then.
+                d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
+                dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                         gbuf[:, :cin], into_param_grads=d1)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
+                    gw1 = conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
+                _side_park(z.device, dz, gbuf, z, buf)
+                grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None]
+                continue
+            main = torch.cuda.current_stream()
+            side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
             if fused2:
                 # fused forward: a2 = relu(bn2(z)) was never stored.  Both kernels read dy in place from the gradient
                 # buffer (row stride C_total): no contiguous copy, no MIOpen call
@@ -568,6 +618,7 @@ class DenseBlockFn(torch.autograd.Function):
                                       stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
             gw1 = dw1[1] if isinstance(dw1, tuple) else _wgrad(w1, dw1)
             grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None if dw2_done else _wgrad(w2, dw2)]
+        _side_join(buf.device)
         return (gbuf[:, :C0], None, *grads)
 
 
@@ -783,13 +834,11 @@ class TransitionFn(torch.autograd.Function):
         Co = w16.shape[0]
         _rows(dy)                                             # channels-last (possibly channel-sliced) view
         main = torch.cuda.current_stream()
-        side = _side_stream(buf.device) if USE_SIDE_STREAM else None
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dw = conv1x1_wrw(dy, p, w)                    # dW += dy^T p, straight into w.grad when it exists
-        else:
-            dw = conv1x1_wrw(dy, p, w)
+        deferred = (USE_SIDE_STREAM and SIDE_MODE == "block" and DIRECT_PARAM_GRADS and _direct_grad_ok(w)
+                    and w.grad.is_contiguous())
+        if deferred:
+            ev = torch.cuda.Event()
+            ev.record(main)                                   # dy is final
         dp = torch.mm(_as2d(dy), w16.view(Co, C))             # (S/4, C): plain library GEMM (hipBLASLt)
         dx = torch.empty_like(buf, memory_format=CL)
         direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
@@ -804,8 +853,16 @@ class TransitionFn(torch.autograd.Function):
                                        beta.data_ptr(), stats.mean.data_ptr(), stats.rstd.data_ptr(), ws.data_ptr(),
                                        dg.data_ptr(), db.data_ptr(), int(direct), dx.data_ptr(), C, _stream()),
               "mcl_bn_act_avgpool_bwd")
-        if side is not None:
-            main.wait_stream(side)
+        if deferred:
+            # weight gradient (atomics-bound, needs only dy and p) on the side stream; joined by the dense block that
+            # follows in the backward order
+            side = _side_stream(buf.device)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                dw = conv1x1_wrw(dy, p, w)
+            _side_park(buf.device, dy, p)
+        else:
+            dw = conv1x1_wrw(dy, p, w)                        # dW += dy^T p, straight into w.grad when it exists
         gw = None if dw is None else dw.view_as(w).to(w.dtype)
         return dx, (None if direct else dg), (None if direct else db), gw, None
 
