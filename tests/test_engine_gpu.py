@@ -38,11 +38,19 @@ def test_graph_replay_equals_eager_identity_encoder():
 
 
 def test_graph_replay_with_densenet_backbone_fp32():
-    le, pe, _ = _run(False, "densenet121", steps=6, B=4, hw=64)
-    lg, pg, tr = _run(True, "densenet121", steps=6, B=4, hw=64)
+    # MIOpen's default fp32 solvers alternate between calls and use atomics (tools/diag_direct.py): a 6-step
+    # trajectory of this chaotic random-init net then diverges by percents between ANY two runs.  With its
+    # deterministic solvers the eager and the replayed trajectories must agree closely.
+    det = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    try:
+        le, pe, _ = _run(False, "densenet121", steps=6, B=4, hw=64)
+        lg, pg, tr = _run(True, "densenet121", steps=6, B=4, hw=64)
+    finally:
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = det
     assert tr.ga is not None
     for a, b in zip(le, lg):
-        assert abs(a - b) < 2e-2 * max(1.0, abs(a)), (le, lg)   # MIOpen weight-gradient atomics: not bit-exact
+        assert abs(a - b) < 2e-2 * max(1.0, abs(a)), (le, lg)
     # untouched table rows decay identically; touched rows and heads follow the same trajectory
     assert torch.allclose(pe["x_embed.weight"][60000], pg["x_embed.weight"][60000])
 
