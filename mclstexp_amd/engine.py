@@ -7,6 +7,7 @@ per step on the host -- as long as the GPU work itself.  Capturing removes the h
 
 Structure (identical for 1 GPU and for data parallel, so RCCL collectives are never inside a capture):
 
+  (one process without collectives: ONE graph = A + the InfoNCE kernels + B; the split below is the data-parallel form)
     graph A   forward up to the (B, P) embeddings            [model.embed]
     eager     symmetric InfoNCE fwd+bwd (+ 2 all-gathers)     [model.loss_and_grads]  -> loss, dE
     graph B   zero_grad + backward from the embeddings        [torch.autograd.backward captured]
@@ -19,6 +20,7 @@ last batch, train.py:49 has no drop_last) falls back to the eager path.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -27,14 +29,19 @@ Tensor = torch.Tensor
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, reducer=None, graphs: bool = True, warmup: int = 3):
+    def __init__(self, model, optimizer, reducer=None, graphs: bool = True, warmup: int = 3,
+                 single_graph: Optional[bool] = None):
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.graphs = graphs and torch.cuda.is_available()
         self.warmup = max(2, warmup)
         self.calls = 0
         self.static_in: Optional[Dict[str, Tensor]] = None
         self.ga = self.gb = None
-        self.es = self.ei = self.d_es = self.d_ei = None
+        self.es = self.ei = self.d_es = self.d_ei = self.loss = None
+        can_single = reducer is None and getattr(model, "process_group", None) is None
+        if single_graph is None:
+            single_graph = os.environ.get("MCL_SINGLE_GRAPH", "1") != "0"
+        self.single_graph = bool(single_graph) and can_single
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
@@ -65,6 +72,19 @@ class TrainStep:
         # capture_error_mode "thread_local": under data parallelism the RCCL watchdog thread polls events while we
         # capture; in the default "global" mode any such call from another thread invalidates the capture
         self.ga = torch.cuda.CUDAGraph()
+        if self.single_graph:
+            # one process, no collectives: forward, InfoNCE (closed-form forward + backward) and backward replay as ONE
+            # graph -- no host round trip between the three phases (the eager InfoNCE launches left the GPU idle
+            # while the second graph was being submitted)
+            with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
+                self.es, self.ei = m.embed(self.static_in)
+                self.loss, d_es, d_ei = m.loss_and_grads(self.es, self.ei)
+                self.opt.zero_grad()
+                torch.autograd.backward((self.es, self.ei), (d_es, d_ei))
+            if getattr(m, "embedding_grad", "dense") == "rowsparse":
+                m.sparse_grads["static"] = True
+            torch.cuda.synchronize()
+            return
         with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
             self.es, self.ei = m.embed(self.static_in)
         self.d_es = torch.zeros_like(self.es)
@@ -98,6 +118,9 @@ class TrainStep:
         for k, v in self.static_in.items():
             v.copy_(batch[k], non_blocking=True)
         self.ga.replay()
+        if self.single_graph:
+            self._reduce_and_step()
+            return self.loss.clone()
         loss, d_es, d_ei = self.model.loss_and_grads(self.es, self.ei)
         self.d_es.copy_(d_es)
         self.d_ei.copy_(d_ei)

@@ -6,7 +6,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run(graphs, encoder, steps=7, B=8, G=171, hw=64):
+def _run(graphs, encoder, steps=7, B=8, G=171, hw=64, single_graph=None):
     from mclstexp_amd import densenet_fused as dn, synth
     from mclstexp_amd.engine import TrainStep
     from mclstexp_amd.model import mclSTExp_Attention
@@ -18,7 +18,7 @@ def _run(graphs, encoder, steps=7, B=8, G=171, hw=64):
     m.load_state_dict(sd)
     m.to(DEV).train()
     opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
-    tr = TrainStep(m, opt, None, graphs=graphs, warmup=2)
+    tr = TrainStep(m, opt, None, graphs=graphs, warmup=2, single_graph=single_graph)
     losses = []
     for s in range(steps):
         kw = dict(image_dim=1024) if encoder == "identity" else dict(image_hw=hw)
@@ -28,10 +28,13 @@ def _run(graphs, encoder, steps=7, B=8, G=171, hw=64):
     return losses, {n: p.detach().clone() for n, p in m.named_parameters()}, tr
 
 
-def test_graph_replay_equals_eager_identity_encoder():
+@pytest.mark.parametrize("single_graph", [True, False])
+def test_graph_replay_equals_eager_identity_encoder(single_graph):
+    """single_graph: forward + InfoNCE + backward as one graph (one process); False: the two-graph form that data
+    parallelism uses (collectives between the graphs)."""
     le, pe, _ = _run(False, "identity")
-    lg, pg, tr = _run(True, "identity")
-    assert tr.ga is not None and tr.gb is not None          # really captured
+    lg, pg, tr = _run(True, "identity", single_graph=single_graph)
+    assert tr.ga is not None and (tr.gb is None) == single_graph          # really captured, in the requested form
     assert le == lg, (le, lg)                               # deterministic kernels: bit-identical
     for n in pe:
         assert torch.equal(pe[n], pg[n]), n
