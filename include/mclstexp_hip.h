@@ -279,6 +279,14 @@ int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* x, int64_t 
                            int32_t C, const float* gamma, const float* beta, const float* mean, const float* rstd,
                            float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx,
                            int64_t lddx, mcl_stream_t stream);
+/* DenseNet stem convolution conv0 (7x7, stride 2, pad 3, 3 -> 64; torchvision densenet121.features.conv0) with the
+ * batch statistics of its output for norm0:  x (N,H,W,3) bf16 NHWC contiguous, Wt (64,7,7,3) bf16 (a channels-last
+ * (64,3,7,7) weight), y (N,H/2,W/2,64) bf16 NHWC; mean/var (biased)/rstd of the bf16-rounded y (all three NULL:
+ * none).  H % 4 == 0, W % 8 == 0, W <= 256.  workspace: mcl_conv0_workspace_floats(N, H, W) floats.            */
+int64_t mcl_conv0_workspace_floats(int32_t N, int32_t H, int32_t W);
+int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, const void* Wt, void* y, float* workspace, float eps,
+                  float* mean, float* var, float* rstd, mcl_stream_t stream);
+
 /* DenseNet stem tail norm0 -> relu0 -> pool0 (MaxPool2d(3, 2, 1)) in one pass over the conv0 output x (N,H,W,C) bf16
  * NHWC contiguous: y (N,OH,OW,C) = maxpool(relu(bn(x))), idx = arg-max byte per pooled element (ky*3+kx, first maximum
  * in window order).  Backward: mcl_maxpool3s2_nhwc_bf16_bwd(idx, dy) followed by mcl_bn_act_bwd(relu = 1) on x

@@ -91,6 +91,8 @@ PROTOTYPES = {
     "mcl_bn_act_avgpool_fwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "mcl_bn_act_avgpool_bwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,
                                c_p],
+    "mcl_conv0_workspace_floats": [c_i, c_i, c_i],
+    "mcl_conv0_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_bn_act_maxpool_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_l2_normalize_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mcl_topk_rows_max_k": [],
@@ -100,7 +102,7 @@ PROTOTYPES = {
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64,
-             "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64}
+             "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

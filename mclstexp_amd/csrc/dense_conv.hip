@@ -710,3 +710,174 @@ extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
+
+// =====================================================================================================================
+// DenseNet stem convolution conv0: 7x7, stride 2, pad 3, 3 -> 64 channels (torchvision densenet121.features.conv0;
+// /root/reference/model.py:75-76), with the batch statistics norm0 needs from its epilogue.
+//
+//     y[n, oy, ox, co] = sum_{ky, kx, c} x[n, 2 oy - 3 + ky, 2 ox - 3 + kx, c] * W[co][ky][kx][c]
+//
+// Implicit GEMM M = pixels, N = 64, K = 7 x 24 (per ky the 7*3 = 21 contiguous NHWC input values padded to 24: every
+// 8-value K chunk then is a contiguous run of one input row, 4-byte aligned, and the 3 pad weights are zero).  A
+// workgroup owns two output rows of one image (<= 256 pixels): the 9 input rows they touch are staged once into a
+// zero-padded LDS slab (the input is read from HBM ~once: 38 MB at 128 x 224^2), A fragments are 4 ds_read_b32 from
+// the slab, the 22 weight fragments live in registers for the whole launch.  HBM-bound on the 205 MB output; MIOpen's
+// split-K igemm needs a zero-fill pass (71 us) + 199 us, and a separate statistics pass (40 us) follows it.
+namespace {
+
+constexpr int C0_OUT = 64, C0_K = 7, C0_KP = 24;        // output channels, kernel size, padded (kx, c) run
+constexpr int C0_CHUNKS = 22;                            // 7 * 3 chunks of 8 + one zero chunk -> 11 k-steps of 16
+
+__global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
+                                                           const bf16_t* __restrict__ Wt, bf16_t* __restrict__ y,
+                                                           float2* __restrict__ partial, int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int OH = H >> 1, OW = W >> 1;
+  const int PW = (W + 6) * 3 + 8;                        // slab row pitch in elements (even)
+  const int npix = 2 * OW;                               // pixels per tile
+  bf16_t* slab = reinterpret_cast<bf16_t*>(lds);         // [9][PW]
+  const int slab_bytes = (9 * PW * 2 + 15) & ~15;
+  bf16_t* ot = reinterpret_cast<bf16_t*>(lds + slab_bytes);                  // [256][64] bf16
+  float* red = reinterpret_cast<float*>(lds + slab_bytes + 256 * 128);       // [4 waves][64][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  // weight fragments: B[k][n], lane supplies n = nt*32 + l31, k chunk q = 2*s + h -> (ky = q/3, j0 = 8*(q%3))
+  bf16x8 breg[2][11];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+      const int q = 2 * s + h, ky = q / 3, j0 = (q % 3) * 8;
+      const int co = nt * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = j0 + i;
+        breg[nt][s][i] = (q < 21 && j < 21) ? (short)Wt[(co * C0_K + ky) * 21 + j] : (short)0;
+      }
+    }
+  const int nmt = (npix + 31) >> 5;
+
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int n = tile / (OH >> 1), oy0 = (tile % (OH >> 1)) * 2;
+    __syncthreads();                                     // previous tile's output staging is done with LDS
+    for (int i = tid; i < slab_bytes / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // 9 input rows iy = 2*oy0 - 3 + r, each W*3 bf16 = W*6/16 chunks of 16 B; data of pixel ix sits at element 9 + 3*ix
+    const int cpr = (W * 6) >> 4;
+    for (int c = tid; c < 9 * cpr; c += 256) {
+      const int r = c / cpr, cc = c % cpr;
+      const int iy = 2 * oy0 - 3 + r;
+      if (iy >= 0 && iy < H) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + ((long long)(n * H + iy) * W) * 3 + cc * 8);
+        bf16_t* d = slab + r * PW + 9 + cc * 8;          // odd element offset: 2-byte stores
+        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[2 * i] = (bf16_t)(wv[i] & 0xFFFFu);
+          d[2 * i + 1] = (bf16_t)(wv[i] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    for (int mt = wave; mt < nmt; mt += 4) {
+      int m = mt * 32 + l31;
+      const bool mvalid = m < npix;
+      if (!mvalid) m = npix - 1;
+      const int rr = m / OW, ox = m - rr * OW;
+      const unsigned* arow = reinterpret_cast<const unsigned*>(slab + (2 * rr) * PW + 6 * ox);   // 4-byte aligned
+      f32x16 acc[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 11; ++s) {
+        const int q = 2 * s + h, ky = q / 3, j0 = (q % 3) * 8;
+        const unsigned* ap = arow + ((ky * PW + j0) >> 1);
+        u32x4 av;
+        av[0] = ap[0]; av[1] = ap[1]; av[2] = ap[2]; av[3] = ap[3];
+        if (q >= 21) av = (u32x4){0u, 0u, 0u, 0u};
+        const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, breg[nt][s], acc[nt], 0, 0, 0);
+      }
+      // acc[nt][r]: pixel mt*32 + (r&3) + 8*(r>>2) + 4*h, channel nt*32 + l31
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int px = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = round_bf16(acc[nt][r]);
+          if (px < npix) {
+            s1[nt] += v;
+            s2[nt] = fmaf(v, v, s2[nt]);
+            ot[px * C0_OUT + nt * 32 + l31] = (bf16_t)(__float_as_uint(v) >> 16);
+          }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      s1[nt] += __shfl_xor(s1[nt], 32, 64);
+      s2[nt] += __shfl_xor(s2[nt], 32, 64);
+      if (h == 0) {
+        red[(wave * 64 + nt * 32 + l31) * 2] = s1[nt];
+        red[(wave * 64 + nt * 32 + l31) * 2 + 1] = s2[nt];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += red[(w * 64 + tid) * 2];
+        b += red[(w * 64 + tid) * 2 + 1];
+      }
+      const float nn = (float)npix;
+      partial[(long long)tid * ntile + tile] = make_float2(a, b - a * a / nn);       // (sum, M2) of the tile
+    }
+    // the tile's pixels are contiguous in y: npix rows of 128 bytes
+    bf16_t* yo = y + ((long long)(n * OH + oy0) * OW) * C0_OUT;
+    for (int c = tid; c < npix * 8; c += 256)
+      reinterpret_cast<uint4*>(yo)[c] = reinterpret_cast<const uint4*>(ot)[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t mcl_conv0_workspace_floats(int32_t N, int32_t H, int32_t W) {
+  if (N <= 0 || H <= 0 || W <= 0) return -1;
+  return (int64_t)N * (H / 4 + 1) * C0_OUT * 2;
+}
+
+extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, const void* Wt, void* y, float* workspace,
+                             float eps, float* mean, float* var, float* rstd, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!x || !Wt || !y || !workspace || N <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
+  const bool want_stats = mean || var || rstd;
+  if (want_stats && (!mean || !var || !rstd)) return MCL_EINVAL;
+  // two output rows per workgroup, whole 16-byte input chunks per row
+  if ((H % 4) || (W % 8) || W > 256 || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(y) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int OH = H / 2, OW = W / 2;
+  const int ntile = N * (OH / 2);
+  const int PW = (W + 6) * 3 + 8;
+  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + 256 * 128 + 4 * 64 * 2 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  hipStream_t st = mcl_stream(stream);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(conv0_fwd_kernel, dim3(ntile < 1024 ? ntile : 1024), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H,
+                     W, (const bf16_t*)Wt, (bf16_t*)y, part, ntile);
+  if (want_stats)
+    hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(C0_OUT), dim3(256), 0, st, (const float2*)part, ntile, C0_OUT,
+                       (long long)N * OH * OW, 2 * OW, eps, mean, var, rstd);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

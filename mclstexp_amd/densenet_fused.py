@@ -659,6 +659,52 @@ def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats, stats: Optional[_
     return buf, stats
 
 
+# --------------------------------------------------------------------------- stem convolution (csrc/dense_conv.hip)
+USE_HIP_CONV0 = os.environ.get("MCL_HIP_CONV0", "1") != "0"
+
+
+def _conv0_ok(x: Tensor, conv: nn.Conv2d) -> bool:
+    B, C, H, W = x.shape
+    return (USE_HIP_CONV0 and x.is_cuda and x.dtype == torch.bfloat16 and C == 3 and H % 4 == 0 and W % 8 == 0
+            and W <= 256 and x.is_contiguous(memory_format=CL) and tuple(conv.weight.shape) == (64, 3, 7, 7)
+            and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.bias is None and not x.requires_grad)
+
+
+def conv0_fwd(x: Tensor, w16: Tensor, eps: float, stats: Optional[Tuple[Tensor, Tensor, Tensor]]) -> Tensor:
+    """y = conv2d(x, w16, stride 2, padding 3) for the 7x7 stem convolution, bf16 NHWC, and (``stats`` = (mean, var,
+    rstd) tensors of 64 floats, or None) the batch statistics of y for norm0 from the kernel's epilogue."""
+    B, _, H, W = x.shape
+    y = torch.empty((B, 64, H // 2, W // 2), device=x.device, dtype=torch.bfloat16, memory_format=CL)
+    L = _lib.lib()
+    ws = _ws(L.mcl_conv0_workspace_floats(B, H, W), x.device)
+    st = (None, None, None) if stats is None else tuple(t.data_ptr() for t in stats)
+    check(L.mcl_conv0_fwd(x.data_ptr(), B, H, W, w16.data_ptr(), y.data_ptr(), ws.data_ptr(), eps, *st, _stream()),
+          "mcl_conv0_fwd")
+    return y
+
+
+class Conv0Fn(torch.autograd.Function):
+    """The stem convolution on the hand-written kernel; meta = (eps, (mean, var, rstd)) receives norm0's batch
+    statistics.  Backward: weight gradient only (the image does not require a gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, meta):
+        eps, stats = meta
+        w16 = _weight(w, x.dtype)
+        y = conv0_fwd(x, w16, eps, stats)
+        ctx.save_for_backward(x, w16)
+        ctx.w = w
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=CL)
+        dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                 [False, True, False])[1]
+        return None, _wgrad(ctx.w, dw), None
+
+
 # --------------------------------------------------------------------------- pooling (csrc/pool.hip)
 USE_HIP_POOLS = os.environ.get("MCL_HIP_POOLS", "1") != "0"
 
@@ -874,13 +920,19 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
         raise RuntimeError("densenet_features_fused: input is on the CPU; the fused backbone path is GPU-only")
     rec = _RunningStats()
     x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
-    x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
-                 padding=features.conv0.padding)
+    own_conv0 = _conv0_ok(x, features.conv0)
+    if own_conv0:
+        mean0, var0, rstd0 = (torch.empty(64, device=x.device, dtype=torch.float32) for _ in range(3))
+        x = Conv0Fn.apply(x, features.conv0.weight, (features.norm0.eps, (mean0, var0, rstd0)))
+    else:
+        x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
+                     padding=features.conv0.padding)
     x = x.contiguous(memory_format=CL)
     if _stem_tail_ok(x):
         C0 = x.shape[1]
-        mean0, var0, rstd0 = (torch.empty(C0, device=x.device, dtype=torch.float32) for _ in range(3))
-        bn_stats(x, mean0, var0, rstd0, features.norm0.eps)
+        if not own_conv0:
+            mean0, var0, rstd0 = (torch.empty(C0, device=x.device, dtype=torch.float32) for _ in range(3))
+            bn_stats(x, mean0, var0, rstd0, features.norm0.eps)
         rec.add(features.norm0, mean0, var0, x.numel() // C0)
         x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, mean0, rstd0)
     else:
@@ -939,8 +991,11 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
         return out
 
     x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
-    x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
-                 padding=features.conv0.padding)
+    if _conv0_ok(x, features.conv0):
+        x = conv0_fwd(x, _weight(features.conv0.weight, act_dtype), features.norm0.eps, None)
+    else:
+        x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
+                     padding=features.conv0.padding)
     x = x.contiguous(memory_format=CL)
     if _stem_tail_ok(x):
         x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, features.norm0.running_mean,

@@ -579,3 +579,25 @@ def test_stem_tail_kernels(B, C, H, W):
     # BatchNorm's dx sums to ~0 per channel; what is left is bf16 rounding of the S = B*H*W stored entries
     tol = 4.0 * (B * H * W) ** 0.5 * 2.0 ** -9 * x32.grad.abs().max().item() + 1e-3
     assert (xs.grad.float().sum(dim=(0, 2, 3)) - x32.grad.sum(dim=(0, 2, 3))).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 224, 224), (3, 96, 96), (1, 256, 256), (2, 64, 72), (5, 4, 8)])
+def test_conv0_kernel(B, H, W):
+    """csrc/dense_conv.hip conv0_fwd_kernel (7x7 stride 2 pad 3, 3 -> 64, bf16 NHWC) and its norm0 statistics against
+    fp64 conv2d on the same bf16-rounded data."""
+    import torch.nn.functional as F
+    from mclstexp_amd import densenet_fused as dn
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.rand(B, 3, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, generator=g) * 0.1).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    mean, var, rstd = (torch.empty(64, device=DEV) for _ in range(3))
+    y = dn.conv0_fwd(x, w, 1e-5, (mean, var, rstd))
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert_close_scaled(y.float().cpu(), ref.cpu(), 6e-3, what="conv0")
+    yd = y.double()
+    assert_close(mean.cpu(), yd.mean(dim=(0, 2, 3)).cpu(), 1e-4, 1e-3, what="mean of the stored output")
+    assert_close(var.cpu(), yd.var(dim=(0, 2, 3), unbiased=False).cpu(), 1e-5, 2e-3, what="var")
+    assert_close(rstd.cpu(), torch.rsqrt(yd.var(dim=(0, 2, 3), unbiased=False) + 1e-5).cpu(), 1e-4, 2e-3, what="rstd")
+    y2 = dn.conv0_fwd(x, w, 1e-5, None)                  # inference form: no statistics
+    assert torch.equal(y2, y)
