@@ -286,6 +286,9 @@ int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* x, int64_t 
 int64_t mcl_conv0_workspace_floats(int32_t N, int32_t H, int32_t W);
 int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, const void* Wt, void* y, float* workspace, float eps,
                   float* mean, float* var, float* rstd, mcl_stream_t stream);
+/* Weight gradient of conv0: dW (64,7,7,3) fp32 (the channels-last parameter's .grad) += sum_p dy[p] (x) patch(x)[p],
+ * ACCUMULATED with float atomics.  dy: (N,H/2,W/2,64) bf16 NHWC contiguous.  H % 4 == 0, W % 32 == 0, W <= 256.  */
+int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* dW, mcl_stream_t stream);
 
 /* DenseNet stem tail norm0 -> relu0 -> pool0 (MaxPool2d(3, 2, 1)) in one pass over the conv0 output x (N,H,W,C) bf16
  * NHWC contiguous: y (N,OH,OW,C) = maxpool(relu(bn(x))), idx = arg-max byte per pooled element (ky*3+kx, first maximum

@@ -93,6 +93,7 @@ PROTOTYPES = {
                                c_p],
     "mcl_conv0_workspace_floats": [c_i, c_i, c_i],
     "mcl_conv0_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
+    "mcl_conv0_wrw": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "mcl_bn_act_maxpool_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_l2_normalize_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mcl_topk_rows_max_k": [],

@@ -845,7 +845,104 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
   }
 }
 
+// Weight gradient of conv0:  dW[co][ky][kx][c] += sum_p dy[p][co] * x[n, 2 oy - 3 + ky, 2 ox - 3 + kx, c]   (fp32 atomics
+// into the channels-last parameter's .grad).  GEMM M = 64 (co), N = 7 x 24 (k, as in the forward), K = pixels.  Same
+// tiles and input slab as the forward; dy is staged TRANSPOSED ([co][pixel]) so that an A fragment (8 consecutive pixels
+// of one channel) is one ds_read_b128; a B fragment (8 consecutive pixels of one k column) is 8 strided 2-byte reads of
+// the slab (12 bytes apart).  Wave w owns co tile w & 1 and k tiles 3 (w >> 1) .. + 2; accumulators persist over the
+// workgroup's tiles.  Needs OW % 16 == 0 (a 16-pixel k-step must not straddle output rows).
+__global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
+                                                           const bf16_t* __restrict__ dy, float* __restrict__ dW,
+                                                           int ntile) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int OH = H >> 1, OW = W >> 1;
+  const int PW = (W + 6) * 3 + 8;
+  const int npix = 2 * OW, PP = npix + 8;
+  bf16_t* slab = reinterpret_cast<bf16_t*>(lds);
+  const int slab_bytes = (9 * PW * 2 + 15) & ~15;
+  bf16_t* dyT = reinterpret_cast<bf16_t*>(lds + slab_bytes);                 // [64][PP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int mt = wave & 1, kt0 = (wave >> 1) * 3;
+  int koff[3];
+  bool kval[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int k = (kt0 + t) * 32 + l31;
+    const int ky = k / C0_KP, j = k % C0_KP;
+    kval[t] = k < 7 * C0_KP && j < 21;
+    koff[t] = kval[t] ? ky * PW + j : 0;
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int n = tile / (OH >> 1), oy0 = (tile % (OH >> 1)) * 2;
+    __syncthreads();
+    for (int i = tid; i < slab_bytes / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // dy tile, transposed: chunk c = (pixel, 8 channels)
+    const bf16_t* dyo = dy + ((long long)(n * OH + oy0) * OW) * C0_OUT;
+    for (int c = tid; c < npix * 8; c += 256) {
+      const int px = c >> 3, c8 = c & 7;
+      const uint4 v = reinterpret_cast<const uint4*>(dyo)[c];
+      const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dyT[(c8 * 8 + 2 * i) * PP + px] = (bf16_t)(wv[i] & 0xFFFFu);
+        dyT[(c8 * 8 + 2 * i + 1) * PP + px] = (bf16_t)(wv[i] >> 16);
+      }
+    }
+    __syncthreads();
+    const int cpr = (W * 6) >> 4;
+    for (int c = tid; c < 9 * cpr; c += 256) {
+      const int r = c / cpr, cc = c % cpr;
+      const int iy = 2 * oy0 - 3 + r;
+      if (iy >= 0 && iy < H) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + ((long long)(n * H + iy) * W) * 3 + cc * 8);
+        bf16_t* d = slab + r * PW + 9 + cc * 8;
+        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          d[2 * i] = (bf16_t)(wv[i] & 0xFFFFu);
+          d[2 * i + 1] = (bf16_t)(wv[i] >> 16);
+        }
+      }
+    }
+    __syncthreads();
+
+    for (int p0 = 0; p0 < npix; p0 += 16) {              // k-step: pixels p0 .. p0 + 15 of one output row
+      const int rr = p0 / OW, ox0 = p0 - rr * OW;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dyT + (mt * 32 + l31) * PP + p0 + 8 * h);
+      const bf16_t* brow = slab + (2 * rr) * PW + 6 * (ox0 + 8 * h);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const bf16_t* bp = brow + koff[t];
+        bf16x8 b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = (short)bp[6 * i];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // acc[t][r]: co = mt*32 + (r&3) + 8*(r>>2) + 4*h, k = (kt0+t)*32 + l31 -> dW[co][ky][j]  ((64, 7, 7*3) fp32)
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    if (!kval[t]) continue;
+    const int k = (kt0 + t) * 32 + l31;
+    const int ky = k / C0_KP, j = k % C0_KP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      unsafeAtomicAdd(dW + (co * C0_K + ky) * 21 + j, acc[t][r]);
+    }
+  }
+}
+
 }  // namespace
+
 
 extern "C" int64_t mcl_conv0_workspace_floats(int32_t N, int32_t H, int32_t W) {
   if (N <= 0 || H <= 0 || W <= 0) return -1;
@@ -878,6 +975,28 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
   if (want_stats)
     hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(C0_OUT), dim3(256), 0, st, (const float2*)part, ntile, C0_OUT,
                        (long long)N * OH * OW, 2 * OW, eps, mean, var, rstd);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* dW,
+                             mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!x || !dy || !dW || N <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
+  if ((H % 4) || (W % 32) || W > 256 || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(dy) & 15u))
+    return MCL_EUNSUPPORTED;                             // W % 32: a 16-pixel k-step stays inside one output row
+  const int OH = H / 2, OW = W / 2;
+  const int ntile = N * (OH / 2);
+  const int PW = (W + 6) * 3 + 8;
+  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + (size_t)C0_OUT * (2 * OW + 8) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wrw_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv0_wrw_kernel, dim3(ntile < 384 ? ntile : 384), dim3(256), lds_bytes, mcl_stream(stream),
+                     (const bf16_t*)x, N, H, W, (const bf16_t*)dy, dW, ntile);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -700,6 +700,13 @@ class Conv0Fn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w16 = ctx.saved_tensors
         dy = dy.contiguous(memory_format=CL)
+        w = ctx.w
+        B, _, H, W = x.shape
+        if (DIRECT_PARAM_GRADS and _direct_grad_ok(w) and w.grad.permute(0, 2, 3, 1).is_contiguous() and W % 32 == 0
+                and dy.dtype == torch.bfloat16):
+            check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), w.grad.data_ptr(), _stream()),
+                  "mcl_conv0_wrw")                       # straight into the parameter's fp32 .grad
+            return None, None, None
         dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                  [False, True, False])[1]
         return None, _wgrad(ctx.w, dw), None

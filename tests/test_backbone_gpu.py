@@ -601,3 +601,20 @@ def test_conv0_kernel(B, H, W):
     assert_close(rstd.cpu(), torch.rsqrt(yd.var(dim=(0, 2, 3), unbiased=False) + 1e-5).cpu(), 1e-4, 2e-3, what="rstd")
     y2 = dn.conv0_fwd(x, w, 1e-5, None)                  # inference form: no statistics
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 224, 224), (3, 96, 96), (1, 256, 256), (2, 64, 64), (4, 4, 32)])
+def test_conv0_wrw_kernel(B, H, W):
+    """conv0 weight gradient (fp32 atomics into a channels-last (64,3,7,7) .grad) against fp64 autograd."""
+    import torch.nn.functional as F
+    from mclstexp_amd import _lib, densenet_fused as dn
+    from mclstexp_amd._lib import check
+    g = torch.Generator().manual_seed(H + W + B)
+    x = torch.rand(B, 3, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    dy = (torch.rand(B, 64, H // 2, W // 2, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(
+        memory_format=torch.channels_last)
+    w64 = torch.zeros(64, 3, 7, 7, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv2d(x.double(), w64, stride=2, padding=3).backward(dy.double())
+    dW = torch.full((64, 3, 7, 7), 0.25, device=DEV).contiguous(memory_format=torch.channels_last)   # accumulates
+    check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), dW.data_ptr(), dn._stream()), "mcl_conv0_wrw")
+    assert_close_scaled((dW - 0.25).cpu(), w64.grad.cpu(), 2e-5, floor=1e-4, what="dW conv0")
