@@ -970,7 +970,9 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
   }
   hipStream_t st = mcl_stream(stream);
   float2* part = reinterpret_cast<float2*>(workspace);
-  hipLaunchKernelGGL(conv0_fwd_kernel, dim3(ntile < 1024 ? ntile : 1024), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H,
+  // persistent: the 22 weight fragments are built once per workgroup; 768 = 3 per CU (47 KB of LDS each); measured
+  // 108 us vs 124 us at 1024 and 212 us with one workgroup per tile (128 x 224^2)
+  hipLaunchKernelGGL(conv0_fwd_kernel, dim3(ntile < 768 ? ntile : 768), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H,
                      W, (const bf16_t*)Wt, (bf16_t*)y, part, ntile);
   if (want_stats)
     hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(C0_OUT), dim3(256), 0, st, (const float2*)part, ntile, C0_OUT,
@@ -995,7 +997,7 @@ extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv0_wrw_kernel, dim3(ntile < 384 ? ntile : 384), dim3(256), lds_bytes, mcl_stream(stream),
+  hipLaunchKernelGGL(conv0_wrw_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, mcl_stream(stream),
                      (const bf16_t*)x, N, H, W, (const bf16_t*)dy, dW, ntile);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
