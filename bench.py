@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE configs[1]: 128)")
     ap.add_argument("--genes", type=int, default=1000)
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--n_batches", type=int, default=16, help="distinct synthetic batches resident in HBM, cycled")
     ap.add_argument("--encoder", type=str, default="densenet121")
     ap.add_argument("--image_dim", type=int, default=1024)
     ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16"],
@@ -153,10 +154,14 @@ def main():
     dist_on = pg is not None            # world > 1, or MCL_FORCE_DIST=1 (size-1 RCCL group: DP code path on one GPU)
     reducer = mdist.GradReducer(pg) if dist_on else None
 
-    # synthetic inputs, resident in HBM before the timed region (4 distinct batches, cycled)
+    # synthetic inputs, resident in HBM before the timed region: args.n_batches distinct batches, cycled (expression /
+    # position from the procedural formula; pixels uniform[0,1) from a seeded device generator -- 19 M values per batch)
     batches = []
-    for s in range(4):
-        b = synth.make_batch(args.batch, args.genes, image_hw=args.image, seed=s, rank=rank)
+    gen = torch.Generator(device=dev)
+    for s in range(args.n_batches):
+        b = synth.make_batch(args.batch, args.genes, seed=s, rank=rank)
+        gen.manual_seed(1234 + 1000 * rank + s)
+        b["image"] = torch.rand((args.batch, 3, args.image, args.image), device=dev, generator=gen)
         b = {k: v.to(dev) for k, v in b.items()}
         if bb is not None:
             b["image"] = b["image"].contiguous(memory_format=torch.channels_last)
