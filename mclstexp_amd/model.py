@@ -257,7 +257,24 @@ class _ContrastiveBase(nn.Module):
         return ops.PosEmbedAddFn.apply(batch["expression"], batch["position"], self.x_embed.weight,
                                        self.y_embed.weight, sink)
 
+    # "infonce": the reference's identity-target symmetric cross entropy (model.py:242-247).  "bleep" / "bleep_vit": the
+    # soft-target CLIP loss of the reference's main baseline (baselines/Bleep/models.py:34-43 / 66-76) on the same
+    # kernels; single process only.
+    loss_kind = "infonce"
+
+    def _soft_clip(self) -> Optional[bool]:
+        if self.loss_kind == "infonce":
+            return None
+        if self.loss_kind not in ("bleep", "bleep_vit"):
+            raise ValueError("loss_kind must be 'infonce', 'bleep' or 'bleep_vit'")
+        if self.process_group is not None:
+            raise RuntimeError("the BLEEP soft-target loss is implemented for a single process only")
+        return self.loss_kind == "bleep_vit"
+
     def _loss(self, spot_embeddings: Tensor, image_embeddings: Tensor) -> Tensor:
+        soft = self._soft_clip()
+        if soft is not None:
+            return ops.SoftClipLossFn.apply(spot_embeddings, image_embeddings, float(self.temperature), soft)
         stash = self.last if self.capture else None
         if self.capture:
             self.last["spot_embeddings"] = spot_embeddings.detach()
@@ -281,6 +298,9 @@ class _ContrastiveBase(nn.Module):
         es, ei = spot_embeddings.detach(), image_embeddings.detach()
         if self.capture:
             self.last["spot_embeddings"], self.last["image_embeddings"] = es, ei
+        soft = self._soft_clip()
+        if soft is not None:
+            return ops.soft_clip_fwd_bwd(es, ei, float(self.temperature), soft)
         fused = self.infonce == "fused"
         if self.process_group is not None:
             from . import dist as mdist

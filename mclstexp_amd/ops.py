@@ -488,3 +488,64 @@ class InfoNCEFn(torch.autograd.Function):
     def backward(ctx, gl):
         d_es, d_ei = ctx.saved_tensors
         return d_es * gl, d_ei * gl, None, None, None
+
+
+# --------------------------------------------------------------------------- BLEEP soft-target CLIP loss (§8 f4)
+def soft_clip_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, targets_times_temperature: bool = False
+                      ) -> Tuple[Tensor, Tensor, Tensor]:
+    """(loss, dE_spot, dE_img) of the reference baseline's soft-target contrastive loss
+    (/root/reference/baselines/Bleep/models.py:34-43, 66-76, 228-234), forward and backward in closed form on the
+    same kernels as the exact InfoNCE path (fp32 MFMA GEMMs, row-softmax, row/column LSE); gradients flow through the
+    soft targets as in the reference.
+
+        S = E_s E_i^T / T,  Tg = softmax_rows(k (E_i E_i^T + E_s E_s^T)/2),  k = 1/T (CLIPModel) or T (CLIPModel_ViT)
+        loss = -(1/2B) sum_ij Tg_ij (logsoftmax_row(S) + logsoftmax_col(S))_ij
+    """
+    es, ei = _rowmajor(e_spot, "spot_embeddings"), _rowmajor(e_img, "image_embeddings")
+    B, P = es.shape
+    assert ei.shape == (B, P)
+    dev = es.device
+    L = _lib.lib()
+    inv_t = 1.0 / temperature
+    k = temperature if targets_times_temperature else inv_t
+    S = torch.empty((B, B), device=dev, dtype=torch.float32)
+    gemm_raw(B, B, P, 1, es, es.stride(0), 1, 0, ei, 1, ei.stride(0), 0, S, B, 0, alpha=inv_t, compute=COMPUTE_F32)
+    Tg = torch.empty((B, B), device=dev, dtype=torch.float32)
+    gemm_raw(B, B, P, 1, ei, ei.stride(0), 1, 0, ei, 1, ei.stride(0), 0, Tg, B, 0, alpha=0.5, compute=COMPUTE_F32)
+    gemm_raw(B, B, P, 1, es, es.stride(0), 1, 0, es, 1, es.stride(0), 0, Tg, B, 0, alpha=0.5, flags=EPI_ACCUM,
+             compute=COMPUTE_F32)
+    check(L.mcl_softmax_rows_fwd(Tg.data_ptr(), B, B, B, k, _stream()), "mcl_softmax_rows_fwd")      # Tg in place
+    lse = torch.empty((2, B), device=dev, dtype=torch.float32)
+    check(L.mcl_infonce_lse(S.data_ptr(), B, B, B, lse[0].data_ptr(), lse[1].data_ptr(), _stream()), "mcl_infonce_lse")
+    ls = S - lse[0][:, None]                                     # log-softmax over rows
+    lc = S - lse[1][None, :]                                     # log-softmax over columns
+    lsum = ls + lc
+    c = 1.0 / (2.0 * B)
+    loss = -(Tg * lsum).sum() * c
+    # backward
+    dS = (torch.exp(ls) + torch.exp(lc) * Tg.sum(0)[None, :] - 2.0 * Tg) * c
+    dA = lsum.mul_(-c)                                           # d loss / d Tg
+    check(L.mcl_softmax_rows_bwd(Tg.data_ptr(), dA.data_ptr(), B, B, B, k, _stream()), "mcl_softmax_rows_bwd")
+    dsym = (dA + dA.t()).mul_(0.5).contiguous()                  # A = (II + SS)/2 and both Gram matrices are symmetric
+    d_es = torch.empty_like(es)
+    d_ei = torch.empty_like(ei)
+    gemm_raw(B, P, B, 1, dS, B, 1, 0, ei, ei.stride(0), 1, 0, d_es, P, 0, alpha=inv_t, compute=COMPUTE_F32)
+    gemm_raw(B, P, B, 1, dsym, B, 1, 0, es, es.stride(0), 1, 0, d_es, P, 0, flags=EPI_ACCUM, compute=COMPUTE_F32)
+    gemm_raw(B, P, B, 1, dS, 1, B, 0, es, es.stride(0), 1, 0, d_ei, P, 0, alpha=inv_t, compute=COMPUTE_F32)
+    gemm_raw(B, P, B, 1, dsym, B, 1, 0, ei, ei.stride(0), 1, 0, d_ei, P, 0, flags=EPI_ACCUM, compute=COMPUTE_F32)
+    return loss, d_es, d_ei
+
+
+class SoftClipLossFn(torch.autograd.Function):
+    """loss = soft-target CLIP loss of (spot_embeddings, image_embeddings); backward from the closed form."""
+
+    @staticmethod
+    def forward(ctx, e_spot, e_img, temperature, targets_times_temperature):
+        loss, d_es, d_ei = soft_clip_fwd_bwd(e_spot.detach(), e_img.detach(), temperature, targets_times_temperature)
+        ctx.save_for_backward(d_es, d_ei)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d_es, d_ei = ctx.saved_tensors
+        return d_es * g, d_ei * g, None, None

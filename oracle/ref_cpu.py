@@ -262,3 +262,18 @@ def train_step(params: Params, state: Dict[str, Tuple[Tensor, Tensor]], batch: D
                 state[n] = (torch.zeros_like(p), torch.zeros_like(p))
             adam_l2_step(p, p.grad, state[n][0], state[n][1], step)
     return float(out["loss"])
+
+
+# --------------------------------------------------------------------------- BLEEP soft-target CLIP loss
+def bleep_soft_clip_loss(e_spot: Tensor, e_img: Tensor, temperature: float, targets_times_temperature: bool = False
+                         ) -> Tensor:
+    """baselines/Bleep/models.py:34-43 (CLIPModel) and :66-76 (CLIPModel_ViT, ``targets_times_temperature``):
+    logits = E_s E_i^T / T; targets = softmax((E_i E_i^T + E_s E_s^T)/2 {/T | *T}); loss = mean of
+    (CE(logits, targets) + CE(logits^T, targets^T)) / 2 with soft targets (cross_entropy, models.py:228-234).
+    The targets are NOT detached: gradients flow through them as in the reference."""
+    logits_ = (e_spot @ e_img.T) / temperature
+    sim = (e_img @ e_img.T + e_spot @ e_spot.T) / 2
+    targets = torch.softmax(sim * temperature if targets_times_temperature else sim / temperature, dim=-1)
+    spots_loss = (-targets * torch.log_softmax(logits_, dim=-1)).sum(1)
+    images_loss = (-targets.T * torch.log_softmax(logits_.T, dim=-1)).sum(1)
+    return ((images_loss + spots_loss) / 2.0).mean()

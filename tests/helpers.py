@@ -90,3 +90,17 @@ def check_topk(indices, sim64, tol=2e-6, values=None, what="topk"):
             assert np.abs(np.asarray(values[i], dtype=np.float64) - got).max() <= tol, f"{what}: row {i} values"
         exact_rows += int(set(order[:k].tolist()) == set(idx.tolist()))
     return exact_rows
+
+
+# --------------------------------------------------------------------------- BLEEP soft-target CLIP loss
+BLEEP_CASES = ["clip_b8", "clip_b33_t07", "vit_b16_t05"]
+
+
+def bleep_embeddings(B, seed):
+    """Procedural (B, 256) spot / image embeddings: LayerNorm-ed, correlated pairs, small norm (so that the soft targets
+    are not saturated)."""
+    es = synth.uniform_tensor("bleep.es", (B, 256), -1.0, 1.0, seed)
+    ei = synth.uniform_tensor("bleep.ei", (B, 256), -1.0, 1.0, seed)
+    ei = 0.6 * es + 0.4 * ei
+    ln = torch.nn.functional.layer_norm
+    return (ln(es, (256,)) * 0.08).contiguous(), (ln(ei, (256,)) * 0.08).contiguous()

@@ -357,3 +357,42 @@ def test_infonce_fused_spike_forces_rescale(ops):
     lse_ref, _, _ = _fused_ref(a, b, 1.0, 0)
     lse, _ = ops.infonce_fused_lse(ops.cast_bf16(a.to(DEV)), ops.cast_bf16(b.to(DEV)), 1.0, 0)
     assert_close(lse.cpu(), lse_ref, 1e-3, rtol=1e-5, what="lse with a late spike")
+
+
+# ------------------------------------------------------------------ BLEEP soft-target CLIP loss
+@pytest.mark.parametrize("name", ["clip_b8", "clip_b33_t07", "vit_b16_t05"])
+def test_soft_clip_loss_against_reference_fixture(ops, name):
+    """ops.soft_clip_fwd_bwd (fp32 MFMA GEMMs + softmax / LSE kernels, closed-form backward through the soft targets)
+    against the loss and autograd gradients of the reference's own code (tests/golden/bleep_loss.npz): 1e-4 absolute
+    on the loss (north_star's bar for loss/logits), gradients 2e-5 of their largest entry."""
+    import os
+    from helpers import GOLDEN_DIR, bleep_embeddings
+    z = np.load(os.path.join(GOLDEN_DIR, "bleep_loss.npz"))
+    B, seed, vit = [int(v) for v in z[name + ".meta"]]
+    es, ei = bleep_embeddings(B, seed)
+    loss, d_es, d_ei = ops.soft_clip_fwd_bwd(es.to(DEV), ei.to(DEV), float(z[name + ".T"]), bool(vit))
+    assert_close(loss.item(), z[name + ".loss"], 1e-4, what="loss (1e-4 abs)")
+    assert_close_scaled(d_es.cpu(), z[name + ".d_es"], 2e-5, what="d_es")
+    assert_close_scaled(d_ei.cpu(), z[name + ".d_ei"], 2e-5, what="d_ei")
+    # autograd wrapper + model hook
+    from mclstexp_amd.model import mclSTExp_MLP
+    a, b = es.to(DEV).requires_grad_(True), ei.to(DEV).requires_grad_(True)
+    (ops.SoftClipLossFn.apply(a, b, float(z[name + ".T"]), bool(vit)) * 2.0).backward()
+    assert_close_scaled(a.grad.cpu(), 2.0 * z[name + ".d_es"], 2e-5, what="autograd d_es")
+    m = mclSTExp_MLP(float(z[name + ".T"]), 1024, 171, 256, encoder_name="identity")
+    m.loss_kind = "bleep_vit" if vit else "bleep"
+    assert abs(m._loss(es.to(DEV), ei.to(DEV)).item() - float(z[name + ".loss"])) < 1e-4
+
+
+def test_soft_clip_loss_large_batch_vs_oracle(ops):
+    from oracle import ref_cpu
+    g = torch.Generator().manual_seed(5)
+    es = torch.nn.functional.layer_norm(torch.randn(1000, 256, generator=g), (256,)) * 0.05
+    ei = (0.5 * es + 0.05 * torch.randn(1000, 256, generator=g)).contiguous()
+    a, b = es.double().requires_grad_(True), ei.double().requires_grad_(True)
+    ref = ref_cpu.bleep_soft_clip_loss(a, b, 0.8)
+    ref.backward()
+    loss, d_es, d_ei = ops.soft_clip_fwd_bwd(es.to(DEV), ei.to(DEV), 0.8)
+    assert_close(loss.item(), ref.item(), 1e-4, what="loss")
+    assert_close_scaled(d_es.cpu(), a.grad, 5e-5, what="d_es")
+    assert_close_scaled(d_ei.cpu(), b.grad, 5e-5, what="d_ei")

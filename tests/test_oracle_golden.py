@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/ref_cpu.py) to fixtures captured from the reference's own
 classes (tests/golden/gen_goldens.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -133,3 +135,21 @@ def test_retrieval_oracle_matches_reference_fixture(name):
                                                   z["indices"], ord=meta["ord"])
     assert_close(emb, z["emb_pred"], 1e-12, 1e-12, what="emb_pred")
     assert_close(expr, z["expr_pred"], 1e-12, 1e-12, what="expr_pred")
+
+
+# --------------------------------------------------------------------------- BLEEP soft-target loss
+from helpers import BLEEP_CASES, bleep_embeddings  # noqa: E402
+
+
+@pytest.mark.parametrize("name", BLEEP_CASES)
+def test_bleep_loss_oracle_matches_reference_fixture(name):
+    """oracle/ref_cpu.bleep_soft_clip_loss against loss and autograd gradients of the reference's own loss section."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bleep_loss.npz"))
+    B, seed, vit = [int(v) for v in z[name + ".meta"]]
+    es, ei = bleep_embeddings(B, seed)
+    es.requires_grad_(True); ei.requires_grad_(True)
+    loss = ref_cpu.bleep_soft_clip_loss(es, ei, float(z[name + ".T"]), bool(vit))
+    loss.backward()
+    assert_close(loss.item(), z[name + ".loss"], 1e-6, what="loss")
+    assert_close(es.grad.numpy(), z[name + ".d_es"], 1e-7, 1e-5, what="d_es")
+    assert_close(ei.grad.numpy(), z[name + ".d_ei"], 1e-7, 1e-5, what="d_ei")
