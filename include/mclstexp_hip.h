@@ -346,6 +346,20 @@ int mcl_knn_weighted_average(const float* spot_key, int64_t ldk, const float* ex
                              int32_t dim, int32_t genes, int32_t ord, float* emb_pred, float* expr_pred,
                              mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- input pipeline on the GPU
+ * mcl_patch_gather: the reference's per-spot patch extraction (dataset.py:226-231 PIL crop + transforms.ToTensor;
+ *   dataset.py:330-336 numpy crop of the cv2 image + TenxDataset.transform) for a whole batch: image_u8 (Hs, Ws, 3)
+ *   uint8 resident in HBM, centers_rc (N, 2) int32 (row, col), patch side 2r.  Source pixels outside the image read 0.
+ *   ops (N bytes, may be NULL): bit 0 horizontal flip, bit 1 vertical flip, bits 2-3 = k: then a counter-clockwise
+ *   rotation by k*90 degrees (TF.hflip -> TF.vflip -> TF.rotate(angle), angle = 90 k).  Values are divided by divisor
+ *   (255: ToTensor's .div(255); 1: Tenx) and written as fp32 NCHW (N,3,2r,2r) and/or bf16 NHWC (N,2r,2r,3); either may be NULL.
+ * mcl_log_library_size_normalize: out = log10(counts / rowsum(counts) * rescale + 1) (scprep.transform.log(
+ *   scprep.normalize.library_size_normalize(.)), dataset.py:188-189; rescale 1e4); all-zero rows stay zero.      */
+int mcl_patch_gather(const void* image_u8, int32_t Hs, int32_t Ws, const int32_t* centers_rc, int32_t N, int32_t r,
+                     const void* ops, float divisor, float* out_nchw_f32, void* out_nhwc_bf16, mcl_stream_t stream);
+int mcl_log_library_size_normalize(const float* counts, int64_t ldx, float* out, int64_t ldy, int32_t rows,
+                                   int32_t cols, float rescale, mcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

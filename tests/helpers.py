@@ -104,3 +104,17 @@ def bleep_embeddings(B, seed):
     ei = 0.6 * es + 0.4 * ei
     ln = torch.nn.functional.layer_norm
     return (ln(es, (256,)) * 0.08).contiguous(), (ln(ei, (256,)) * 0.08).contiguous()
+
+
+# --------------------------------------------------------------------------- input pipeline
+INPUT_CASE = dict(r=16,
+                  centers_xy=[(40, 50), (16, 16), (3, 70), (115, 95), (60, 2), (119, 99)],      # (x, y); some cross the border
+                  tenx_centers=[(50, 40), (30, 60), (70, 80), (16, 16), (84, 104), (45, 45), (33, 77), (60, 30)],
+                  hflip=[0, 1, 0, 1, 0, 1, 1, 0], vflip=[0, 0, 1, 1, 0, 0, 1, 1],
+                  angle=[0, 90, 180, -90, 90, 180, -90, 0])
+
+
+def synthetic_slide(hs=100, ws=120):
+    """Procedural (hs, ws, 3) uint8 'whole-slide image'."""
+    u = synth.uniform_tensor("slide", (hs, ws, 3), 0.0, 256.0, 0).numpy()
+    return np.clip(np.floor(u), 0, 255).astype(np.uint8)

@@ -153,3 +153,26 @@ def test_bleep_loss_oracle_matches_reference_fixture(name):
     assert_close(loss.item(), z[name + ".loss"], 1e-6, what="loss")
     assert_close(es.grad.numpy(), z[name + ".d_es"], 1e-7, 1e-5, what="d_es")
     assert_close(ei.grad.numpy(), z[name + ".d_ei"], 1e-7, 1e-5, what="d_ei")
+
+
+# --------------------------------------------------------------------------- input pipeline
+from helpers import INPUT_CASE, synthetic_slide  # noqa: E402
+
+
+def test_input_oracle_matches_pil_fixture():
+    """oracle/ref_input.py against PIL's own crop / ToTensor / flips / quarter-turn rotations (bit-exact)."""
+    from oracle import ref_input
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "input_patches.npz"))
+    img = synthetic_slide()
+    r = INPUT_CASE["r"]
+    got = np.stack([ref_input.to_tensor(ref_input.crop(img, y, x, r)) for (x, y) in INPUT_CASE["centers_xy"]])
+    assert np.array_equal(got, z["eval"])
+    got = np.stack([ref_input.tenx_transform(ref_input.crop(img, v1, v2, r), bool(h), bool(v), a).transpose(2, 0, 1)
+                    .astype(np.float32) for (v1, v2), h, v, a in zip(INPUT_CASE["tenx_centers"], INPUT_CASE["hflip"],
+                                                                     INPUT_CASE["vflip"], INPUT_CASE["angle"])])
+    assert np.array_equal(got, z["tenx"])
+    # normalisation: rows sum to 1e4 before the log; empty spots stay zero
+    c = np.array([[1.0, 3.0, 0.0, 6.0], [0.0, 0.0, 0.0, 0.0]])
+    y = ref_input.log_library_size_normalize(c)
+    assert_close(y[0], np.log10(c[0] * 1000.0 + 1.0), 1e-12, what="log10(x / libsize * 1e4 + 1)")
+    assert (y[1] == 0).all()
