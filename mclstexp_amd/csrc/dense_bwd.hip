@@ -18,6 +18,7 @@
 // accumulator layout (lane = channel) would otherwise touch HBM in 64-byte fragments; the per-channel BatchNorm
 // constants live in registers (a lane keeps its channel for the whole tile).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,8 +42,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // All global loads of a row tile (dz, x and -- dx launch -- the gradient-buffer chunks) are issued together at the
 // top, so the x / gradient latency hides under the dz staging and the MFMAs; LDS holds W1 (32 KB) + one 32 KB tile
 // that is first dz, then x, then (dx launch) the bf16 deltas: 64 KB, two workgroups per CU.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ W1,
+template <int MODE, int TMv>
+__global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ W1,
                                                          int K /* C_in: row length of W1 */,
                                                          const bf16_t* __restrict__ x, long long ldx, long long S,
                                                          const float* __restrict__ gamma,
@@ -52,15 +53,15 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ coef /* MODE 1: [C][2] */,
                                                          bf16_t* gbuf, long long ldg,
                                                          float2* __restrict__ partial /* MODE 0: [C][nrt] */, int nrt) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TM * 256 + 2048];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TK * 256 + TMv * 256 + 2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int n0 = blockIdx.y * TN;
   unsigned char* wt = lds;                  // [128 k][128 n] bf16, 256-byte rows, chunk ^ f(k) for transposing reads
-  unsigned char* dzt = lds + TM * 256;      // [128 rows][128 k] bf16, chunk ^ (row & 15); later the x tile / deltas
+  unsigned char* dzt = lds + TK * 256;      // [128 rows][128 k] bf16, chunk ^ (row & 15); later the x tile / deltas
   bf16_t* xt = reinterpret_cast<bf16_t*>(dzt);                   // [128][128] bf16, plain rows
-  float* red = reinterpret_cast<float*>(lds + 2 * TM * 256);     // [2 wm][128] float2
+  float* red = reinterpret_cast<float*>(lds + TK * 256 + TMv * 256);     // [2 wm][128] float2
 
   const int cc = tid & 15, rr = tid >> 4;
   const bool cok = n0 + cc * 8 < K;
@@ -91,11 +92,12 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
   const int g2 = 2 * ((lane >> 4) & 1) + (jj >> 1);
 
   for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
-    const long long row0 = (long long)rt * TM;
+    const long long row0 = (long long)rt * TMv;
     // ---- all global loads of this row tile, issued together
-    uint4 dzr[8], xr[8], gr[8];
+    constexpr int NL = TMv / 16, RI = TMv / 64;   // 16-byte chunks per thread and tile; 32-row blocks per wave
+    uint4 dzr[NL], xr[NL], gr[NL];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const long long rg = row0 + rr + 16 * i;
       const bool ok = rg < S;
       dzr[i] = ok ? *reinterpret_cast<const uint4*>(dz + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
@@ -105,26 +107,26 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
     }
     __syncthreads();   // the previous row tile is done with the shared tile
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int r = rr + 16 * i;
       *reinterpret_cast<uint4*>(dzt + r * 256 + ((cc ^ (r & 15)) << 4)) = dzr[i];
     }
     __syncthreads();
 
     // ---- da tile = dz_tile (128 x 128k) . W1_tile (128k x 128n): wave (wm, wn) owns rows wm*64.., channels wn*64..
-    f32x16 acc[2][2];
+    f32x16 acc[RI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[RI], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = wm * 64 + i * 32 + l31;
+      for (int i = 0; i < RI; ++i) {
+        const int r = wm * (TMv / 2) + i * 32 + l31;
         fa[i] = *reinterpret_cast<const bf16x8*>(dzt + r * 256 + (((2 * ks + h) ^ (r & 15)) << 4));
       }
 #pragma unroll
@@ -141,17 +143,17 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
         fb[j][4] = hi[0]; fb[j][5] = hi[1]; fb[j][6] = hi[2]; fb[j][7] = hi[3];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();   // dz tile dead: the same LDS now takes the x tile (plain 256-byte rows)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(xt + (rr + 16 * i) * TN + cc * 8) = xr[i];
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<uint4*>(xt + (rr + 16 * i) * TN + cc * 8) = xr[i];
     __syncthreads();
 
     // ---- epilogue: acc[i][j][r] is da at row wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*h, channel wn*64 + j*32 + l31
-    const long long nvalid = min((long long)TM, S - row0);
+    const long long nvalid = min((long long)TMv, S - row0);
     float s1[2], s2[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -160,10 +162,10 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
       // dx = sc*(g - c1 - xhat*c2) = sc*g + (ka*x + kb);   sum g*xhat = rs*(sum g*x - mu*sum g)
       const float ka = -sc[j] * c2[j] * rs[j], kb = fmaf(-ka, mu[j], -sc[j] * c1[j]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int row = wm * (TMv / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float xv = bf2f(xt[row * TN + cl]);
           const float gi = fmaf(xv, sc[j], sh[j]) > 0.0f ? acc[i][j][r] : 0.0f;
           if (MODE == 0) {
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void bn1_bwd_kernel(const bf16_t* __restric
       __syncthreads();
       if (cok) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NL; ++i) {
           const int r = rr + 16 * i;
           const long long rg = row0 + r;
           if (rg < S) {
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256) void bn2_dz_kernel(const bf16_t* __restrict__ 
 
 extern "C" int64_t mcl_dense_bn1_bwd_workspace_floats(int64_t S, int32_t C) {
   if (S <= 0 || C <= 0) return -1;
-  return ((S + TM - 1) / TM) * 2 * (int64_t)C + 2 * (int64_t)C;
+  return ((S + 63) / 64) * 2 * (int64_t)C + 2 * (int64_t)C;     // sized for the 64-row tiling
 }
 
 extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
@@ -453,22 +455,29 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
       (reinterpret_cast<uintptr_t>(W1) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
       (reinterpret_cast<uintptr_t>(gbuf) & 15u))
     return MCL_EUNSUPPORTED;
-  const int nrt = (int)((S + TM - 1) / TM), nct = (C + TN - 1) / TN;
+  // 64-row tiles: 50 KB of LDS and <= 168 VGPRs -> three workgroups per CU instead of two.  These kernels spend
+  // 55 % of their wave cycles in s_waitcnt (memory latency): 2302 -> 1835 us/step (dx) and 1774 -> 1561 us/step (reduce)
+  // summed over the 58 layers, faster in every block; MCL_BN1_TM=128 selects the 128-row tiling for A/B runs.
+  static const char* e_tm = getenv("MCL_BN1_TM");
+  const int tmv = (e_tm && atoi(e_tm) == 128) ? 128 : 64;
+  const int nrt = (int)((S + tmv - 1) / tmv), nct = (C + TN - 1) / TN;
   float2* part = reinterpret_cast<float2*>(workspace);
   float* coef = workspace + (int64_t)nrt * 2 * C;
   hipStream_t st = mcl_stream(stream);
-  // persistent over row tiles: ~512 workgroups in total (two per CU), each keeps one column tile
-  int gx = (512 + nct - 1) / nct;
+  // persistent over row tiles: two (128-row tiles) or three (64-row tiles) workgroups per CU, each keeps one column tile
+  int gx = ((tmv == 64 ? 768 : 512) + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
-  hipLaunchKernelGGL(bn1_bwd_kernel<0>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
-                     (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)nullptr, (bf16_t*)nullptr,
-                     0LL, part, nrt);
+#define MCL_BN1(MODE, TMV, COEF, GB, LDG, PART)                                                                         \
+  hipLaunchKernelGGL((bn1_bwd_kernel<MODE, TMV>), grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,       \
+                     (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, COEF, GB, LDG, PART, nrt)
+  if (tmv == 64) MCL_BN1(0, 64, (const float*)nullptr, (bf16_t*)nullptr, 0LL, part);
+  else MCL_BN1(0, 128, (const float*)nullptr, (bf16_t*)nullptr, 0LL, part);
   hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float2*)part, nrt, C,
                      (long long)S, dgamma, dbeta, coef, accumulate_params);
-  hipLaunchKernelGGL(bn1_bwd_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, (const bf16_t*)x,
-                     (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)coef, (bf16_t*)gbuf,
-                     (long long)ldg, (float2*)nullptr, nrt);
+  if (tmv == 64) MCL_BN1(1, 64, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
+  else MCL_BN1(1, 128, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
+#undef MCL_BN1
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
