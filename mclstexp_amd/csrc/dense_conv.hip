@@ -17,6 +17,7 @@
 // stored as whole 256-byte rows.  Statistics: per-tile (sum, M2) about a per-tile shift, merged by a one-wave-per
 // -channel finalize with Chan's formula in double (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -50,7 +51,10 @@ __device__ __forceinline__ uint4 bn_relu_chunk(uint4 v, const float (&sc)[8], co
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int WM>
+// WM wave-rows of RW (64 or 32) rows each, two wave-columns of 64 channels: BM = WM*RW rows, 128*WM threads.  <2, 32> is
+// the small-map form of <1, 64>: the same 64-row tile and LDS footprint but four waves instead of two per workgroup
+// (two waves per SIMD instead of one at two workgroups per CU).
+template <int WM, int RW = 64>
 __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, long long S,
                                                                int K, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
@@ -58,7 +62,9 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
                                                                const float* __restrict__ rstd,
                                                                const bf16_t* __restrict__ W, bf16_t* __restrict__ z,
                                                                long long ldz, float2* __restrict__ partial, int nblk) {
-  constexpr int BM = 64 * WM, NT = 128 * WM;
+  constexpr int BM = RW * WM, NT = 128 * WM;
+  constexpr int RI = RW / 32;                // 32-row blocks per wave
+  constexpr int NA = (BM * 8) / NT;          // A chunks per thread and stage
   constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;
   constexpr int NB = (BN * 8) / NT;  // W chunks per thread and stage
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_B + 2 * 1024 * 4];
@@ -78,11 +84,11 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
 
   // staging roles: A chunk column ca = tid & 7, rows (tid >> 3) + (NT/8)*i; B chunk column the same, rows (tid>>3) + (NT/8)*i
   const int cc = tid & 7, rr = tid >> 3;
-  uint4 ra[4], rb[NB];
+  uint4 ra[NA], rb[NB];
   auto load_stage = [&](int k0) {
     const int kc = k0 + cc * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const long long r = row0 + rr + (NT / 8) * i;
       ra[i] = (r < S && kc < K) ? *reinterpret_cast<const uint4*>(x + r * ldx + kc) : make_uint4(0u, 0u, 0u, 0u);
     }
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
       for (int i = 0; i < 8; ++i) sc[i] = sh[i] = 0.0f;   // K tail: relu(0*0 + 0) = 0
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int r = rr + (NT / 8) * i;
       const long long rg = row0 + r;
       uint4 v = bn_relu_chunk(ra[i], sc, sh);
@@ -122,9 +128,9 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[RI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   int co[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) co[kk] = ((2 * kk + h) ^ sw) << 4;
-  const int arow = (wm * 64 + l31) * 128, brow = (wn * 64 + l31) * 128;
+  const int arow = (wm * RW + l31) * 128, brow = (wn * 64 + l31) * 128;
 
   const int nst = (K + BK - 1) / BK;
   load_stage(0);
@@ -148,13 +154,13 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
     const unsigned char* Bt = At + A_B;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[RI], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(At + arow + i * 4096 + co[kk]);
+      for (int i = 0; i < RI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(At + arow + i * 4096 + co[kk]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bt + brow + j * 4096 + co[kk]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < RI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
@@ -162,14 +168,14 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[i][j][r]: row wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*h, channel wn*64 + j*32 + l31
+  // ---- epilogue.  acc[i][j][r]: row wm*RW + i*32 + (r&3) + 8*(r>>2) + 4*h, channel wn*64 + j*32 + l31
   float* red = reinterpret_cast<float*>(lds);                    // [WM][128] float2 (s1, s2)   (tiles are dead now)
   float* kshift = red + WM * 128 * 2;                            // [128]
   unsigned char* ot = lds + (WM * 128 * 2 + 128) * 4;           // output tile [BM][128] bf16, 256-byte rows
   const long long nvalid = min((long long)BM, S - row0);
   // round to bf16 (the statistics are those of the stored tensor)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -185,10 +191,10 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
     const float ks = kshift[c];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = wm * RW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[i][j][r];
         if (row < nvalid) {
           const float dlt = v - ks;
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   }
   // whole 256-byte rows out: BM*16 chunks over NT threads
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < (BM * 16) / NT; ++i) {
     const int q = tid + NT * i;
     const int row = q >> 4, ch = q & 15;
     if (row < nvalid)
@@ -285,16 +291,21 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
       (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(z) & 15u))
     return MCL_EUNSUPPORTED;
   const int wm = pick_wm(S);
-  const int bm = 64 * wm;
+  const int bm = 64 * wm;      // wm == 1 runs as <2, 32>: the same 64-row tile on four waves
   const int nblk = (int)((S + bm - 1) / bm);
   hipStream_t st = mcl_stream(stream);
   float2* part = reinterpret_cast<float2*>(workspace);
-#define MCL_LAUNCH(WMV)                                                                                              \
-  hipLaunchKernelGGL(conv1x1_fwd_kernel<WMV>, dim3(nblk), dim3(128 * WMV), 0, st, (const bf16_t*)x, (long long)ldx, \
-                     (long long)S, K, gamma, beta, mean, rstd, (const bf16_t*)W, (bf16_t*)z, (long long)ldz, part, nblk)
-  if (wm == 4) MCL_LAUNCH(4);
-  else if (wm == 2) MCL_LAUNCH(2);
-  else MCL_LAUNCH(1);
+#define MCL_LAUNCH(WMV, RWV)                                                                                         \
+  hipLaunchKernelGGL((conv1x1_fwd_kernel<WMV, RWV>), dim3(nblk), dim3(128 * WMV), 0, st, (const bf16_t*)x,           \
+                     (long long)ldx, (long long)S, K, gamma, beta, mean, rstd, (const bf16_t*)W, (bf16_t*)z,          \
+                     (long long)ldz, part, nblk)
+  static const char* e_half = getenv("MCL_C1F_HALF");
+  const bool half_waves = !(e_half && atoi(e_half) == 0);
+  // (the same doubling for the 128- / 256-row tiles, which already run two waves per SIMD, measured no gain)
+  if (wm == 4) MCL_LAUNCH(4, 64);
+  else if (wm == 2) MCL_LAUNCH(2, 64);
+  else if (half_waves) MCL_LAUNCH(2, 32);
+  else MCL_LAUNCH(1, 64);
 #undef MCL_LAUNCH
   if (want_stats)
     hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(BN), dim3(256), 0, st, (const float2*)part, nblk, BN,
