@@ -97,6 +97,26 @@ class TrainStep:
             m.sparse_grads["static"] = True
         torch.cuda.synchronize()
 
+    def _eager_ragged(self, batch) -> Tensor:
+        """A batch whose shapes differ from the captured ones (ragged last batch: train.py:49 has no drop_last) runs
+        eagerly.  The captured backward refills the STATIC sink entries (dout / ix / iy of the position tables) on
+        every replay; the eager backward overwrites them with its own tensors and FusedAdam.step then clears the
+        sink -- so the static entries are set aside here and put back afterwards, otherwise every later replay
+        would silently stop updating x_embed / y_embed."""
+        sink = getattr(self.model, "sparse_grads", None)
+        rowsparse = sink is not None and getattr(self.model, "embedding_grad", "dense") == "rowsparse"
+        saved = {}
+        if rowsparse:
+            saved = {k: sink[k] for k in ("dout", "ix", "iy") if k in sink}
+            sink.clear()
+        try:
+            return self._eager(batch)
+        finally:
+            if rowsparse:
+                sink.clear()
+                sink.update(saved)
+                sink["static"] = True
+
     def _same_shapes(self, batch) -> bool:
         return all(k in batch and batch[k].shape == v.shape and batch[k].dtype == v.dtype
                    for k, v in self.static_in.items())
@@ -110,11 +130,7 @@ class TrainStep:
         if self.ga is None:
             self._capture(batch)
         if not self._same_shapes(batch):
-            self.model.sparse_grads.pop("static", None)
-            out = self._eager(batch)
-            if getattr(self.model, "embedding_grad", "dense") == "rowsparse":
-                self.model.sparse_grads["static"] = True
-            return out
+            return self._eager_ragged(batch)
         for k, v in self.static_in.items():
             v.copy_(batch[k], non_blocking=True)
         self.ga.replay()

@@ -32,6 +32,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._tables: Dict[int, dict] = {}        # id(param) -> table state
         self._where: Dict[int, tuple] = {}        # id(param) -> (group index, element offset in the flat buffer)
         self._sink: Optional[dict] = None
+        self._pver: Dict[int, int] = {}           # id(param) -> autograd version at the last shadow refresh
         # bench.py sets this to a list to time every adam_table_kernel launch with HIP events recorded on
         # the launch stream: [(start_event, end_event), ...]
         self.profile_events: Optional[list] = None
@@ -46,6 +47,10 @@ class FusedAdam(torch.optim.Optimizer):
                 self._tables[id(emb.weight)] = {"key": key, "param": emb.weight}
         if self.process_group is None:
             self.process_group = getattr(model, "process_group", None)
+        # load_state_dict() into a live model rewrites the flat fp32 buffer behind the bf16 shadows' back (captured
+        # HIP graphs read the shadows directly, so the lazy per-parameter check in shadow() cannot catch that case)
+        if hasattr(model, "register_load_state_dict_post_hook"):
+            model.register_load_state_dict_post_hook(lambda mod, incompatible: self._refresh_shadows())
         # bf16 shadow weights for the fused backbone: one flat cast per step instead of ~120 per-weight casts
         from . import densenet_fused
         densenet_fused.set_weight_provider(self.shadow)
@@ -102,12 +107,27 @@ class FusedAdam(torch.optim.Optimizer):
         if key not in f:
             f[key] = f["p"].to(dtype)
             f.setdefault("shadow_keys", []).append((key, dtype))
-        return f[key].as_strided(p.shape, p.stride(), off)
+            self._pver.update({id(q): q._version for q in f["params"]})
+        v = f[key].as_strided(p.shape, p.stride(), off)
+        if self._pver.get(id(p)) != p._version:
+            # the parameter was written outside step() (p.copy_, load_state_dict without the model hook, an in-place
+            # edit): its autograd version counter moved, the kernels' own writes do not move it -> re-cast this segment
+            with torch.no_grad():
+                for k2, _ in f.get("shadow_keys", []):
+                    f[k2].as_strided(p.shape, p.stride(), off).copy_(p)
+            self._pver[id(p)] = p._version
+        return v
 
+    @torch.no_grad()
     def _refresh_shadows(self) -> None:
         for f in self._flat.values():
-            for key, _ in f.get("shadow_keys", []):
+            if not f.get("shadow_keys"):
+                continue
+            for key, _ in f["shadow_keys"]:
                 f[key].copy_(f["p"])
+            self._pver.update({id(q): q._version for q in f["params"]})
+
+    refresh_shadows = _refresh_shadows      # public: call after editing parameters in place outside step()
 
     def flat_grads(self) -> List[Tensor]:
         """Flat gradient buffers (the data-parallel all-reduce buckets)."""

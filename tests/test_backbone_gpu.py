@@ -234,6 +234,45 @@ def test_direct_param_grads_and_bf16_shadow():
     dn.set_weight_provider(None)
 
 
+def test_bf16_shadow_follows_load_state_dict_and_inplace_edits():
+    """The flat bf16 shadow served to the fused backbone must follow parameter writes that happen OUTSIDE
+    FusedAdam.step(): load_state_dict() into a trained model (evel_her2st.py:32-39 restores a checkpoint) and in-place
+    edits.  Stale shadows would run the convolutions on old weights with no error."""
+    from mclstexp_amd import densenet_fused as dn, synth
+    from mclstexp_amd.model import mclSTExp_Attention
+    from mclstexp_amd.optim import FusedAdam
+    G = 171
+    torch.manual_seed(0)
+    m = mclSTExp_Attention("densenet121", 1.0, 1024, G, 256, 8, 64, 1, backbone_dtype=torch.bfloat16,
+                           embedding_grad="rowsparse")
+    m.to(DEV).to(memory_format=torch.channels_last).train()
+    opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
+    batch = {k: v.to(DEV) for k, v in synth.make_batch(4, G, image_hw=64, seed=0).items()}
+    for _ in range(2):
+        loss = m(batch); opt.zero_grad(); loss.backward(); opt.step()
+    torch.manual_seed(123)
+    other = mclSTExp_Attention("densenet121", 1.0, 1024, G, 256, 8, 64, 1).to(DEV)
+    m.load_state_dict(other.state_dict())
+    for n, p in m.named_parameters():
+        if n.startswith("image_encoder") and p.dim() == 4:
+            v = opt.shadow(p, torch.bfloat16)
+            assert v is not None and torch.equal(v, p.detach().to(torch.bfloat16)), n
+    m.eval()
+    x = batch["image"]
+    with torch.no_grad():
+        got = m.encode_image(x)                                   # fused eval path, reads the shadows
+        dn.set_weight_provider(None)
+        want = m.encode_image(x)                                  # same kernels, per-weight casts of the fp32 params
+        dn.set_weight_provider(opt.shadow)
+    assert torch.equal(got, want)
+    # an in-place edit without any hook: the per-parameter version check re-casts that segment
+    w = m.image_encoder.model[0].denseblock1.denselayer1.conv1.weight
+    with torch.no_grad():
+        w.mul_(0.5)
+    assert torch.equal(opt.shadow(w, torch.bfloat16), w.detach().to(torch.bfloat16))
+    dn.set_weight_provider(None)
+
+
 @pytest.mark.parametrize("S,M,N,lda", [(4096, 128, 256, 256), (1000, 128, 96, 96), (777, 128, 160, 416),
                                         (50000, 128, 64, 64), (300, 256, 512, 512), (31, 128, 992, 1024)])
 def test_conv1x1_wrw_kernel(S, M, N, lda):

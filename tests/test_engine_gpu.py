@@ -59,11 +59,43 @@ def test_graph_replay_with_densenet_backbone_fp32():
 
 
 def test_ragged_batch_falls_back_to_eager():
-    from mclstexp_amd import synth
+    """train.py:49 has no drop_last: the ragged last batch runs eagerly, and the replayed steps AFTER it must keep
+    updating the position tables (touched rows through the row-sparse gradient, untouched rows through weight decay)
+    bit-identically to an all-eager run of the same batch sequence."""
+    from mclstexp_amd import densenet_fused as dn, synth
     from mclstexp_amd.engine import TrainStep
-    le, pe, tr = _run(True, "identity", steps=5)
-    batch = {k: v.to(DEV) for k, v in synth.make_batch(5, 171, image_dim=1024, seed=9).items()}   # ragged: B=5
-    loss = tr(batch)
-    assert torch.isfinite(loss)
-    batch = {k: v.to(DEV) for k, v in synth.make_batch(8, 171, image_dim=1024, seed=10).items()}
-    assert torch.isfinite(tr(batch))
+    from mclstexp_amd.model import mclSTExp_Attention
+    from mclstexp_amd.optim import FusedAdam
+    G = 171
+    sizes = [8, 8, 8, 8, 8, 5, 8, 8]          # capture happens at call 3; call 6 is ragged; calls 7, 8 replay again
+
+    def run(graphs):
+        torch.manual_seed(0)
+        m = mclSTExp_Attention("identity", 1.0, 1024, G, 256, 8, 64, 2, embedding_grad="rowsparse")
+        sd = m.state_dict()
+        sd.update(synth.make_params(G, 1024, seed=0))
+        m.load_state_dict(sd)
+        m.to(DEV).train()
+        opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
+        tr = TrainStep(m, opt, None, graphs=graphs, warmup=2)
+        losses, snaps = [], []
+        for s, b in enumerate(sizes):
+            batch = {k: v.to(DEV) for k, v in synth.make_batch(b, G, image_dim=1024, seed=s).items()}
+            losses.append(tr(batch).item())
+            row = int(batch["position"][0, 0].item())
+            snaps.append((row, m.x_embed.weight[row].detach().clone(), m.x_embed.weight[60000].detach().clone(),
+                          m.y_embed.weight[int(batch["position"][0, 1].item())].detach().clone()))
+        dn.set_weight_provider(None)
+        return losses, snaps, tr
+
+    le, se, _ = run(False)
+    lg, sg, tr = run(True)
+    assert tr.ga is not None
+    assert le == lg, (le, lg)
+    for i, ((r0, a, u, y), (r1, b, v, z)) in enumerate(zip(se, sg)):
+        assert r0 == r1
+        assert torch.equal(a, b), f"touched x_embed row differs after call {i + 1}"
+        assert torch.equal(u, v), f"untouched x_embed row (weight decay only) differs after call {i + 1}"
+        assert torch.equal(y, z), f"touched y_embed row differs after call {i + 1}"
+    # and the rows really moved on the replayed steps after the ragged batch
+    assert not torch.equal(sg[-1][2], sg[-3][2])
