@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: mclSTExp contrastive TRAINING STEP throughput on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1: this process spawns N workers itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,9 +13,10 @@ batch 128 per GPU, 224x224 patches, 1000 genes, bf16 backbone.  N > 1 = data par
 fixed (weak scaling), global InfoNCE over the all-gathered embeddings.
 
 Prints ONE JSON line (rank 0).  `value` = spots/s of the whole job = steps/s x global batch.
-`roofline` = the dominant hand-written kernel (fused Adam over the position tables, HBM-bound),
-timed with HIP events on its own stream inside the timed region.  `cpu_baseline` = the CPU oracle
-(oracle/ref_cpu.py) timed on this host's cores on a bounded sample (N=1 only).
+`roofline` = the C-ABI launch unit with the LARGEST time per step (`roofline_kernels` lists the others), each
+call timed with HIP events on its launch stream in an eager pass right after the timed region (same process, same
+resident model and inputs; every kernel alone on the GPU: side streams off).  `cpu_baseline` = the CPU oracle
+(oracle/ref_cpu.py) timed on this host's cores on the same workload, a bounded number of steps (N=1 only).
 """
 from __future__ import annotations
 
@@ -29,14 +30,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not initialise the GPU)
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (BASELINE configs[1]: 128)")
     ap.add_argument("--genes", type=int, default=1000)
     ap.add_argument("--image", type=int, default=224)
@@ -45,14 +48,19 @@ def parse():
     ap.add_argument("--image_dim", type=int, default=1024)
     ap.add_argument("--compute", type=str, default="f32", choices=["f32", "bf16"],
                     help="MFMA operand type of the hand-written spot-path kernels")
-    ap.add_argument("--infonce", type=str, default="fused", choices=["fused", "exact"],
-                    help="fused = flash-style bf16 MFMA InfoNCE (logits never in HBM); exact = fp32 GEMM + LSE kernels")
+    ap.add_argument("--infonce", type=str, default="fused", choices=["fused", "exact", "fp8"],
+                    help="fused = flash-style bf16 MFMA InfoNCE (logits never in HBM); exact = fp32 GEMM + LSE kernels; "
+                         "fp8 = the fused kernel on e4m3 operands (BASELINE configs[4])")
     ap.add_argument("--backbone_dtype", type=str, default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_graphs", action="store_true", help="A/B: eager launches instead of HIP-graph replay")
-    ap.add_argument("--conv1x1", type=str, default="miopen", choices=["mm", "miopen"], help="A/B: 1x1 convs of the dense blocks")
     ap.add_argument("--unfused_backbone", action="store_true", help="A/B: plain torch module path for the backbone")
-    ap.add_argument("--cpu_budget_s", type=float, default=15.0)
+    ap.add_argument("--cpu_budget_s", type=float, default=25.0)
+    ap.add_argument("--profile_steps", type=int, default=2,
+                    help="eager steps after the timed region in which the hot C-ABI calls are timed with HIP events "
+                         "(0 = no `roofline` object)")
+    ap.add_argument("--launch_check", action="store_true",
+                    help="only exercise the launcher + process group (works without a GPU, gloo): prints a JSON line")
     return ap.parse_args()
 
 
@@ -64,7 +72,8 @@ def _host_cores() -> int:
 
 
 def _cpu_baseline_worker(genes: int, image: int, batch: int, budget_s: float) -> dict:
-    """Runs in a child process (no GPU init): the CPU oracle's full training step on the host cores."""
+    """Runs in a child process (no GPU init): the CPU oracle's full training step on the host cores, at the GPU
+    workload's own batch size."""
     from mclstexp_amd import synth
     from mclstexp_amd.backbones import densenet121_features_module
     from oracle import ref_cpu
@@ -73,7 +82,6 @@ def _cpu_baseline_worker(genes: int, image: int, batch: int, budget_s: float) ->
     cores = min(32, _host_cores())
     torch.set_num_threads(cores)
     G = genes
-    sample_b = min(batch, 32)
     torch.manual_seed(0)
     params = synth.make_params(G, 1024, seed=0)
     net = densenet121_features_module()
@@ -83,18 +91,18 @@ def _cpu_baseline_worker(genes: int, image: int, batch: int, budget_s: float) ->
     for p in params.values():
         p.requires_grad_(True)
     state = {}
-    b = synth.make_batch(sample_b, G, image_hw=image, seed=0)
+    b = synth.make_batch(batch, G, image_hw=image, seed=0)
     ref_cpu.train_step(params, state, b, 1)               # warm-up (allocations, oneDNN primitives)
     n_steps, t0 = 0, time.perf_counter()
-    while n_steps < 5 and (n_steps < 1 or time.perf_counter() - t0 < budget_s):
+    while n_steps < 6 and (n_steps < 2 or time.perf_counter() - t0 < budget_s):
         ref_cpu.train_step(params, state, b, n_steps + 2)
         n_steps += 1
     t = (time.perf_counter() - t0) / n_steps
-    return {"value": round(sample_b / t, 3), "unit": "spots/s", "cores": cores, "kind": "port",
+    return {"value": round(batch / t, 3), "unit": "spots/s", "cores": cores, "kind": "port",
             "steps_per_sec": round(1.0 / t, 4),
             "sample": f"oracle/ref_cpu.train_step (fp32 torch CPU: DenseNet-121 restatement + spot path + dense-table "
-                      f"Adam over all params), batch {sample_b} x {image}^2 patches x {G} genes (the GPU workload's "
-                      f"batch is {batch}), 1 warm-up + {n_steps} timed steps, {t:.2f} s/step, {cores} threads"}
+                      f"Adam over all params), batch {batch} x {image}^2 patches x {G} genes = the GPU workload, "
+                      f"1 warm-up + {n_steps} timed steps, {t:.2f} s/step, {cores} threads"}
 
 
 def cpu_baseline(args, budget_s: float):
@@ -105,9 +113,9 @@ def cpu_baseline(args, budget_s: float):
             "print('CPUBASE ' + json.dumps(bench._cpu_baseline_worker(%d, %d, %d, %f)))"
             % (ROOT, args.genes, args.image, args.batch, budget_s))
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    limit = max(120.0, 8 * budget_s)
     try:
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=max(60.0, 6 * budget_s),
-                           env=env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit, env=env)
         for line in r.stdout.splitlines():
             if line.startswith("CPUBASE "):
                 return json.loads(line[8:])
@@ -115,7 +123,7 @@ def cpu_baseline(args, budget_s: float):
                 "sample": "cpu baseline failed: " + (r.stderr.strip().splitlines() or ["?"])[-1][:200]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "spots/s", "cores": _host_cores(), "kind": "port",
-                "sample": f"cpu baseline exceeded its {max(60.0, 6 * budget_s):.0f} s wall-clock limit"}
+                "sample": f"cpu baseline exceeded its {limit:.0f} s wall-clock limit"}
 
 
 def log(msg: str) -> None:
@@ -123,15 +131,87 @@ def log(msg: str) -> None:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ kernel roofline
+# C-ABI launch unit -> (kernels it enqueues, bound, algorithmic bytes of ONE call from its argument tuple).
+# Algorithmic bytes = every operand element read once + every result element written once.
+def _kernel_table():
+    from mclstexp_amd import kernel_costs
+    return kernel_costs.TABLE
+
+
+def kernel_roofline(step_fn, n_steps: int, model) -> list:
+    """Eager pass: every listed C-ABI call of ``n_steps`` steps is bracketed by HIP events on its launch stream.
+    Side streams are switched off for the pass so that each timed launch has the GPU to itself (the durations are
+    then comparable with the serial rocprofv3 kernel trace under profiles/)."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    table = _kernel_table()
+    side, overlap = dn.USE_SIDE_STREAM, type(model).overlap_branches
+    dn.USE_SIDE_STREAM, type(model).overlap_branches = False, False
+    try:
+        step_fn(0)                                        # un-timed: first eager call after graph replay
+        torch.cuda.synchronize()
+        with _lib.AbiTimer(list(table)) as t:
+            for i in range(n_steps):
+                step_fn(i + 1)
+            summ = t.summary()
+    finally:
+        dn.USE_SIDE_STREAM, type(model).overlap_branches = side, overlap
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))
+        except Exception:
+            traffic = {}
+    rows = []
+    for name, s in summ.items():
+        spec = table[name]
+        alg = [float(spec["bytes"](a)) for a in s["args"]]
+        tot_b, tot_s = sum(alg), s["total_ms"] * 1e-3
+        ach = tot_b / tot_s / 1e9
+        tr = traffic.get(name)
+        rows.append({"abi": name, "kernel": spec["kernels"], "bound": "hbm", "achieved": round(ach, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                     "traffic": tr, "launches_per_step": s["calls"] / n_steps,
+                     "avg_launch_ms": round(s["avg_ms"], 5), "ms_per_step": round(s["total_ms"] / n_steps, 4),
+                     "algorithmic_bytes": round(tot_b / s["calls"], 1)})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_check() -> None:
+    """Launcher / rendezvous self-test (no GPU needed): every rank contributes rank+1 to an all-reduce."""
+    from mclstexp_amd import dist as mdist
+    os.environ.setdefault("MCL_DIST_BACKEND", "gloo" if not torch.cuda.is_available() else "nccl")
+    pg, rank, world = mdist.init_from_env()
+    t = torch.tensor([float(rank + 1)])
+    if pg is not None:
+        if torch.cuda.is_available() and os.environ["MCL_DIST_BACKEND"] == "nccl":
+            t = t.cuda()
+        torch.distributed.all_reduce(t, group=pg)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "sum": float(t.item())}), flush=True)
+    mdist.shutdown()
+
+
 def main():
     args = parse()
+    from mclstexp_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # parent: no GPU call has been made (torch.cuda is untouched) -> start one fresh worker per GPU and relay
+        # rank 0's JSON line.  Never re-exec a process that has initialised HIP.
+        raise SystemExit(launch.spawn_workers(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus and not (args.gpus == 1 and world_env == 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks")
+    if args.launch_check:
+        return launch_check()
+
     from mclstexp_amd import dist as mdist
     pg, rank, world = mdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
-    if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device("cuda", torch.cuda.current_device())
     from mclstexp_amd import _lib, synth
     from mclstexp_amd.model import mclSTExp_Attention
@@ -144,7 +224,6 @@ def main():
                                backbone_dtype=bb, embedding_grad="rowsparse",
                                process_group=pg, infonce=args.infonce)
     from mclstexp_amd import densenet_fused
-    densenet_fused.USE_MM_1X1 = args.conv1x1 == "mm"
     model.fused_backbone = not args.unfused_backbone
     model.to(dev)
     if bb is not None:
@@ -173,24 +252,19 @@ def main():
     def step(i):
         return trainer(batches[i % len(batches)])
 
-    # setup (not part of the W warm-up steps): MIOpen solver search, flat optimizer bucket, HIP-graph capture
+    # setup (not part of the W warm-up steps): flat optimizer bucket, HIP-graph capture
     log("setup: 3 eager steps + graph capture")
     for i in range(5 if not args.no_graphs else 2):
         step(i)
     torch.cuda.synchronize()
     log(f"model + inputs resident; warm-up {args.warmup} steps")
     for i in range(args.warmup):
-        tw = time.perf_counter()
         loss = step(i)
-        if i < 3:
-            torch.cuda.synchronize()
-            log(f"warm-up step {i}: {time.perf_counter() - tw:.2f} s")
     torch.cuda.synchronize()
     log("timed region")
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    opt.profile_events = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
@@ -203,34 +277,29 @@ def main():
     log(f"host enqueue {1e3 * t_host / args.steps:.2f} ms/step, wall {1e3 * dt / args.steps:.2f} ms/step "
         f"({'HOST-bound' if t_host > 0.9 * dt else 'GPU-bound'})")
     final_loss = float(loss.item())
-    ev = opt.profile_events
-    opt.profile_events = None
     if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
-    # dominant hand-written kernel: adam_table_kernel, HBM-bound, 24 B/element (read p,m,v; write p,m,v)
-    roof = None
-    if ev:
-        ms = [a.elapsed_time(b) for a, b in ev]
-        avg_ms = sum(ms) / len(ms)
-        alg_bytes = 24.0 * 65536 * args.genes
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "adam_table_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"G{args.genes}")
-            except Exception:
-                traffic = None
-        roof = {"kernel": "adam_table_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "avg_launch_ms": round(avg_ms, 4), "launches": len(ms), "algorithmic_bytes": alg_bytes}
+    # per-kernel roofline: eager pass with HIP events around the hot C-ABI calls (rank 0's GPU; N = 1 only, so that the
+    # collectives of the other ranks are not left waiting)
+    roof_rows = []
+    if args.profile_steps > 0 and world == 1 and args.encoder == "densenet121" and not args.unfused_backbone:
+        log(f"kernel timing pass: {args.profile_steps} eager steps, HIP events per C-ABI call")
+        eager = TrainStep(model, opt, reducer, graphs=False)
+        if getattr(model, "embedding_grad", "dense") == "rowsparse":
+            model.sparse_grads.clear()                   # the eager pass owns the sink from here on
+        roof_rows = kernel_roofline(lambda i: eager(batches[i % len(batches)]), args.profile_steps, model)
 
     if rank == 0:
         steps_per_s = args.steps / dt
         gb = args.batch * world
+        roof = None
+        if roof_rows:
+            roof = dict(roof_rows[0])
+            roof["note"] = ("launch unit with the largest time per step; HIP events on the launch stream, eager pass "
+                            "after the timed region, side streams off (each launch alone on the GPU)")
         out = {
             "metric": "training spots/sec (= steps/sec x global batch) at batch 128/GPU, 224px patches, 1000 genes",
             "value": round(steps_per_s * gb, 2), "unit": "spots/s", "steps_per_sec": round(steps_per_s, 4),
@@ -240,9 +309,16 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: train step, batch {args.batch}/GPU, {args.image}x{args.image} "
                                    f"patches, {args.genes} genes, {args.encoder} image encoder",
                        "global_batch": gb, "parallelism": f"dp{world}", "backbone_dtype": args.backbone_dtype,
-                       "spot_path_mfma": args.compute, "infonce": args.infonce, "hip_graphs": not args.no_graphs, "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
-                       "final_loss": round(final_loss, 4)},
+                       "spot_path_mfma": args.compute, "infonce": args.infonce, "hip_graphs": not args.no_graphs,
+                       "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
+                       "dp_semantics": "spot-encoder attention and BatchNorm statistics are per shard (per GPU); "
+                                       "InfoNCE is global over the all-gathered embeddings",
+                       "fallbacks": densenet_fused.fallback_counts(),
+                       "final_loss": round(final_loss, 4),
+                       "final_loss_note": f"{args.n_batches} synthetic batches are cycled: the loss reflects "
+                                          "memorisation of that set, it is not a convergence claim"},
             "roofline": roof,
+            "roofline_kernels": roof_rows[1:8],
         }
         if world == 1 and not args.no_cpu_baseline:
             log("gpu done: %.2f ms/step; timing the CPU oracle baseline" % out["ms_per_step"])

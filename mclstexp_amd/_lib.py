@@ -139,3 +139,54 @@ def check(code: int, what: str = "") -> None:
     if code != 0:
         msg = lib().mcl_error_string(code)
         raise RuntimeError(f"mclstexp_hip {what} failed: [{code}] {msg.decode() if msg else '?'}")
+
+
+class AbiTimer:
+    """Times selected C-ABI entry points with HIP events recorded on the stream they launch on.
+
+    ``with AbiTimer(["mcl_dense_bn1_wrw", ...]) as t: step()`` wraps each named entry point so that every call is
+    bracketed by two timing events on torch's CURRENT stream -- the stream ``ops._stream()`` hands to the ABI, i.e.
+    the launch stream.  ``t.summary()`` (after a device synchronise) returns, per name, the call count, the mean and
+    total duration in ms, and the recorded argument tuples (bench.py derives each call's algorithmic bytes from
+    them).  An entry point that enqueues more than one kernel (a reduce + its finalize) is timed as one unit."""
+
+    def __init__(self, names):
+        self.names = list(names)
+        self.records = {n: [] for n in self.names}
+        self._orig = {}
+
+    def __enter__(self):
+        L = lib()
+        for n in self.names:
+            orig = getattr(L, n)
+            self._orig[n] = orig
+
+            def wrapped(*args, _orig=orig, _n=n):
+                st = torch.cuda.current_stream()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                rc = _orig(*args)
+                e1.record(st)
+                self.records[_n].append((e0, e1, args))
+                return rc
+            setattr(L, n, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        for n, orig in self._orig.items():
+            setattr(L, n, orig)
+        self._orig = {}
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, recs in self.records.items():
+            if not recs:
+                continue
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[n] = {"calls": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "ms": ms,
+                      "args": [r[2] for r in recs]}
+        return out

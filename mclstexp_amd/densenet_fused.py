@@ -35,6 +35,23 @@ Tensor = torch.Tensor
 CL = torch.channels_last
 _ws_cache = {}
 
+# Every place where this file leaves the hand-written kernels for a library path (MIOpen through aten.convolution*,
+# ATen pooling) counts itself here: a shape regression that silently puts MIOpen back on the hot path shows up in
+# ``fallback_counts()`` (asserted empty by the bf16 tests, printed in bench.py's JSON line).
+_fallbacks: dict = {}
+
+
+def _fallback(site: str) -> None:
+    _fallbacks[site] = _fallbacks.get(site, 0) + 1
+
+
+def fallback_counts() -> dict:
+    return dict(_fallbacks)
+
+
+def reset_fallbacks() -> None:
+    _fallbacks.clear()
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -211,6 +228,7 @@ def _as2d(t: Tensor) -> Tensor:
 
 def _conv1x1_fwd(a: Tensor, w: Tensor) -> Tensor:
     if not USE_MM_1X1:
+        _fallback("conv1x1_fwd:miopen")
         return F.conv2d(a, w).contiguous(memory_format=CL)
     B, C, H, W = a.shape
     z = torch.mm(_as2d(a), w.reshape(w.shape[0], C).t())
@@ -371,9 +389,11 @@ def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Optional[Tensor] = N
         assert dz.dtype == torch.bfloat16 and w_param is not None
         # the data gradient needs only dz and w: a transposed convolution IS the backward-data kernel and, unlike
         # aten.convolution_backward, does not make a contiguous copy of the (channel-sliced) layer input first
+        _fallback("conv1x1_bwd_data:miopen")
         da = F.conv_transpose2d(dz, w)
         return da.contiguous(memory_format=CL), ("direct", conv1x1_wrw(dz, a, w_param, bn=bn))
     if not USE_MM_1X1:
+        _fallback("conv1x1_bwd:miopen")
         if USE_HIP_WRW_1X1 and w_param is not None and dz.dtype == torch.bfloat16:
             da = torch.ops.aten.convolution_backward(dz, a, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
@@ -430,6 +450,7 @@ def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
 
 
 def _conv_bwd(dy, x, w, padding):
+    _fallback("conv_bwd:miopen")
     return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [padding, padding], [1, 1], False, [0, 0], 1,
                                                [True, True, False])
 
@@ -515,6 +536,7 @@ class DenseBlockFn(torch.autograd.Function):
             else:
                 a2 = torch.empty_like(z, memory_format=CL)
                 bn_act_fwd(z, g2, b2, m2, r2, True, a2)
+                _fallback("conv3x3_fwd:miopen")
                 y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
                 bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
                          copy_out=buf[:, cin:c1])
@@ -707,6 +729,7 @@ class Conv0Fn(torch.autograd.Function):
             check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), w.grad.data_ptr(), _stream()),
                   "mcl_conv0_wrw")                       # straight into the parameter's fp32 .grad
             return None, None, None
+        _fallback("conv0_wrw:miopen")
         dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                  [False, True, False])[1]
         return None, _wgrad(ctx.w, dw), None
@@ -804,11 +827,17 @@ def _stem_tail_ok(x: Tensor) -> bool:
 
 
 def max_pool_3s2(x: Tensor) -> Tensor:
-    return MaxPool3s2Fn.apply(x) if _pool_ok(x, False) else F.max_pool2d(x, 3, 2, 1)
+    if _pool_ok(x, False):
+        return MaxPool3s2Fn.apply(x)
+    _fallback("maxpool:aten")
+    return F.max_pool2d(x, 3, 2, 1)
 
 
 def avg_pool_2(x: Tensor) -> Tensor:
-    return AvgPool2Fn.apply(x) if _pool_ok(x, True) else F.avg_pool2d(x, 2, 2)
+    if _pool_ok(x, True):
+        return AvgPool2Fn.apply(x)
+    _fallback("avgpool:aten")
+    return F.avg_pool2d(x, 2, 2)
 
 
 # --------------------------------------------------------------------------- transitions
@@ -932,6 +961,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
         mean0, var0, rstd0 = (torch.empty(64, device=x.device, dtype=torch.float32) for _ in range(3))
         x = Conv0Fn.apply(x, features.conv0.weight, (features.norm0.eps, (mean0, var0, rstd0)))
     else:
+        _fallback("conv0_fwd:miopen")
         x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                      padding=features.conv0.padding)
     x = x.contiguous(memory_format=CL)
@@ -963,6 +993,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
                                        (stats, next_stats, nxt[0].norm1.eps))
             else:
                 a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
+                _fallback("transition:miopen")
                 x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
                 x = avg_pool_2(x.contiguous(memory_format=CL))
         else:
@@ -1001,6 +1032,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
     if _conv0_ok(x, features.conv0):
         x = conv0_fwd(x, _weight(features.conv0.weight, act_dtype), features.norm0.eps, None)
     else:
+        _fallback("eval.conv0_fwd:miopen")
         x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                      padding=features.conv0.padding)
     x = x.contiguous(memory_format=CL)
@@ -1026,6 +1058,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 dense_conv3x3_fwd(z, ly.norm2.weight, ly.norm2.bias, ly.norm2.running_mean, rs[id(ly.norm2)], w2c,
                                   buf[:, cin:cin + growth], ly.norm1.eps, None, None, None)
             else:
+                _fallback("eval.dense_layer:miopen")
                 a = affine(buf[:, :cin], ly.norm1, True)
                 z = affine(_conv1x1_fwd(a, w1c), ly.norm2, True)
                 buf[:, cin:cin + growth].copy_(F.conv2d(z, w2c, padding=1))
@@ -1035,6 +1068,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 p = bn_act_avgpool_fwd(buf, tr.norm.weight, tr.norm.bias, tr.norm.running_mean, rs[id(tr.norm)])
                 x = pooled_conv1x1_fwd(p, _weight(tr.conv.weight, act_dtype), tr.norm.eps, None)
             else:
+                _fallback("eval.transition:miopen")
                 a = affine(buf, tr.norm, True)
                 x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
         else:
