@@ -25,7 +25,7 @@ defaults to the HIP kernels (``HipPrims``).  CPU tests inject oracle-backed prim
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as td
@@ -80,6 +80,62 @@ def _all_gather_cat(x: Tensor, pg) -> Tensor:
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
     td.all_gather_into_tensor(out, x, group=pg)
     return out
+
+
+# --------------------------------------------------------------------------- ragged shards
+# The reference's DataLoader has no drop_last (train.py:49): the last batch of an epoch is short, and under data
+# parallelism the ranks may then hold DIFFERENT numbers of pairs.  Shard sizes are agreed on the HOST every step
+# (``SizeExchange``: a tiny gloo all-gather that never touches the GPU stream, so the launch-ahead of the step is
+# kept) and handed to the collectives below, which pad to the largest shard, gather, and drop the padding rows.
+_step_sizes: Optional[List[int]] = None
+
+
+def set_step_sizes(sizes: Optional[Sequence[int]]) -> None:
+    """Shard sizes (pairs per rank, rank order) of the CURRENT step; None = equal shards (the fast path)."""
+    global _step_sizes
+    _step_sizes = None if sizes is None or len(set(sizes)) == 1 else [int(v) for v in sizes]
+
+
+def step_sizes() -> Optional[List[int]]:
+    return _step_sizes
+
+
+class SizeExchange:
+    """Host-side agreement on the per-rank batch sizes of a step (one int per rank over a gloo group)."""
+
+    def __init__(self, pg):
+        self.pg = pg
+        self.world = td.get_world_size(pg)
+        self._cpu_pg = None
+
+    def _group(self):
+        if self._cpu_pg is None:
+            self._cpu_pg = self.pg if td.get_backend(self.pg) == "gloo" else td.new_group(backend="gloo")
+        return self._cpu_pg
+
+    def __call__(self, b_loc: int) -> List[int]:
+        if self.world == 1:
+            return [int(b_loc)]
+        mine = torch.tensor([int(b_loc)], dtype=torch.int64)
+        out = torch.empty((self.world,), dtype=torch.int64)
+        td.all_gather_into_tensor(out, mine, group=self._group())
+        return [int(v) for v in out.tolist()]
+
+
+def _all_gather_rows(x: Tensor, pg, sizes: Optional[Sequence[int]] = None) -> Tensor:
+    """Rank-ordered concatenation along dim 0; ``sizes`` = rows per rank when the shards are ragged."""
+    if sizes is None:
+        return _all_gather_cat(x, pg)
+    world, rank = td.get_world_size(pg), td.get_rank(pg)
+    if len(sizes) != world or x.shape[0] != sizes[rank]:
+        raise RuntimeError(f"ragged all-gather: this rank holds {x.shape[0]} rows, sizes say {list(sizes)}")
+    cap = max(sizes)
+    if cap == 0:
+        return x.new_empty((0,) + tuple(x.shape[1:]))
+    pad = x.new_zeros((cap,) + tuple(x.shape[1:]))
+    pad[: x.shape[0]] = x
+    full = _all_gather_cat(pad, pg).view((world, cap) + tuple(x.shape[1:]))
+    return torch.cat([full[r, : sizes[r]] for r in range(world)], dim=0)
 
 
 def _all_reduce_sum(x: Tensor, pg) -> None:
@@ -148,15 +204,17 @@ class HipPrims:
         return out
 
 
-def dist_infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipPrims
-                         ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+def dist_infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipPrims,
+                         sizes: Optional[Sequence[int]] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """Global symmetric InfoNCE from per-rank embeddings.  Returns (loss [identical on every rank],
-    dE_spot_loc, dE_img_loc, S_row_strip)."""
+    dE_spot_loc, dE_img_loc, S_row_strip).  ``sizes`` (default: the step's agreed sizes, ``set_step_sizes``): pairs
+    per rank when the shards are ragged."""
     world, rank = td.get_world_size(pg), td.get_rank(pg)
+    sizes = _step_sizes if sizes is None else (None if len(set(sizes)) == 1 else list(sizes))
     b_loc, P = e_spot.shape
-    b_glob = world * b_loc
-    row0 = rank * b_loc
-    all_e = _all_gather_cat(torch.cat([e_spot, e_img], dim=1), pg)          # collective 1: (B_glob, 2P)
+    b_glob = world * b_loc if sizes is None else sum(sizes)
+    row0 = rank * b_loc if sizes is None else sum(sizes[:rank])
+    all_e = _all_gather_rows(torch.cat([e_spot, e_img], dim=1), pg, sizes)   # collective 1: (B_glob, 2P)
     es_all, ei_all = all_e[:, :P], all_e[:, P:]
     inv_t = 1.0 / temperature
     s_rows = prims.logits(e_spot.contiguous(), ei_all, inv_t)                # (B_loc, B_glob)
@@ -165,10 +223,10 @@ def dist_infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, 
     cl = prims.col_lse(s_cols)
     idx = torch.arange(b_loc, device=e_spot.device)
     diag = s_rows[idx, row0 + idx]
-    packed = _all_gather_cat(torch.stack([rl, cl, diag]).unsqueeze(0), pg)   # collective 2: (W, 3, B_loc)
-    rl_all = packed[:, 0].reshape(-1)
-    cl_all = packed[:, 1].reshape(-1)
-    diag_all = packed[:, 2].reshape(-1)
+    packed = _all_gather_rows(torch.stack([rl, cl, diag], dim=1), pg, sizes)  # collective 2: (B_glob, 3)
+    rl_all = packed[:, 0].contiguous()
+    cl_all = packed[:, 1].contiguous()
+    diag_all = packed[:, 2]
     loss = ((rl_all - diag_all).sum() + (cl_all - diag_all).sum()) / (2.0 * b_glob)
     coef = 1.0 / (2.0 * b_glob * temperature)
     ds_rows = prims.dlogits(s_rows, rl, cl_all, row0, 0, coef)
@@ -198,27 +256,29 @@ class HipFusedPrims:
         return ops.infonce_fused_grad(a16, b16, inv_t, lse_a, lse_b, coef, diag_off)
 
 
-def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipFusedPrims
-                               ) -> Tuple[Tensor, Tensor, Tensor, None]:
+def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipFusedPrims,
+                               sizes: Optional[Sequence[int]] = None) -> Tuple[Tensor, Tensor, Tensor, None]:
     """Same global symmetric InfoNCE as ``dist_infonce_fwd_bwd`` on the fused kernels: the embeddings are rounded
-    to bf16 BEFORE the all-gather (half the bytes on xGMI), each rank runs the strip kernel in both orientations
-    (own spots vs all images: row LSEs + dE_spot; own images vs all spots: column LSEs + dE_img) and no logits
-    strip is ever written.  Still two collectives: [E_spot | E_img] bf16, then [row_lse | col_lse | diag]."""
+    to bf16 (or e4m3, ``prims``) BEFORE the all-gather (half / a quarter of the bytes on xGMI), each rank runs the strip
+    kernel in both orientations (own spots vs all images: row LSEs + dE_spot; own images vs all spots: column LSEs +
+    dE_img) and no logits strip is ever written.  Still two collectives: [E_spot | E_img], then [row_lse | col_lse |
+    diag].  ``sizes``: pairs per rank for ragged shards (default: ``set_step_sizes``)."""
     world, rank = td.get_world_size(pg), td.get_rank(pg)
+    sizes = _step_sizes if sizes is None else (None if len(set(sizes)) == 1 else list(sizes))
     b_loc, P = e_spot.shape
-    b_glob = world * b_loc
-    doff = rank * b_loc
+    b_glob = world * b_loc if sizes is None else sum(sizes)
+    doff = rank * b_loc if sizes is None else sum(sizes[:rank])
     inv_t = 1.0 / temperature
-    loc16 = torch.cat([prims.cast(e_spot), prims.cast(e_img)], dim=1)       # (B_loc, 2P) bf16
-    all16 = _all_gather_cat(loc16, pg)                                       # collective 1: (B_glob, 2P) bf16
+    loc16 = torch.cat([prims.cast(e_spot), prims.cast(e_img)], dim=1)       # (B_loc, 2P) low precision
+    all16 = _all_gather_rows(loc16, pg, sizes)                               # collective 1: (B_glob, 2P)
     es_loc, ei_loc = loc16[:, :P], loc16[:, P:]                              # row stride 2P: read in place
     es_all, ei_all = all16[:, :P], all16[:, P:]
     rl, diag = prims.lse(es_loc, ei_all, inv_t, doff)                        # rows of S owned by this rank
     cl, _ = prims.lse(ei_loc, es_all, inv_t, doff)                           # columns of S owned by this rank
-    packed = _all_gather_cat(torch.stack([rl, cl, diag]).unsqueeze(0), pg)   # collective 2: (W, 3, B_loc)
-    rl_all = packed[:, 0].reshape(-1).contiguous()
-    cl_all = packed[:, 1].reshape(-1).contiguous()
-    diag_all = packed[:, 2].reshape(-1)
+    packed = _all_gather_rows(torch.stack([rl, cl, diag], dim=1), pg, sizes)  # collective 2: (B_glob, 3)
+    rl_all = packed[:, 0].contiguous()
+    cl_all = packed[:, 1].contiguous()
+    diag_all = packed[:, 2]
     loss = ((rl_all - diag_all).sum() + (cl_all - diag_all).sum()) / (2.0 * b_glob)
     coef = inv_t / (2.0 * b_glob)
     d_es = prims.grad(es_loc, ei_all, inv_t, rl, cl_all, coef, doff)
@@ -243,12 +303,14 @@ class DistInfoNCEFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- gradient exchange
-def gather_rows(dout: Tensor, ix: Tensor, iy: Tensor, pg) -> Tuple[Tensor, Tensor, Tensor]:
+def gather_rows(dout: Tensor, ix: Tensor, iy: Tensor, pg, sizes: Optional[Sequence[int]] = None
+                ) -> Tuple[Tensor, Tensor, Tensor]:
     """Sparse exchange for the two position tables: both share one upstream gradient (B_loc, G), so a
     single all-gather of it (+ the two index vectors) replaces a dense 2 x (65536, G) all-reduce
     (4 MB vs 524 MB at B_glob=1024, G=1000).  Every rank then reduces the identical global rows."""
-    g_dout = _all_gather_cat(dout, pg)
-    g_idx = _all_gather_cat(torch.stack([ix, iy], dim=1), pg)
+    sizes = _step_sizes if sizes is None else (None if len(set(sizes)) == 1 else list(sizes))
+    g_dout = _all_gather_rows(dout, pg, sizes)
+    g_idx = _all_gather_rows(torch.stack([ix, iy], dim=1), pg, sizes)
     return g_dout, g_idx[:, 0].contiguous(), g_idx[:, 1].contiguous()
 
 

@@ -42,6 +42,8 @@ class TrainStep:
         if single_graph is None:
             single_graph = os.environ.get("MCL_SINGLE_GRAPH", "1") != "0"
         self.single_graph = bool(single_graph) and can_single
+        self._sizes_ex = None
+        self._all_regular = True
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
@@ -122,14 +124,37 @@ class TrainStep:
                    for k, v in self.static_in.items())
 
     # ------------------------------------------------------------------ call
+    def _agree_sizes(self, batch) -> bool:
+        """Data parallel: the ranks agree (on the host, dist.SizeExchange) on this step's per-rank batch sizes, so
+        that every rank takes the SAME path -- graph replay only when every shard has the captured size -- and the
+        collectives of a ragged step (last batch of an epoch, train.py:49) know the true shard sizes.  Returns
+        True when all shards are equal."""
+        if self.reducer is None:
+            return True
+        from . import dist as mdist
+        if self._sizes_ex is None:
+            self._sizes_ex = mdist.SizeExchange(self.reducer.pg)
+        sizes = self._sizes_ex(batch["expression"].shape[0])
+        if min(sizes) == 0:
+            raise RuntimeError(f"data-parallel step with an empty shard (sizes {sizes}): drop or re-balance the "
+                               "last batch")
+        mdist.set_step_sizes(sizes)
+        self._all_regular = self.static_in is not None and all(
+            v == self.static_in["expression"].shape[0] for v in sizes)
+        return len(set(sizes)) == 1
+
     def __call__(self, batch: Dict[str, Tensor]) -> Tensor:
         batch = {k: batch[k] for k in ("image", "expression", "position")}
         self.calls += 1
+        equal = self._agree_sizes(batch)
         if not self.graphs or self.calls <= self.warmup:
             return self._eager(batch)
         if self.ga is None:
+            if not equal:
+                return self._eager(batch)            # never capture on a ragged step
             self._capture(batch)
-        if not self._same_shapes(batch):
+            self._all_regular = True
+        if not self._same_shapes(batch) or (self.reducer is not None and not self._all_regular):
             return self._eager_ragged(batch)
         for k, v in self.static_in.items():
             v.copy_(batch[k], non_blocking=True)

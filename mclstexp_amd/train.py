@@ -79,9 +79,16 @@ def train(model, train_dataLoader: Iterable, optimizer, epoch: int, log_every: i
     engine.TrainStep that performs the same forward / zero_grad / backward / step from captured HIP graphs."""
     loss_meter = AvgMeter()
     step = 0
+    sizes_ex = None
+    if reducer is not None and stepper is None:
+        from . import dist as mdist
+        sizes_ex = mdist.SizeExchange(reducer.pg)
     for batch in train_dataLoader:
         batch = {k: v.cuda(non_blocking=True) for k, v in batch.items() if
                  k == "image" or k == "expression" or k == "position"}
+        if sizes_ex is not None:
+            # ragged last batch (no drop_last, train.py:49): the ranks agree on their shard sizes on the host
+            mdist.set_step_sizes(sizes_ex(batch["expression"].shape[0]))
         if stepper is not None:
             if batch["image"].dtype == torch.float32 and getattr(model, "backbone_dtype", None) is not None:
                 batch["image"] = batch["image"].contiguous(memory_format=torch.channels_last)

@@ -8,7 +8,7 @@ from mclstexp_amd import synth
 from oracle import ref_cpu
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_CASES = ["b8_g785", "b33_g171", "b128_g1000", "b16_g685_vit", "b8_g171_mlp"]
+GOLDEN_CASES = ["b8_g785", "b33_g171", "b128_g1000", "b16_g685_vit", "b8_g171_mlp", "b256_g3467"]
 UNTOUCHED_ROW = 60000
 
 
@@ -17,6 +17,11 @@ def load_golden(name):
     B, G, D, L, steps = [int(v) for v in z["meta"]]
     return z, dict(B=B, G=G, D=D, layers=L, steps=steps, T=float(z["temperature"]),
                    variant="mlp" if name.endswith("mlp") else "attention")
+
+
+def layer_sample(v, B, G):
+    """Sub-sampling of a per-layer (B, G) output as stored by tests/golden/gen_goldens.py."""
+    return v if B * G <= 40000 else (v[::8] if B * G <= 200000 else v[::32, ::4])
 
 
 def sample(t, n=256):

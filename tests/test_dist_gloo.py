@@ -169,6 +169,70 @@ def test_gather_rows_is_rank_ordered_concat():
         assert torch.equal(o[3], dcat) and torch.equal(o[4], xcat) and torch.equal(o[5], ycat)
 
 
+RAGGED = {2: [6, 3], 4: [5, 2, 7, 4], 8: [4, 4, 1, 4, 3, 4, 4, 2]}
+
+
+def _ragged_case(rank, world):
+    """Ragged shards (last batch of an epoch, train.py:49 has no drop_last): sizes agreed on the host."""
+    from mclstexp_amd import dist as mdist
+    sizes = mdist.SizeExchange(td.group.WORLD)(RAGGED[world][rank])
+    assert sizes == RAGGED[world]
+    mdist.set_step_sizes(sizes)
+    P, T = 32, 0.7
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(77)
+    es_all = torch.nn.functional.layer_norm(torch.randn(n, P, generator=g), (P,)).bfloat16().float()
+    ei_all = torch.nn.functional.layer_norm(torch.randn(n, P, generator=g), (P,)).bfloat16().float()
+    o = sum(sizes[:rank])
+    sl = slice(o, o + sizes[rank])
+    le, d_es, d_ei, s_rows = mdist.dist_infonce_fwd_bwd(es_all[sl].clone(), ei_all[sl].clone(), T, td.group.WORLD,
+                                                        prims=OraclePrims)
+    lf, f_es, f_ei, _ = mdist.dist_infonce_fused_fwd_bwd(es_all[sl].clone(), ei_all[sl].clone(), T, td.group.WORLD,
+                                                         prims=OracleFusedPrims)
+    g2 = torch.Generator().manual_seed(100 + rank)
+    dout = torch.randn(sizes[rank], 11, generator=g2)
+    ix = torch.randint(0, 9, (sizes[rank],), generator=g2, dtype=torch.int32)
+    iy = torch.randint(0, 9, (sizes[rank],), generator=g2, dtype=torch.int32)
+    G, X, Y = mdist.gather_rows(dout, ix, iy, td.group.WORLD)
+    mdist.set_step_sizes(None)
+    return le.item(), d_es, d_ei, lf.item(), f_es, f_ei, (dout, ix, iy, G, X, Y)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ragged_shards_equal_single_process(world):
+    outs = _spawn(_ragged_case, world)
+    sizes = RAGGED[world]
+    P, T = 32, 0.7
+    n = sum(sizes)
+    g = torch.Generator().manual_seed(77)
+    es = torch.nn.functional.layer_norm(torch.randn(n, P, generator=g), (P,)).bfloat16().float().requires_grad_(True)
+    ei = torch.nn.functional.layer_norm(torch.randn(n, P, generator=g), (P,)).bfloat16().float().requires_grad_(True)
+    loss = ref_cpu.symmetric_infonce(ref_cpu.logits(es, ei, T))
+    loss.backward()
+    dcat = torch.cat([o[6][0] for o in outs]); xcat = torch.cat([o[6][1] for o in outs]); ycat = torch.cat([o[6][2] for o in outs])
+    for r, (le, d_es, d_ei, lf, f_es, f_ei, rows) in enumerate(outs):
+        o = sum(sizes[:r])
+        sl = slice(o, o + sizes[r])
+        assert abs(le - loss.item()) < 1e-5 and abs(lf - loss.item()) < 1e-5
+        assert torch.allclose(d_es, es.grad[sl], atol=2e-6) and torch.allclose(d_ei, ei.grad[sl], atol=2e-6)
+        assert torch.allclose(f_es, es.grad[sl], atol=2e-6) and torch.allclose(f_ei, ei.grad[sl], atol=2e-6)
+        assert torch.equal(rows[3], dcat) and torch.equal(rows[4], xcat) and torch.equal(rows[5], ycat)
+
+
+def _bad_sizes_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    try:
+        mdist._all_gather_rows(torch.zeros(3, 2), td.group.WORLD, sizes=[4, 4])
+    except RuntimeError as e:
+        return str(e)
+    return ""
+
+
+def test_ragged_all_gather_rejects_wrong_sizes():
+    for msg in _spawn(_bad_sizes_case, 2):
+        assert "ragged all-gather" in msg
+
+
 class _FakeFlatOpt:
     """Stands in for FusedAdam's flat-bucket interface (its step() needs the GPU)."""
 

@@ -95,6 +95,64 @@ def test_two_rank_dp_step_on_one_gpu():
     assert torch.equal(ret[0]["xrows"], ret[1]["xrows"])
 
 
+def _ragged_worker(rank, world, port, ret):
+    """3 DP steps through engine.TrainStep: steps 1-2 equal shards, step 3 ragged (rank 0: 8 pairs, rank 1: 5), with
+    per-rank DIFFERENT duplicate positions (several pairs of a rank hit the same table row; both ranks also share a
+    row)."""
+    import torch.distributed as td
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", MCL_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mclstexp_amd import dist as mdist, synth
+        from mclstexp_amd.engine import TrainStep
+        from mclstexp_amd.model import mclSTExp_Attention
+        from mclstexp_amd.optim import FusedAdam
+        pg = td.group.WORLD
+        G, D = 171, 1024
+        m = mclSTExp_Attention("identity", 1.0, D, G, 256, 8, 64, 2, embedding_grad="rowsparse", process_group=pg)
+        m.load_state_dict(synth.make_params(G, D, seed=0))
+        m.cuda().train()
+        m.capture = True
+        opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
+        tr = TrainStep(m, opt, mdist.GradReducer(pg), graphs=False)
+        losses, embs = [], []
+        for step, sizes in enumerate([(8, 8), (8, 8), (8, 5)]):
+            b = synth.make_batch(sizes[rank], G, image_dim=D, seed=step, rank=rank)
+            pos = b["position"]
+            pos[: 3 + rank, 0] = 7.0 + rank          # duplicates inside the rank (different count / row per rank)
+            pos[-1, 0] = 21.0                        # one row shared by both ranks
+            pos[:2, 1] = 3.0
+            losses.append(tr({k: v.cuda() for k, v in b.items()}).item())
+            embs.append((m.last["spot_embeddings"].cpu(), m.last["image_embeddings"].cpu()))
+        ret[rank] = dict(losses=losses, embs=embs, sizes=mdist.step_sizes(),
+                         params={n: p.detach().cpu() for n, p in m.named_parameters() if "embed" not in n},
+                         xrows=m.x_embed.weight.detach()[:64].cpu(), yrows=m.y_embed.weight.detach()[:64].cpu(),
+                         far=m.x_embed.weight.detach()[60000].cpu())
+    finally:
+        td.destroy_process_group()
+
+
+def test_ragged_dp_steps_keep_replicas_identical():
+    from oracle import ref_cpu
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ragged_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    a, b = ret[0], ret[1]
+    assert a["sizes"] == [8, 5] and b["sizes"] == [8, 5]          # the ragged step's agreed shard sizes
+    assert a["losses"] == b["losses"]                              # identical global loss on both ranks, every step
+    for step in range(3):
+        es = torch.cat([a["embs"][step][0], b["embs"][step][0]]).double()
+        ei = torch.cat([a["embs"][step][1], b["embs"][step][1]]).double()
+        ref = ref_cpu.symmetric_infonce(ref_cpu.logits(es, ei, 1.0)).item()
+        assert abs(a["losses"][step] - ref) < 1e-4, (step, a["losses"][step], ref)   # global InfoNCE over 16 / 13 pairs
+    for n in a["params"]:
+        assert torch.equal(a["params"][n], b["params"][n]), n      # replicas bit-identical after 3 steps
+    assert torch.equal(a["xrows"], b["xrows"]) and torch.equal(a["yrows"], b["yrows"]) and torch.equal(a["far"], b["far"])
+
+
 def _rccl_worker(_index, port, ret):
     """Size-1 RCCL group: the full data-parallel step (bf16 embedding all-gather, LSE all-gather, async flat
     all-reduce, gathered table rows, HIP-graph replay around the collectives) on the REAL nccl backend."""
