@@ -228,6 +228,14 @@ int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z, int64_t S
                           const float* gamma, const float* beta, const float* mean, const float* rstd, float* dW,
                           mcl_stream_t stream);
 
+/* Atomics-free form of mcl_dense_conv3x3_wrw: every workgroup stores its fp32 partial (32 x 1152) in the workspace and
+ * a merge launch adds the partials in fixed order -> dW (accumulate_w != 0: +=).  Bit-reproducible.
+ * workspace: mcl_dense_conv3x3_wrw_workspace_floats(S) floats.                                                  */
+int64_t mcl_dense_conv3x3_wrw_workspace_floats(int64_t S);
+int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
+                              const float* gamma, const float* beta, const float* mean, const float* rstd,
+                              float* workspace, float* dW, int32_t accumulate_w, mcl_stream_t stream);
+
 /* Backward of a dense layer's head x -> norm1 -> relu1 -> conv1 (1x1) -> z with respect to x, fused (csrc/dense_bwd.hip):
  *   da = dz W1 ; g = da*[bn1(x) > 0] ; dgamma (+)= sum g*xhat ; dbeta (+)= sum g ;
  *   gbuf[s, :C] += gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))
@@ -240,6 +248,26 @@ int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, const void* x, 
                       const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
                       float* dgamma, float* dbeta, int32_t accumulate_params, void* gbuf, int64_t ldg,
                       mcl_stream_t stream);
+
+/* Deterministic replacement of the reduce launch of mcl_dense_bn1_bwd AND of the bottleneck weight gradient
+ * (csrc/wrw_fused.hip): one pass over (dz, x) forms the Gram matrices R = dz^T mask and Qx = dz^T (mask*x) and from
+ * them  dW1 (+)= dz^T relu(bn1(x))  [accumulate_w != 0: += into the parameter's fp32 .grad (128, C) contiguous],
+ * dgamma / dbeta (+)= the BatchNorm-backward sums, and coef_out[2c] = mean(g), coef_out[2c+1] = mean(g*xhat) for
+ * mcl_dense_bn1_dx.  Slab partials go through the workspace and are merged in fixed order: no atomics,
+ * bit-reproducible.  Same operand layouts as mcl_dense_bn1_bwd.  workspace: mcl_wrw_workspace_floats(S, 128, C). */
+int64_t mcl_wrw_workspace_floats(int64_t S, int32_t M, int32_t N);
+int mcl_dense_bn1_wrw(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                      const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
+                      float* dW, int32_t accumulate_w, float* dgamma, float* dbeta, int32_t accumulate_params,
+                      float* coef_out, mcl_stream_t stream);
+/* The dx pass of mcl_dense_bn1_bwd alone, with the two per-channel means supplied (coef: 2*C floats).       */
+int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                     const float* gamma, const float* beta, const float* mean, const float* rstd, const float* coef,
+                     void* gbuf, int64_t ldg, mcl_stream_t stream);
+/* Plain deterministic 1x1 weight gradient dW[M][N] (+)= dz[S][M]^T a[S][N] (transition convolutions): the
+ * atomics-free form of mcl_conv1x1_wrw_bf16 without prologue.  workspace: mcl_wrw_workspace_floats(S, min(M,128), N). */
+int mcl_conv1x1_wrw_det(const void* dz, int64_t ldz, const void* a, int64_t lda, float* workspace, float* dW,
+                        int32_t accumulate_w, int64_t S, int32_t M, int32_t N, mcl_stream_t stream);
 
 /* Backward of a dense layer's tail z -> norm2 -> relu2 -> conv2 (3x3, pad 1, 128 -> 32) with respect to z, fused:
  *   da2 = conv3x3 backward-data of dy ; g2 = da2*[bn2(z) > 0] ; dgamma2 (+)= sum g2*zhat ; dbeta2 (+)= sum g2 ;
@@ -286,9 +314,13 @@ int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* x, int64_t 
 int64_t mcl_conv0_workspace_floats(int32_t N, int32_t H, int32_t W);
 int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, const void* Wt, void* y, float* workspace, float eps,
                   float* mean, float* var, float* rstd, mcl_stream_t stream);
-/* Weight gradient of conv0: dW (64,7,7,3) fp32 (the channels-last parameter's .grad) += sum_p dy[p] (x) patch(x)[p],
- * ACCUMULATED with float atomics.  dy: (N,H/2,W/2,64) bf16 NHWC contiguous.  H % 4 == 0, W % 32 == 0, W <= 256.  */
-int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* dW, mcl_stream_t stream);
+/* Weight gradient of conv0: dW (64,7,7,3) fp32 (the channels-last parameter's .grad) (+)= sum_p dy[p] (x) patch(x)[p].
+ * dy: (N,H/2,W/2,64) bf16 NHWC contiguous.  H % 4 == 0, W % 8 == 0, W <= 256.  workspace != NULL
+ * (mcl_conv0_wrw_workspace_floats floats): deterministic -- per-workgroup partials merged in fixed order,
+ * accumulate_w != 0 adds into dW, else overwrites.  workspace == NULL: round-1 form, fp32 atomics (+= only).      */
+int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W);
+int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* workspace, float* dW,
+                  int32_t accumulate_w, mcl_stream_t stream);
 
 /* DenseNet stem tail norm0 -> relu0 -> pool0 (MaxPool2d(3, 2, 1)) in one pass over the conv0 output x (N,H,W,C) bf16
  * NHWC contiguous: y (N,OH,OW,C) = maxpool(relu(bn(x))), idx = arg-max byte per pooled element (ky*3+kx, first maximum

@@ -83,6 +83,12 @@ PROTOTYPES = {
     "mcl_maxpool3s2_nhwc_bf16_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_dense_conv3x3_bwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "mcl_dense_bn1_bwd": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
+    "mcl_dense_conv3x3_wrw_workspace_floats": [c_l],
+    "mcl_dense_conv3x3_wrw_det": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
+    "mcl_wrw_workspace_floats": [c_l, c_i, c_i],
+    "mcl_dense_bn1_wrw": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p],
+    "mcl_dense_bn1_dx": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "mcl_conv1x1_wrw_det": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_l, c_i, c_i, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
@@ -93,7 +99,8 @@ PROTOTYPES = {
                                c_p],
     "mcl_conv0_workspace_floats": [c_i, c_i, c_i],
     "mcl_conv0_fwd": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p],
-    "mcl_conv0_wrw": [c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "mcl_conv0_wrw_workspace_floats": [c_i, c_i, c_i],
+    "mcl_conv0_wrw": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p],
     "mcl_bn_act_maxpool_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_patch_gather": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_f, c_p, c_p, c_p],
     "mcl_log_library_size_normalize": [c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
@@ -105,7 +112,9 @@ PROTOTYPES = {
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64,
-             "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64}
+             "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64,
+             "mcl_wrw_workspace_floats": C.c_int64, "mcl_dense_conv3x3_wrw_workspace_floats": C.c_int64,
+             "mcl_conv0_wrw_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

@@ -244,11 +244,14 @@ __global__ __launch_bounds__(NTH) void act_avgpool_fwd_kernel(const T* __restric
 
 // POOL: dy is the gradient of the 2x2-average-pooled activation (rows = pooled pixels); the gradient reaching
 // pixel r of the (n, H, W) map is dy[pooled(r)] / 4 (transition: norm -> relu -> avgpool, see bn_act_avgpool_fwd)
+// Odd H / W (nn.AvgPool2d floors: the last row / column of the map belongs to no window): -1, the pixel receives no
+// gradient through the pool (its BatchNorm-backward terms are still applied: the statistics cover every pixel).
 __device__ __forceinline__ long long pooled_row(long long r, int H, int W) {
   const int xw = (int)(r % W);
   const long long t = r / W;
   const int yh = (int)(t % H);
   const long long n = t / H;
+  if ((xw >> 1) >= (W >> 1) || (yh >> 1) >= (H >> 1)) return -1;
   return (n * (H >> 1) + (yh >> 1)) * (W >> 1) + (xw >> 1);
 }
 
@@ -289,10 +292,11 @@ __global__ __launch_bounds__(NTH) void act_bwd_reduce_kernel(const T* __restrict
     for (long long r = r0 + rloc; r < r1; r += rpi) {
       float f[V], g[V];
       Vec<T>::load(x + r * ldx + (long long)cv * V, f);
-      Vec<T>::load(dy + (POOL ? pooled_row(r, H, W) : r) * lddy + (long long)cv * V, g);
+      const long long pr = POOL ? pooled_row(r, H, W) : r;
+      if (pr >= 0) Vec<T>::load(dy + pr * lddy + (long long)cv * V, g);
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        if (POOL) g[i] *= 0.25f;
+        if (POOL) g[i] = pr >= 0 ? g[i] * 0.25f : 0.0f;
         const float gi = (relu && fmaf(f[i], sc[i], sh[i]) <= 0.0f) ? 0.0f : g[i];
         s1[i] += gi;
         s2[i] = fmaf(gi, (f[i] - mu[i]) * rs[i], s2[i]);
@@ -375,11 +379,12 @@ __global__ __launch_bounds__(NTH) void act_bwd_dx_kernel(const T* __restrict__ d
   for (long long r = r0 + rloc; r < r1; r += rpi) {
     float f[V], g[V], o[V];
     Vec<T>::load(x + r * ldx + (long long)cv * V, f);
-    Vec<T>::load(dy + (POOL ? pooled_row(r, H, W) : r) * lddy + (long long)cv * V, g);
+    const long long pr = POOL ? pooled_row(r, H, W) : r;
+    if (pr >= 0) Vec<T>::load(dy + pr * lddy + (long long)cv * V, g);
     if (accumulate) Vec<T>::load(dx + r * lddx + (long long)cv * V, o);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      if (POOL) g[i] *= 0.25f;
+      if (POOL) g[i] = pr >= 0 ? g[i] * 0.25f : 0.0f;
       const float gi = (relu && fmaf(f[i], sc[i], sh[i]) <= 0.0f) ? 0.0f : g[i];
       const float xh = (f[i] - mu[i]) * rs[i];
       const float d = sc[i] * (gi - c1[i] - xh * c2[i]);
@@ -520,7 +525,7 @@ extern "C" int mcl_bn_act_avgpool_fwd(const void* x, int64_t ldx, int32_t N, int
                                       void* y, int64_t ldy, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!gamma || !beta || !mean || !rstd || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
-  if ((H & 1) || (W & 1) || !ok_layout(x, ldx, C, 1) || !ok_layout(y, ldy, C, 1)) return MCL_EUNSUPPORTED;
+  if (H < 2 || W < 2 || !ok_layout(x, ldx, C, 1) || !ok_layout(y, ldy, C, 1)) return MCL_EUNSUPPORTED;
   const long long SP = (long long)N * (H / 2) * (W / 2);
   int nblk, rpb, tiles;
   plan(SP, C, 1, &nblk, &rpb, &tiles);
@@ -538,7 +543,7 @@ extern "C" int mcl_bn_act_avgpool_bwd(const void* dp, int64_t lddp, const void* 
   MCL_CLEAR_ERROR();
   if (!gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || N <= 0 || H <= 0 || W <= 0 || C <= 0)
     return MCL_EINVAL;
-  if ((H & 1) || (W & 1) || !ok_layout(dp, lddp, C, 1) || !ok_layout(x, ldx, C, 1) || !ok_layout(dx, lddx, C, 1))
+  if (H < 2 || W < 2 || !ok_layout(dp, lddp, C, 1) || !ok_layout(x, ldx, C, 1) || !ok_layout(dx, lddx, C, 1))
     return MCL_EUNSUPPORTED;
   const long long S = (long long)N * H * W;
   int nblk, rpb, tiles;

@@ -36,3 +36,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// csrc/wrw_fused.hip: dW[e] (+)= sum_{z < ks} wpart[z*MN + e] in fixed order (deterministic merge of per-workgroup
+// weight-gradient partials); MN a multiple of 4, all pointers 16-byte aligned.  Enqueue only.
+void mcl_launch_wrw_merge(const float* wpart, int ks, long long MN, float* dW, int accumulate_w, hipStream_t st);

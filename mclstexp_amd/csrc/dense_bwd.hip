@@ -482,6 +482,27 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   return MCL_OK;
 }
 
+// dx pass alone: gbuf += gamma*rstd*(g - coef[2c] - xhat*coef[2c+1]),  g = relu'(.)*(dz W1), with the two means per channel
+// supplied by the caller (mcl_dense_bn1_wrw derives them from the weight-gradient Gram matrices: no reduce launch).
+extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                                const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                const float* coef, void* gbuf, int64_t ldg, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !coef || !gbuf || S <= 0 || C <= 0) return MCL_EINVAL;
+  if ((C % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
+      (reinterpret_cast<uintptr_t>(W1) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(gbuf) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
+  int gx = (768 + nct - 1) / nct;
+  if (gx > nrt) gx = nrt;
+  hipLaunchKernelGGL((bn1_bwd_kernel<1, 64>), dim3(gx, nct), dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
+                     (const bf16_t*)W1, C, (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, coef,
+                     (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr, nrt);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
 extern "C" int64_t mcl_dense_conv3x3_bwd_workspace_floats(int64_t S) {
   if (S <= 0) return -1;
   return ((S + T3B - 1) / T3B) * 2 * (int64_t)C3I + 2 * (int64_t)C3I;

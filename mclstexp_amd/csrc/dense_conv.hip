@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_kernel(const bf16_t* __res
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ dW,
-                                                             int ntile) {
+                                                             int ntile, float* __restrict__ wpart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   typedef short v4s __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -684,14 +684,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_kernel(const bf16_t* __res
       }
     }
   }
-  // dW[co][n] += acc: co = (r&3) + 8*(r>>2) + 4*h, n = 32*nb + l31 of the 1152-wide row
+  // acc[b][r] is element co = (r&3) + 8*(r>>2) + 4*h, n = 32*nb + l31 of the 1152-wide row.  Deterministic form
+  // (wpart != nullptr): this workgroup's fp32 partial goes to its own workspace slot with plain stores and a merge
+  // launch adds the slots in fixed order; round-1 form: hardware float atomics straight into dW.
+  float* dst = wpart ? wpart + (long long)blockIdx.x * (C3_OUT * 9 * C3_IN) : dW;
 #pragma unroll
   for (int b = 0; b < 9; ++b) {
     const int n = 32 * (9 * wave + b) + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-      unsafeAtomicAdd(dW + co * (9 * C3_IN) + n, acc[b][r]);
+      if (wpart) dst[co * (9 * C3_IN) + n] = acc[b][r];
+      else unsafeAtomicAdd(dst + co * (9 * C3_IN) + n, acc[b][r]);
     }
   }
 }
@@ -717,7 +721,46 @@ extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z
   const int gmax = S >= 200000 ? 512 : (S >= 50000 ? 192 : 128);
   const int grid = ntile < gmax ? ntile : gmax;
   hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(grid), dim3(256), lds_bytes, mcl_stream(stream), (const bf16_t*)dy,
-                     (long long)lddy, (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile);
+                     (long long)lddy, (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile,
+                     (float*)nullptr);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+// Deterministic form: per-workgroup fp32 partials (32 x 1152 each) in the workspace + a fixed-order merge launch.
+static inline int wrw3_grid(int64_t S, int ntile) {
+  // one partial of 147 KB per workgroup is written and re-read by the merge: fewer, longer pixel ranges on the small maps
+  const int gmax = S >= 200000 ? 256 : (S >= 50000 ? 128 : 64);
+  return ntile < gmax ? ntile : gmax;
+}
+
+extern "C" int64_t mcl_dense_conv3x3_wrw_workspace_floats(int64_t S) {
+  if (S <= 0) return -1;
+  return (int64_t)wrw3_grid(S, (int)((S + T3 - 1) / T3)) * (C3_OUT * 9 * C3_IN);
+}
+
+extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
+                                         const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                         float* workspace, float* dW, int32_t accumulate_w, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dy || !z || !gamma || !beta || !mean || !rstd || !dW || !workspace || S <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
+  if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (lddy % 8) || lddy < C3_OUT || (reinterpret_cast<uintptr_t>(dy) & 15u) ||
+      (reinterpret_cast<uintptr_t>(z) & 15u) || (reinterpret_cast<uintptr_t>(dW) & 15u) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int ntile = (int)((S + T3 - 1) / T3);
+  const size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256 + T3 * 64 + (T3 + 2 * W + 2) * 2 + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wrw_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_set = true;
+  }
+  const int grid = wrw3_grid(S, ntile);
+  hipStream_t st = mcl_stream(stream);
+  hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)dy, (long long)lddy,
+                     (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile, workspace);
+  mcl_launch_wrw_merge(workspace, grid, (long long)C3_OUT * 9 * C3_IN, dW, accumulate_w, st);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
@@ -861,14 +904,17 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
 // tiles and input slab as the forward; dy is staged TRANSPOSED ([co][pixel]) so that an A fragment (8 consecutive pixels
 // of one channel) is one ds_read_b128; a B fragment (8 consecutive pixels of one k column) is 8 strided 2-byte reads of
 // the slab (12 bytes apart).  Wave w owns co tile w & 1 and k tiles 3 (w >> 1) .. + 2; accumulators persist over the
-// workgroup's tiles.  Needs OW % 16 == 0 (a 16-pixel k-step must not straddle output rows).
+// workgroup's tiles.  Each output row of the tile is padded to a multiple of 16 pixels in the transposed dy tile (zero
+// columns: a 16-pixel k-step never straddles output rows, and OW = 56 -- 112-pixel her2st patches -- works).
+// wpart != nullptr: deterministic form, the workgroup's fp32 partial (64 x 7 x 21) goes to its workspace slot.
 __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
                                                            const bf16_t* __restrict__ dy, float* __restrict__ dW,
-                                                           int ntile) {
+                                                           int ntile, float* __restrict__ wpart) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int OH = H >> 1, OW = W >> 1;
   const int PW = (W + 6) * 3 + 8;
-  const int npix = 2 * OW, PP = npix + 8;
+  const int OWp = (OW + 15) & ~15;
+  const int npix = 2 * OW, PP = 2 * OWp + 8;
   bf16_t* slab = reinterpret_cast<bf16_t*>(lds);
   const int slab_bytes = (9 * PW * 2 + 15) & ~15;
   bf16_t* dyT = reinterpret_cast<bf16_t*>(lds + slab_bytes);                 // [64][PP]
@@ -890,6 +936,9 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+  // the pad columns of the transposed dy tile stay zero for every tile
+  for (int i = tid; i < (C0_OUT * PP * 2) / 16; i += 256)
+    reinterpret_cast<uint4*>(lds + slab_bytes)[i] = make_uint4(0u, 0u, 0u, 0u);
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int n = tile / (OH >> 1), oy0 = (tile % (OH >> 1)) * 2;
     __syncthreads();
@@ -898,12 +947,13 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
     const bf16_t* dyo = dy + ((long long)(n * OH + oy0) * OW) * C0_OUT;
     for (int c = tid; c < npix * 8; c += 256) {
       const int px = c >> 3, c8 = c & 7;
+      const int pc = px < OW ? px : px - OW + OWp;            // column in the padded [2][OWp] pixel layout
       const uint4 v = reinterpret_cast<const uint4*>(dyo)[c];
       const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        dyT[(c8 * 8 + 2 * i) * PP + px] = (bf16_t)(wv[i] & 0xFFFFu);
-        dyT[(c8 * 8 + 2 * i + 1) * PP + px] = (bf16_t)(wv[i] >> 16);
+        dyT[(c8 * 8 + 2 * i) * PP + pc] = (bf16_t)(wv[i] & 0xFFFFu);
+        dyT[(c8 * 8 + 2 * i + 1) * PP + pc] = (bf16_t)(wv[i] >> 16);
       }
     }
     __syncthreads();
@@ -924,8 +974,8 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
     }
     __syncthreads();
 
-    for (int p0 = 0; p0 < npix; p0 += 16) {              // k-step: pixels p0 .. p0 + 15 of one output row
-      const int rr = p0 / OW, ox0 = p0 - rr * OW;
+    for (int p0 = 0; p0 < 2 * OWp; p0 += 16) {           // k-step: (padded) pixels p0 .. p0 + 15 of one output row
+      const int rr = p0 / OWp, ox0 = p0 - rr * OWp;
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(dyT + (mt * 32 + l31) * PP + p0 + 8 * h);
       const bf16_t* brow = slab + (2 * rr) * PW + 6 * (ox0 + 8 * h);
 #pragma unroll
@@ -944,10 +994,12 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
     if (!kval[t]) continue;
     const int k = (kt0 + t) * 32 + l31;
     const int ky = k / C0_KP, j = k % C0_KP;
+    float* dst = wpart ? wpart + (long long)blockIdx.x * (C0_OUT * C0_K * 21) : dW;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      unsafeAtomicAdd(dW + (co * C0_K + ky) * 21 + j, acc[t][r]);
+      if (wpart) dst[(co * C0_K + ky) * 21 + j] = acc[t][r];
+      else unsafeAtomicAdd(dst + (co * C0_K + ky) * 21 + j, acc[t][r]);
     }
   }
 }
@@ -992,24 +1044,42 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
   return MCL_OK;
 }
 
-extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* dW,
-                             mcl_stream_t stream) {
+// workspace == nullptr: round-1 form (fp32 atomics into dW).  Otherwise deterministic: per-workgroup partials in the
+// workspace (mcl_conv0_wrw_workspace_floats floats) + a fixed-order merge launch; accumulate_w != 0 adds into dW.
+extern "C" int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W) {
+  if (N <= 0 || H <= 0 || W <= 0) return -1;
+  const int ntile = N * (H / 4);
+  return (int64_t)(ntile < 256 ? ntile : 256) * (C0_OUT * C0_K * 21);
+}
+
+extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* workspace, float* dW,
+                             int32_t accumulate_w, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!x || !dy || !dW || N <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
-  if ((H % 4) || (W % 32) || W > 256 || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(dy) & 15u))
-    return MCL_EUNSUPPORTED;                             // W % 32: a 16-pixel k-step stays inside one output row
-  const int OH = H / 2, OW = W / 2;
+  if ((H % 4) || (W % 8) || W > 256 || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(dy) & 15u) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(dW) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int OH = H / 2, OW = W / 2, OWp = (OW + 15) & ~15;
   const int ntile = N * (OH / 2);
   const int PW = (W + 6) * 3 + 8;
-  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + (size_t)C0_OUT * (2 * OW + 8) * 2;
+  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + (size_t)C0_OUT * (2 * OWp + 8) * 2;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wrw_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv0_wrw_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, mcl_stream(stream),
-                     (const bf16_t*)x, N, H, W, (const bf16_t*)dy, dW, ntile);
+  hipStream_t st = mcl_stream(stream);
+  if (!workspace) {
+    if (!accumulate_w) return MCL_EINVAL;
+    hipLaunchKernelGGL(conv0_wrw_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H,
+                       W, (const bf16_t*)dy, dW, ntile, (float*)nullptr);
+  } else {
+    const int grid = ntile < 256 ? ntile : 256;
+    hipLaunchKernelGGL(conv0_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H, W,
+                       (const bf16_t*)dy, dW, ntile, workspace);
+    mcl_launch_wrw_merge(workspace, grid, (long long)C0_OUT * C0_K * 21, dW, accumulate_w, st);
+  }
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -281,6 +281,40 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
     return (None, None) if into_param_grads else (dg, db)
 
 
+# Deterministic fusion of the bottleneck weight gradient with the BatchNorm-backward reduction (csrc/wrw_fused.hip): one
+# pass over (dz, x) replaces conv1x1_wrw (fp32 atomics) + the reduce launch + its finalize; then the dx pass alone.
+USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "1") != "0"
+
+
+def _bn1_wrw_ok(w_param: Tensor) -> bool:
+    return (USE_FUSED_BN1_WRW and DIRECT_PARAM_GRADS and _direct_grad_ok(w_param) and w_param.grad.is_contiguous()
+            and w_param.shape[0] == 128 and w_param.shape[2:] == (1, 1))
+
+
+def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
+                     w_param: Tensor, into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """w_param.grad += dz^T relu(bn1(x)); norm1 parameter gradients; gbuf += d loss / d x -- two C-ABI calls
+    (mcl_dense_bn1_wrw: Gram partials + fixed-order merge; mcl_dense_bn1_dx)."""
+    px, S, C, ldx = _rows(x)
+    pg, S2, C2, ldg = _rows(gbuf)
+    assert (S2, C2) == (S, C) and dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128
+    L = _lib.lib()
+    ws = _ws(L.mcl_wrw_workspace_floats(S, 128, C), x.device)
+    if into_param_grads:
+        dg, db = g1.grad, b1.grad
+    else:
+        dg = torch.empty(C, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32)
+    coef = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+    check(L.mcl_dense_bn1_wrw(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
+                              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), w_param.grad.data_ptr(), 1,
+                              dg.data_ptr(), db.data_ptr(), int(into_param_grads), coef.data_ptr(), _stream()),
+          "mcl_dense_bn1_wrw")
+    check(L.mcl_dense_bn1_dx(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
+                             mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), pg, ldg, _stream()), "mcl_dense_bn1_dx")
+    return (None, None) if into_param_grads else (dg, db)
+
+
 # conv2 (3x3) backward-data + norm2/relu2 backward (csrc/dense_bwd.hip): dy is read in place from the gradient buffer
 USE_FUSED_BN2_BWD = os.environ.get("MCL_FUSED_BN2_BWD", "1") != "0"
 
@@ -335,8 +369,16 @@ def dense_conv3x3_wrw(dy: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor,
     B, C, H, W = z.shape
     pd, S, Co, lddy = _rows(dy)
     assert Co == 32 and S == B * H * W
-    check(_lib.lib().mcl_dense_conv3x3_wrw(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(),
-                                           m2.data_ptr(), r2.data_ptr(), w_param.grad.data_ptr(), _stream()),
+    L = _lib.lib()
+    if USE_DET_WRW:
+        # the side stream has its own workspace (keyed by stream in _ws): no aliasing with the main chain's
+        ws = _ws(L.mcl_dense_conv3x3_wrw_workspace_floats(S), z.device)
+        check(L.mcl_dense_conv3x3_wrw_det(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(), m2.data_ptr(),
+                                          r2.data_ptr(), ws.data_ptr(), w_param.grad.data_ptr(), 1, _stream()),
+              "mcl_dense_conv3x3_wrw_det")
+        return True
+    check(L.mcl_dense_conv3x3_wrw(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(),
+                                  m2.data_ptr(), r2.data_ptr(), w_param.grad.data_ptr(), _stream()),
           "mcl_dense_conv3x3_wrw")
     return True
 
@@ -364,6 +406,9 @@ def _fused_1x1_ok(x: Tensor, w16: Tensor) -> bool:
             and w16.permute(0, 2, 3, 1).is_contiguous())
 
 
+USE_DET_WRW = os.environ.get("MCL_DET_WRW", "1") != "0"      # atomics-free weight-gradient kernels (A/B: 0 = round-1 atomics)
+
+
 def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Tensor]:
     """Weight gradient of a 1x1 convolution through csrc/conv1x1.hip.  Adds straight into ``w_param.grad``
     when it is a dense fp32 tensor (returns None), else returns a fresh fp32 gradient.  ``bn`` = (gamma, beta,
@@ -376,6 +421,12 @@ def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Ten
     else:
         tgt = torch.zeros((M, N, 1, 1), device=dz.device, dtype=torch.float32)
         ret = tgt
+    if bn is None and USE_DET_WRW:
+        L = _lib.lib()
+        ws = _ws(L.mcl_wrw_workspace_floats(S, min(M, 128), N), dz.device)
+        check(L.mcl_conv1x1_wrw_det(pz, ldz, pa, lda, ws.data_ptr(), tgt.data_ptr(), 1, S, M, N, _stream()),
+              "mcl_conv1x1_wrw_det")
+        return ret
     g_, b_, m_, r_ = (t.data_ptr() for t in bn) if bn is not None else (None, None, None, None)
     check(_lib.lib().mcl_conv1x1_wrw_bf16(pz, ldz, pa, lda, g_, b_, m_, r_, tgt.data_ptr(), N, S, M, N, _stream()),
           "mcl_conv1x1_wrw_bf16")
@@ -583,12 +634,21 @@ class DenseBlockFn(torch.autograd.Function):
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 ev = torch.cuda.Event()
                 ev.record(main)
-                dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
-                                         gbuf[:, :cin], into_param_grads=d1)
+                fused_wrw = _bn1_wrw_ok(w1)
+                if fused_wrw:
+                    # the bottleneck weight gradient rides on the BatchNorm-backward reduction (one pass over dz, x;
+                    # no atomics): it is part of the main chain now, only the 3x3 weight gradient forks off
+                    dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                                gbuf[:, :cin], w1, into_param_grads=d1)
+                    gw1 = None
+                else:
+                    dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                             gbuf[:, :cin], into_param_grads=d1)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
-                    gw1 = conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
+                    if not fused_wrw:
+                        gw1 = conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
                 _side_park(z.device, dz, gbuf, z, buf)
                 grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None]
                 continue
@@ -620,6 +680,14 @@ class DenseBlockFn(torch.autograd.Function):
                 # fused forward: nothing of norm1's output was kept.  Weight gradient with BN1+ReLU recomputed from the
                 # concat buffer; data gradient + BN1 backward without materialising da
                 bn1 = (g1, b1, stats.mean[:cin], stats.rstd[:cin])
+                if _bn1_wrw_ok(w1):
+                    dw1 = ("direct", None)
+                    dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                                gbuf[:, :cin], w1, into_param_grads=d1)
+                    if side is not None:
+                        main.wait_stream(side)
+                    grads[6 * l: 6 * l + 6] = [dg1, db1, None, dg2, db2, None if dw2_done else _wgrad(w2, dw2)]
+                    continue
                 if side is not None and dw2_done:
                     side.wait_stream(main)                      # dz is ready
                     with torch.cuda.stream(side):
@@ -724,10 +792,12 @@ class Conv0Fn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=CL)
         w = ctx.w
         B, _, H, W = x.shape
-        if (DIRECT_PARAM_GRADS and _direct_grad_ok(w) and w.grad.permute(0, 2, 3, 1).is_contiguous() and W % 32 == 0
+        if (DIRECT_PARAM_GRADS and _direct_grad_ok(w) and w.grad.permute(0, 2, 3, 1).is_contiguous()
                 and dy.dtype == torch.bfloat16):
-            check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), w.grad.data_ptr(), _stream()),
-                  "mcl_conv0_wrw")                       # straight into the parameter's fp32 .grad
+            L = _lib.lib()
+            ws = _ws(L.mcl_conv0_wrw_workspace_floats(B, H, W), x.device) if USE_DET_WRW else None
+            check(L.mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), None if ws is None else ws.data_ptr(),
+                                  w.grad.data_ptr(), 1, _stream()), "mcl_conv0_wrw")   # straight into the fp32 .grad
             return None, None, None
         _fallback("conv0_wrw:miopen")
         dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
@@ -887,8 +957,9 @@ def pooled_conv1x1_fwd(p: Tensor, w16: Tensor, eps: float, stats: Optional[_Bloc
 
 def _transition_ok(buf: Tensor, w: Tensor) -> bool:
     B, C, H, W = buf.shape
-    return (USE_FUSED_TRANSITION and USE_FUSED_1X1 and buf.is_cuda and buf.dtype == torch.bfloat16 and H % 2 == 0
-            and W % 2 == 0 and C % 8 == 0 and C <= 1024 and w.shape[0] % 128 == 0 and w.shape[1] == C
+    # odd maps (her2st: 112 px patches reach 7 x 7 at the last transition) pool with floor, like nn.AvgPool2d(2, 2)
+    return (USE_FUSED_TRANSITION and USE_FUSED_1X1 and buf.is_cuda and buf.dtype == torch.bfloat16 and H >= 2
+            and W >= 2 and C % 8 == 0 and C <= 1024 and w.shape[0] % 128 == 0 and w.shape[1] == C
             and buf.is_contiguous(memory_format=CL))
 
 

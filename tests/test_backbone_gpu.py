@@ -396,6 +396,17 @@ def test_dense_conv3x3_wrw_fused(B, H, W, lddy):
     y.backward(dy.double().reshape(B, H, W, 32).permute(0, 3, 1, 2))
     ref = w.grad.permute(0, 2, 3, 1) + 0.125
     assert_close_scaled(dW.cpu(), ref.cpu(), 1e-4, what="fused conv3x3 weight gradient")   # fp32 atomics over <= 512 partials
+    # atomics-free form: per-workgroup partials + fixed-order merge; same values, bit-reproducible
+    L = _lib.lib()
+    ws = torch.empty(L.mcl_dense_conv3x3_wrw_workspace_floats(S), device=DEV)
+    outs = []
+    for acc in (1, 0, 1):
+        dWd = torch.full((32, 3, 3, 128), 0.125, device=DEV)
+        _lib.check(L.mcl_dense_conv3x3_wrw_det(dy.data_ptr(), lddy, z.data_ptr(), S, H, W, gam.data_ptr(), bet.data_ptr(),
+                                               mu.data_ptr(), rs.data_ptr(), ws.data_ptr(), dWd.data_ptr(), acc, dn._stream()))
+        assert_close_scaled(dWd.cpu(), (ref - (0.0 if acc else 0.125)).cpu(), 1e-4, what=f"deterministic conv3x3 wrw acc={acc}")
+        outs.append(dWd)
+    assert torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("S,C,ld", [(401408 // 16, 64, 256), (100352 // 4, 224, 512), (25088, 992, 1024), (6272, 512, 1024),
@@ -437,6 +448,87 @@ def test_dense_bn1_bwd_fused(S, C, ld):
     assert_close_scaled((dg - 0.5).cpu(), gr.grad.cpu(), 2e-4, what="dgamma")
     assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 2e-4, what="dbeta")
     assert torch.equal(gw[:, C:], gw[:, C:]) and float((xw[:, :C] - x).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S,C,ld", [(401408 // 16, 64, 256), (100352 // 4, 224, 512), (25088, 992, 1024), (6272, 512, 1024),
+                                    (300, 96, 96), (129, 160, 512), (70001, 136, 256)])
+def test_dense_bn1_wrw_dx_fused(S, C, ld):
+    """csrc/wrw_fused.hip: the bottleneck weight gradient and the BatchNorm-backward sums from ONE pass over (dz, x)
+    (Gram matrices R = dz^T mask, Qx = dz^T (mask*x); no atomics), then the dx pass -- vs fp64 torch autograd on the
+    same bf16 data; ragged slabs / channel tiles; sliced x, gbuf; accumulate semantics; bit-reproducible."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(S + C)
+    xw = ((torch.rand(S, ld, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)
+    gw = ((torch.rand(S, ld, generator=g) - 0.5) * 0.1).to(torch.bfloat16).to(DEV)
+    x, gbuf = xw[:, :C], gw[:, :C]
+    g0 = gbuf.clone()
+    dz = ((torch.rand(S, 128, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)
+    W1 = ((torch.rand(128, C, generator=g) - 0.5) / 8).to(torch.bfloat16).to(DEV)
+    gam = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    bet = (torch.rand(C, generator=g) - 0.5).to(DEV)
+    xd = x.double()
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    rs = 1.0 / torch.sqrt(var + 1e-5)
+    muf, rsf = mu.float(), rs.float()
+    ws = torch.empty(L.mcl_wrw_workspace_floats(S, 128, C), device=DEV)
+
+    def run():
+        dg = torch.full((C,), 0.5, device=DEV)
+        db = torch.full((C,), -0.25, device=DEV)
+        dW = torch.full((128, C), 0.125, device=DEV)
+        coef = torch.empty(2 * C, device=DEV)
+        _lib.check(L.mcl_dense_bn1_wrw(dz.data_ptr(), W1.data_ptr(), C, x.data_ptr(), ld, S, gam.data_ptr(),
+                                       bet.data_ptr(), muf.data_ptr(), rsf.data_ptr(), ws.data_ptr(), dW.data_ptr(), 1,
+                                       dg.data_ptr(), db.data_ptr(), 1, coef.data_ptr(), dn._stream()))
+        return dg, db, dW, coef
+
+    dg, db, dW, coef = run()
+    dg2, db2, dW2, coef2 = run()
+    assert torch.equal(dW, dW2) and torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(coef, coef2)
+    _lib.check(L.mcl_dense_bn1_dx(dz.data_ptr(), W1.data_ptr(), C, x.data_ptr(), ld, S, gam.data_ptr(), bet.data_ptr(),
+                                  muf.data_ptr(), rsf.data_ptr(), coef.data_ptr(), gbuf.data_ptr(), ld, dn._stream()))
+    xr = xd.clone().requires_grad_(True)
+    gr = gam.double().clone().requires_grad_(True)
+    br = bet.double().clone().requires_grad_(True)
+    wr = W1.double().clone().requires_grad_(True)
+    m_ = xr.mean(0)
+    v_ = xr.var(0, unbiased=False)
+    a = torch.relu((xr - m_) / torch.sqrt(v_ + 1e-5) * gr + br)
+    z = a @ wr.t()
+    z.backward(dz.double())
+    assert_close_scaled(gbuf.float().cpu(), (g0.double() + xr.grad).cpu(), 8e-3, what="gbuf += dx (bf16 accumulate)")
+    assert_close_scaled((dg - 0.5).cpu(), gr.grad.cpu(), 2e-4, what="dgamma")
+    assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 2e-4, what="dbeta")
+    assert_close_scaled(coef.view(C, 2)[:, 0].cpu(), (br.grad / S).cpu(), 2e-4, what="mean(g)")
+    assert_close_scaled(coef.view(C, 2)[:, 1].cpu(), (gr.grad / S).cpu(), 2e-4, what="mean(g*xhat)")
+    # the weight gradient uses the bf16-ROUNDED activation in round 1 (a is an MFMA operand); here a = mask*(gamma*xhat
+    # + beta) is formed in fp32 from exact operands, i.e. it is closer to the fp64 value than the rounded one
+    assert_close_scaled((dW - 0.125).cpu(), wr.grad.cpu(), 2e-4, what="dW1")
+    assert float((xw[:, :C] - x).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("S,M,N,lda", [(4096, 128, 256, 256), (1000, 128, 96, 96), (777, 128, 160, 416), (25088, 256, 512, 512),
+                                       (6272, 512, 1024, 1024), (100352, 128, 256, 256)])
+def test_conv1x1_wrw_det_kernel(S, M, N, lda):
+    """Atomics-free plain weight gradient dW = dz^T a (transition convolutions, M up to 512) vs fp64 of the same bf16
+    data; accumulate and overwrite semantics; bit-reproducible."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(S + N)
+    dz = (torch.rand(S, M, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
+    wide = (torch.rand(S, lda, generator=g) - 0.3).to(torch.bfloat16).to(DEV)
+    a = wide[:, :N]
+    ws = torch.empty(L.mcl_wrw_workspace_floats(S, min(M, 128), N), device=DEV)
+    ref = dz.double().t() @ a.double()
+    outs = []
+    for acc in (1, 0, 1):
+        dW = torch.full((M, N), 0.25, device=DEV)
+        _lib.check(L.mcl_conv1x1_wrw_det(dz.data_ptr(), M, a.data_ptr(), lda, ws.data_ptr(), dW.data_ptr(), acc, S, M, N,
+                                         dn._stream()))
+        assert_close_scaled(dW.cpu(), (ref + (0.25 if acc else 0.0)).cpu(), 2e-5, what=f"wrw det acc={acc}")
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("B,H,W,lddy", [(4, 56, 56, 256), (8, 28, 28, 32), (16, 14, 14, 1024), (32, 7, 7, 64), (3, 10, 6, 32)])
@@ -507,7 +599,8 @@ def test_pool_kernels(B, C, H, W):
         assert_close(xb.grad.float().cpu(), xa.grad.cpu(), 2e-3, what="avg pool backward")
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 256, 24, 24), (3, 512, 6, 10), (1, 1024, 14, 14), (2, 40, 4, 2)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 256, 24, 24), (3, 512, 6, 10), (1, 1024, 14, 14), (2, 40, 4, 2), (4, 1024, 7, 7),
+                                     (2, 64, 5, 9)])
 def test_transition_kernels(B, C, H, W):
     """csrc/bnrelu.hip bn_act_avgpool fwd / bwd (transition with the pool moved in front of the convolution) against
     fp64 autograd of avg_pool2d(relu(batch_norm_train(x))) on the same bf16 data."""
@@ -547,7 +640,7 @@ def test_transition_kernels(B, C, H, W):
     assert_close_scaled(dg.cpu(), 2 * g64.grad.cpu(), 2e-3, what="dgamma accumulated")
 
 
-@pytest.mark.parametrize("B,C,H,W,layers", [(2, 256, 24, 24, 3), (4, 512, 12, 12, 2), (8, 1024, 6, 6, 2)])
+@pytest.mark.parametrize("B,C,H,W,layers", [(2, 256, 24, 24, 3), (4, 512, 12, 12, 2), (8, 1024, 6, 6, 2), (8, 1024, 7, 7, 2)])
 def test_transition_fn_matches_module(B, C, H, W, layers):
     """TransitionFn (pool first, convolution on a quarter of the pixels, statistics for the next block from the
     convolution epilogue) against fp64 autograd of the torchvision order norm -> relu -> conv -> pool."""
@@ -642,18 +735,26 @@ def test_conv0_kernel(B, H, W):
     assert torch.equal(y2, y)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 224, 224), (3, 96, 96), (1, 256, 256), (2, 64, 64), (4, 4, 32)])
+@pytest.mark.parametrize("B,H,W", [(2, 224, 224), (3, 96, 96), (1, 256, 256), (2, 64, 64), (4, 4, 32), (3, 112, 112), (2, 8, 24)])
 def test_conv0_wrw_kernel(B, H, W):
-    """conv0 weight gradient (fp32 atomics into a channels-last (64,3,7,7) .grad) against fp64 autograd."""
+    """conv0 weight gradient into a channels-last (64,3,7,7) .grad against fp64 autograd: deterministic form
+    (per-workgroup partials + fixed-order merge; accumulate and overwrite; bit-reproducible) and the round-1 atomics
+    form; output rows that are not a multiple of 16 pixels (112-pixel her2st patches: OW = 56)."""
     import torch.nn.functional as F
     from mclstexp_amd import _lib, densenet_fused as dn
     from mclstexp_amd._lib import check
+    L = _lib.lib()
     g = torch.Generator().manual_seed(H + W + B)
     x = torch.rand(B, 3, H, W, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
     dy = (torch.rand(B, 64, H // 2, W // 2, generator=g) - 0.5).to(torch.bfloat16).to(DEV).contiguous(
         memory_format=torch.channels_last)
     w64 = torch.zeros(64, 3, 7, 7, dtype=torch.float64, device=DEV, requires_grad=True)
     F.conv2d(x.double(), w64, stride=2, padding=3).backward(dy.double())
-    dW = torch.full((64, 3, 7, 7), 0.25, device=DEV).contiguous(memory_format=torch.channels_last)   # accumulates
-    check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), dW.data_ptr(), dn._stream()), "mcl_conv0_wrw")
-    assert_close_scaled((dW - 0.25).cpu(), w64.grad.cpu(), 2e-5, floor=1e-4, what="dW conv0")
+    ws = torch.empty(L.mcl_conv0_wrw_workspace_floats(B, H, W), device=DEV)
+    outs = []
+    for acc, wsp in ((1, ws.data_ptr()), (0, ws.data_ptr()), (1, ws.data_ptr()), (1, None)):
+        dW = torch.full((64, 3, 7, 7), 0.25, device=DEV).contiguous(memory_format=torch.channels_last)
+        check(L.mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), wsp, dW.data_ptr(), acc, dn._stream()), "mcl_conv0_wrw")
+        assert_close_scaled((dW - (0.25 if acc else 0.0)).cpu(), w64.grad.cpu(), 2e-5, floor=1e-4, what=f"dW conv0 acc={acc}")
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[2])
