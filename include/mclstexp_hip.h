@@ -264,10 +264,12 @@ int mcl_dense_bn1_wrw(const void* dz, const void* W1, int32_t C, const void* x, 
 int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
                      const float* gamma, const float* beta, const float* mean, const float* rstd, const float* coef,
                      void* gbuf, int64_t ldg, mcl_stream_t stream);
-/* Plain deterministic 1x1 weight gradient dW[M][N] (+)= dz[S][M]^T a[S][N] (transition convolutions): the
- * atomics-free form of mcl_conv1x1_wrw_bf16 without prologue.  workspace: mcl_wrw_workspace_floats(S, min(M,128), N). */
-int mcl_conv1x1_wrw_det(const void* dz, int64_t ldz, const void* a, int64_t lda, float* workspace, float* dW,
-                        int32_t accumulate_w, int64_t S, int32_t M, int32_t N, mcl_stream_t stream);
+/* Deterministic 1x1 weight gradient dW[M][N] (+)= dz[S][M]^T a'[S][N]: a' = a (gamma..rstd NULL: transition
+ * convolutions) or relu(BatchNorm(a)) recomputed in registers (all four given) -- the atomics-free form of
+ * mcl_conv1x1_wrw_bf16.  workspace: mcl_wrw_workspace_floats(S, min(M,128), N).                                 */
+int mcl_conv1x1_wrw_det(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* gamma, const float* beta,
+                        const float* mean, const float* rstd, float* workspace, float* dW, int32_t accumulate_w,
+                        int64_t S, int32_t M, int32_t N, mcl_stream_t stream);
 
 /* Backward of a dense layer's tail z -> norm2 -> relu2 -> conv2 (3x3, pad 1, 128 -> 32) with respect to z, fused:
  *   da2 = conv3x3 backward-data of dy ; g2 = da2*[bn2(z) > 0] ; dgamma2 (+)= sum g2*zhat ; dbeta2 (+)= sum g2 ;

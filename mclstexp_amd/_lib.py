@@ -88,7 +88,7 @@ PROTOTYPES = {
     "mcl_wrw_workspace_floats": [c_l, c_i, c_i],
     "mcl_dense_bn1_wrw": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p],
     "mcl_dense_bn1_dx": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
-    "mcl_conv1x1_wrw_det": [c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_l, c_i, c_i, c_p],
+    "mcl_conv1x1_wrw_det": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],

@@ -40,32 +40,65 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 64;        // pixels per LDS tile
 constexpr int BT = 128;       // channel-tile width of both operands
-constexpr int PITCH = 160;    // elements per LDS row (128 + 32 pad = 320 B): the four 16-lane groups of a
-                              // transposing read hit 64 distinct banks
-constexpr int NCH = BK / 16;  // 16-byte chunks per thread and operand tile
+constexpr int ROWB = BT * 2;  // bytes per LDS tile row (raw rows as they lie in HBM: 128 bf16)
+constexpr int TILE_B = BK * ROWB;          // 16 KB per operand tile
+constexpr int STAGE_B = 2 * TILE_B;        // dz tile + x tile
+constexpr int NSTAGE = 2;
 
-// 8 consecutive-k bf16 of channel (cbase + lane&15 [+16 for odd 16-lane groups]) starting at row kbase
-__device__ __forceinline__ bf16x8 frag(const bf16_t* tile, int kbase, int cbase, int lane) {
-  const int i = lane & 15;
-  const bf16_t* p = tile + (kbase + (i >> 2)) * PITCH + cbase + (i & 3) * 4;
+// Slab stride of the partial workspace in floats: (M + 2) x N (two extra rows: the BatchNorm-backward sums) plus 256
+// bytes, so that the stride is never a power of two (same-offset reads of all slabs would share HBM channels).
+__host__ __device__ inline long long slab_stride(long long MN, int N) { return MN + 2LL * N + 64; }
+
+#define MCL_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+
+// One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the wave's 1 KiB lands lane-linear
+// at the (wave-uniform) LDS address in M0 -- no VGPR round trip, so a whole tile can be in flight while the previous
+// one is being multiplied.  Inline asm on purpose: hidden from the compiler's vmcnt bookkeeping, the DMA is covered by
+// the explicit vmcnt(0) + barrier that opens every tile (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* src, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(dst)
+               : "memory");
+}
+
+// Raw tiles keep 256-byte rows (what the DMA writes), so the transposing reads are de-conflicted by an XOR swizzle
+// instead of row padding: 16-byte chunk c of row r lives at physical chunk c ^ ((r & 3) << 2).  A 32-lane group of a
+// ds_read_b64_tr_b16 touches 4 consecutive rows x 4 chunks; the XOR spreads them over 16 distinct chunks = all 64 banks.
+// The swizzle is applied on the SOURCE side of the DMA (lane l of a 4-row piece fetches logical chunk
+// (l & 15) ^ ((l >> 4) << 2) and lands on physical chunk l & 15).
+// Fragment: 8 consecutive-k bf16 of channel (cbase + (lane & 31)) starting at tile row kbase (kbase % 4 == 0).
+__device__ __forceinline__ bf16x8 frag_sw(const unsigned char* tile, int kbase, int cbase, int lane) {
+  const int i = lane & 15, q = i >> 2;
+  const int lchunk = (cbase + 16 * ((lane >> 4) & 1)) / 8 + ((i & 3) >> 1);
+  const unsigned char* p = tile + (kbase + q) * ROWB + ((lchunk ^ (q << 2)) << 4) + (i & 1) * 8;
   const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)p);
-  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 4 * PITCH));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 4 * ROWB));
   bf16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
 }
 
-template <bool FUSED>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// Workgroup = 4 waves; wave w owns output columns [32w, 32w + 32) of the 128-column tile and ALL 128 rows (four
+// 32 x 32 blocks, for Q and for R: 128 accumulator registers).  Its x fragment holds ONE channel per lane, so the
+// BatchNorm+ReLU mask is two per-lane scalars and is applied in registers between the LDS read and the MFMA: the
+// masked operands mask*x and mask never exist in LDS, and there is no separate staging phase.
+// MODE 0: dW = dz^T a (plain).  MODE 1: Gram matrices Qx, R -> dW1 + BatchNorm-backward sums (see the header).
+// MODE 2: dW = dz^T relu(bn(x)) with the prologue applied in registers (one GEMM; for the side stream).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void wrw_partial_kernel(
     const bf16_t* __restrict__ dz, long long ldz, const bf16_t* __restrict__ x, long long ldx,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ rstd, const bf16_t* __restrict__ W1 /* [M][N] */, float* __restrict__ wpart /* [ks][M][N] */,
-    float* __restrict__ spart /* [ks][2][N] */, long long S, int M, int N, long long rows_per_wg, int ks, int tn) {
-  __shared__ __attribute__((aligned(16))) bf16_t lds[(FUSED ? 3 : 2) * BK * PITCH];
-  __shared__ float red[2][2][BT];                     // [wm][sum][column]: cross-wave column sums of the epilogue
+    long long slab /* floats per slab */, long long S, int M, int N, long long rows_per_wg, int ks, int tn) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware decode (block b runs on XCD b % 8): the tn column tiles of one pixel slab share an XCD (its L2 serves
   // the dz slab to all of them); consecutive slabs go round the 8 XCDs
   const int L = blockIdx.x, xcd = L & 7, qq = L >> 3;
@@ -74,198 +107,222 @@ __global__ __launch_bounds__(256, 2) void wrw_partial_kernel(
   const int n0 = tx * BT;
   const long long s_begin = (long long)z * rows_per_wg;
   const long long s_end = min(S, s_begin + rows_per_wg);
+  const int nt = (int)((s_end - s_begin + BK - 1) / BK);
+  const unsigned lds_base = (unsigned)(size_t)MCL_LDSP(lds);
 
-  bf16_t* tA = lds;                      // dz tile
-  bf16_t* tX = lds + BK * PITCH;         // mask*x (FUSED) / a (plain)
-  bf16_t* tM = lds + 2 * BK * PITCH;     // mask as bf16 1.0 / 0.0 (FUSED)
-
-  const int col = (tid & 15) * 8, rr = tid >> 4;
-  const bool cok_a = col < M, cok_x = n0 + col < N;
-  float sc[8], sh[8];
-  if (FUSED) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {       // mask = [x*sc + sh > 0]
-      const int c = n0 + col + i;
-      const bool ok = c < N;
-      sc[i] = ok ? gamma[c] * rstd[c] : 0.0f;
-      sh[i] = ok ? fmaf(-mean[c], sc[i], beta[c]) : -1.0f;
-    }
+  // this lane's channel and its mask constants: mask = [x*sc + sh > 0]
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int n_lane = n0 + wave * 32 + l31;
+  float sc = 0.0f, sh = -1.0f;
+  constexpr bool FUSED = MODE == 1;
+  if (MODE != 0 && n_lane < N) {
+    sc = gamma[n_lane] * rstd[n_lane];
+    sh = fmaf(-mean[n_lane], sc, beta[n_lane]);
   }
 
-  f32x16 accq[2][2], accr[2][2];
+  // DMA source geometry of this lane: piece p (tile rows 4p .. 4p+3) is issued by wave p & 3
+  const int prow = lane >> 4;                                   // row inside a piece
+  const int lchunk = (lane & 15) ^ (prow << 2);                 // logical 16-byte chunk this lane fetches
+  const int ca = lchunk * 8 < M ? lchunk * 8 : 0;               // dz column (elements); chunks beyond M: any valid one
+  const int cx = n0 + lchunk * 8 < N ? n0 + lchunk * 8 : n0;    // x column; chunks beyond N: any valid one (unused)
+  auto dma_tile = [&](int t, int stage) {
+    const long long s0 = s_begin + (long long)t * BK;
+    const unsigned dst = lds_base + stage * STAGE_B;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        accq[i][j][r] = 0.0f;
-        accr[i][j][r] = 0.0f;
-      }
-
-  uint4 ra[NCH], rx[NCH];
-  auto gload = [&](long long s0) {
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const long long s = s0 + rr + 16 * h;
-      const bool ok = s < s_end;
-      ra[h] = (ok && cok_a) ? *reinterpret_cast<const uint4*>(dz + s * ldz + col) : make_uint4(0u, 0u, 0u, 0u);
-      rx[h] = (ok && cok_x) ? *reinterpret_cast<const uint4*>(x + s * ldx + n0 + col) : make_uint4(0u, 0u, 0u, 0u);
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const int row = rr + 16 * h;
-      *reinterpret_cast<uint4*>(tA + row * PITCH + col) = ra[h];
-      if (!FUSED) {
-        *reinterpret_cast<uint4*>(tX + row * PITCH + col) = rx[h];
-      } else {
-        const unsigned w[4] = {rx[h].x, rx[h].y, rx[h].z, rx[h].w};
-        unsigned xm[4], mk[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xFFFF0000u);
-          const bool plo = fmaf(lo, sc[2 * i], sh[2 * i]) > 0.0f, phi = fmaf(hi, sc[2 * i + 1], sh[2 * i + 1]) > 0.0f;
-          const unsigned sel = (plo ? 0x0000FFFFu : 0u) | (phi ? 0xFFFF0000u : 0u);
-          xm[i] = w[i] & sel;
-          mk[i] = 0x3F803F80u & sel;
-        }
-        *reinterpret_cast<uint4*>(tX + row * PITCH + col) = make_uint4(xm[0], xm[1], xm[2], xm[3]);
-        *reinterpret_cast<uint4*>(tM + row * PITCH + col) = make_uint4(mk[0], mk[1], mk[2], mk[3]);
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int p = wave + 4 * u;
+      long long row = s0 + 4 * p + prow;
+      row = row < S ? row : S - 1;                              // ragged last tile: clamped rows are masked out of dz
+      glds16(dz + row * ldz + ca, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+      glds16(x + row * ldx + cx, __builtin_amdgcn_readfirstlane(dst + TILE_B + p * 1024));
     }
   };
 
-  const int nt = (int)((s_end - s_begin + BK - 1) / BK);
-  const int half16 = 16 * ((lane >> 4) & 1);
-  const int kg = 8 * (lane >> 5);
-  if (nt > 0) gload(s_begin);
+  f32x16 accq[4], accr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      accq[i][r] = 0.0f;
+      accr[i][r] = 0.0f;
+    }
+
+  const int kg = 8 * hh;
+  // Both stages are free at the start: tiles 0 and 1 go out together.  From then on tile t+1 is fetched while tile t
+  // is multiplied (its stage was released by the barrier that opens iteration t).
+  if (nt > 0) dma_tile(0, 0);
+  if (nt > 1) dma_tile(1, 1);
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();                       // previous tile's fragments are consumed
-    lstore();
-    __syncthreads();
-    if (t + 1 < nt) gload(s_begin + (long long)(t + 1) * BK);      // in flight under this tile's MFMAs
+    if (t == 0 && nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 only (8 pieces of tile 1 pending)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's pieces of tile t have landed
+    __syncthreads();                                     // ... everybody's; and the other stage is free again
+    if (t >= 1 && t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);   // in flight under this tile's MFMAs
+    const unsigned char* tA = lds + (t & 1) * STAGE_B;
+    const unsigned char* tX = tA + TILE_B;
+    const int nvalid = (int)min((long long)BK, s_end - (s_begin + (long long)t * BK));
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      bf16x8 fa[2], fx[2], fm[2];
+      bf16x8 fa[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag(tA, kk + kg, wm * 64 + i * 32 + half16, lane);
+      for (int i = 0; i < 4; ++i) fa[i] = frag_sw(tA, kk + kg, i * 32, lane);
+      if (nvalid < BK) {                                 // ragged tile (only the last slab): zero dz beyond the end
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        fx[j] = frag(tX, kk + kg, wn * 64 + j * 32 + half16, lane);
-        if (FUSED) fm[j] = frag(tM, kk + kg, wn * 64 + j * 32 + half16, lane);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kk + kg + e >= nvalid) fa[i][e] = 0;
       }
+      const bf16x8 fx = frag_sw(tX, kk + kg, wave * 32, lane);
+      if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i) accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fx, accq[i], 0, 0, 0);
+      } else if (MODE == 2) {
+        const u32x4 w = __builtin_bit_cast(u32x4, fx);
+        u32x4 av;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          accq[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fx[j], accq[i][j], 0, 0, 0);
-          if (FUSED) accr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fm[j], accr[i][j], 0, 0, 0);
+        for (int d = 0; d < 4; ++d) {
+          const float lo = fmaxf(fmaf(__uint_as_float(w[d] << 16), sc, sh), 0.0f);
+          const float hi = fmaxf(fmaf(__uint_as_float(w[d] & 0xFFFF0000u), sc, sh), 0.0f);
+          const f32x2 pv = {lo, hi};
+          av[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));      // RNE, as the forward
         }
+        const bf16x8 fav = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fav, accq[i], 0, 0, 0);
+      } else {
+        const u32x4 w = __builtin_bit_cast(u32x4, fx);
+        u32x4 xm, mk;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float lo = __uint_as_float(w[d] << 16), hi = __uint_as_float(w[d] & 0xFFFF0000u);
+          const unsigned sel = (fmaf(lo, sc, sh) > 0.0f ? 0x0000FFFFu : 0u) | (fmaf(hi, sc, sh) > 0.0f ? 0xFFFF0000u : 0u);
+          xm[d] = w[d] & sel;
+          mk[d] = 0x3F803F80u & sel;
+        }
+        const bf16x8 fxm = __builtin_bit_cast(bf16x8, xm), fmk = __builtin_bit_cast(bf16x8, mk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fxm, accq[i], 0, 0, 0);
+          accr[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fmk, accr[i], 0, 0, 0);
+        }
+      }
     }
   }
 
-  // ---- epilogue: acc[i][j][r] is element m = wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), n = n0 + wn*64 + j*32 + (lane&31)
-  float* wp = wpart + (long long)z * M * N;
-  const int hh = lane >> 5, l31 = lane & 31;
-  float t1[2] = {0.0f, 0.0f}, t2[2] = {0.0f, 0.0f};
+  // ---- epilogue: acc[i][r] is element m = i*32 + (r&3) + 8*(r>>2) + 4*hh, n = n_lane
+  float* wp = wpart + (long long)z * slab;
+  const bool nok = n_lane < N;
+  float t1 = 0.0f, t2 = 0.0f;
+  float g = 0.0f, b = 0.0f, mu = 0.0f, rs = 0.0f;
+  if (FUSED && nok) {
+    g = gamma[n_lane]; b = beta[n_lane]; mu = mean[n_lane]; rs = rstd[n_lane];
+  }
+  if (nok) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + l31;
-    const bool nok = n < N;
-    float g = 0.0f, b = 0.0f, mu = 0.0f, rs = 0.0f;
-    if (FUSED && nok) {
-      g = gamma[n]; b = beta[n]; mu = mean[n]; rs = rstd[n];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (!nok || m >= M) continue;
+        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m >= M) continue;
         if (FUSED) {
-          const float R = accr[i][j][r];
-          const float Q = rs * fmaf(-mu, R, accq[i][j][r]);
-          const float w = __uint_as_float(((unsigned)W1[(long long)m * N + n]) << 16);
-          t1[j] = fmaf(w, R, t1[j]);
-          t2[j] = fmaf(w, Q, t2[j]);
-          wp[(long long)m * N + n] = fmaf(g, Q, b * R);
+          const float R = accr[i][r];
+          const float Q = rs * fmaf(-mu, R, accq[i][r]);
+          const float w = __uint_as_float(((unsigned)W1[(long long)m * N + n_lane]) << 16);
+          t1 = fmaf(w, R, t1);
+          t2 = fmaf(w, Q, t2);
+          wp[(long long)m * N + n_lane] = fmaf(g, Q, b * R);
         } else {
-          wp[(long long)m * N + n] = accq[i][j][r];
+          wp[(long long)m * N + n_lane] = accq[i][r];
         }
       }
   }
   if (FUSED) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      t1[j] += __shfl_xor(t1[j], 32, 64);
-      t2[j] += __shfl_xor(t2[j], 32, 64);
-      if (hh == 0) {
-        red[wm][0][wn * 64 + j * 32 + l31] = t1[j];
-        red[wm][1][wn * 64 + j * 32 + l31] = t2[j];
-      }
-    }
-    __syncthreads();
-    if (tid < BT && n0 + tid < N) {
-      float* sp = spart + (long long)z * 2 * N;
-      sp[n0 + tid] = red[0][0][tid] + red[1][0][tid];
-      sp[N + n0 + tid] = red[0][1][tid] + red[1][1][tid];
+    t1 += __shfl_xor(t1, 32, 64);          // the two lane halves hold disjoint rows m of the same column
+    t2 += __shfl_xor(t2, 32, 64);
+    if (hh == 0 && nok) {                  // rows M, M+1 of the slab: merged by the same code as the weight gradient
+      wp[(long long)M * N + n_lane] = t1;
+      wp[(long long)(M + 1) * N + n_lane] = t2;
     }
   }
 }
 
-// dW[m][n] (+)= sum_z wpart[z][m][n] (blocks [0, nbw)): a block owns 32 float4 columns; its 8 thread groups each sum
-// every 8th slab, then the 8 group sums are added in fixed order -- the same order every run.  Per channel (blocks
-// [nbw, ...)): the two BatchNorm-backward sums in slab order (double), parameter gradients, and the means of the dx pass.
-__global__ __launch_bounds__(256) void wrw_merge_kernel(const float* __restrict__ wpart, const float* __restrict__ spart,
-                                                        int ks, long long MN, int N, long long S, float* __restrict__ dW,
-                                                        int accumulate_w, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta, int accumulate_params,
-                                                        float* __restrict__ coef, int nbw) {
-  __shared__ float4 part[8][32];
-  if ((int)blockIdx.x < nbw) {
-    const int q = threadIdx.x & 31, zg = threadIdx.x >> 5;
-    const long long e = ((long long)blockIdx.x * 32 + q) * 4;
-    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (e < MN) {                                          // MN is a multiple of 8 (M, N multiples of 8)
-      for (int zz = zg; zz < ks; zz += 8) {
-        const float4 v = *reinterpret_cast<const float4*>(wpart + (long long)zz * MN + e);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+// dW[m][n] (+)= sum_z wpart[z][m][n] (blocks [0, nbw)): a block owns 8 float4 columns (128 contiguous bytes per slab);
+// its 32 thread groups each sum every 32nd slab with four loads in flight, then the 32 group sums are added in fixed
+// order -- the same order every run.  (A thread that walks the slabs one dependent load at a time is latency-bound:
+// 512 slabs x ~1 us.)  Per channel (blocks [nbw, ...)): the two BatchNorm-backward sums in slab order (double),
+// parameter gradients, and the means of the dx pass.
+constexpr int MQ = 8, MZG = 256 / MQ;
+// Elements [0, MN) of a slab are the weight-gradient partial; with sums != 0 elements [MN, MN + 2N) are the partial
+// BatchNorm-backward sums (row M: sum g, row M+1: sum g*xhat), merged by the same code and turned into dbeta / dgamma
+// (+=) and the two means of the dx pass.
+__global__ __launch_bounds__(256) void wrw_merge_kernel(const float* __restrict__ wpart, int ks, long long MN, int N,
+                                                        long long S, float* __restrict__ dW, int accumulate_w,
+                                                        int sums, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        int accumulate_params, float* __restrict__ coef,
+                                                        long long stride) {
+  __shared__ float4 part[MZG][MQ];
+  const long long total = MN + (sums ? 2LL * N : 0LL);
+  const int q = threadIdx.x % MQ, zg = threadIdx.x / MQ;
+  const long long e = ((long long)blockIdx.x * MQ + q) * 4;
+  // eight independent loads in flight per thread: with few blocks (N = 64: 260 of them) the merge is otherwise
+  // latency-bound
+  float4 acc8[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc8[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (e < total) {                                       // MN, N multiples of 8
+    const float* p = wpart + e;
+    int zz = zg;
+    for (; zz + 7 * MZG < ks; zz += 8 * MZG) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long long)(zz + u * MZG) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc8[u].x += v[u].x; acc8[u].y += v[u].y; acc8[u].z += v[u].z; acc8[u].w += v[u].w;
       }
     }
-    part[zg][q] = a;
-    __syncthreads();
-    if (zg != 0 || e >= MN) return;
 #pragma unroll
-    for (int g = 1; g < 8; ++g) {
-      const float4 v = part[g][q];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (int u = 0; u < 8; ++u) {
+      if (zz + u * MZG < ks) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p + (long long)(zz + u * MZG) * stride);
+        acc8[u].x += v0.x; acc8[u].y += v0.y; acc8[u].z += v0.z; acc8[u].w += v0.w;
+      }
     }
+  }
+  float4 a;
+  a.x = ((acc8[0].x + acc8[1].x) + (acc8[2].x + acc8[3].x)) + ((acc8[4].x + acc8[5].x) + (acc8[6].x + acc8[7].x));
+  a.y = ((acc8[0].y + acc8[1].y) + (acc8[2].y + acc8[3].y)) + ((acc8[4].y + acc8[5].y) + (acc8[6].y + acc8[7].y));
+  a.z = ((acc8[0].z + acc8[1].z) + (acc8[2].z + acc8[3].z)) + ((acc8[4].z + acc8[5].z) + (acc8[6].z + acc8[7].z));
+  a.w = ((acc8[0].w + acc8[1].w) + (acc8[2].w + acc8[3].w)) + ((acc8[4].w + acc8[5].w) + (acc8[6].w + acc8[7].w));
+  part[zg][q] = a;
+  __syncthreads();
+  if (zg != 0 || e >= total) return;
+#pragma unroll
+  for (int g = 1; g < MZG; ++g) {
+    const float4 v = part[g][q];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (e < MN) {
     float4* o = reinterpret_cast<float4*>(dW + e);
     if (accumulate_w) {
-      const float4 p = *o;
-      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      const float4 pv = *o;
+      a.x += pv.x; a.y += pv.y; a.z += pv.z; a.w += pv.w;
     }
     *o = a;
     return;
   }
-  const int c = ((int)blockIdx.x - nbw) * 256 + threadIdx.x;
-  if (c >= N) return;
-  double a = 0.0, b = 0.0;
-  for (int zz = 0; zz < ks; ++zz) {
-    a += (double)spart[(long long)zz * 2 * N + c];
-    b += (double)spart[(long long)zz * 2 * N + N + c];
+  // four channels of one of the two sums
+  const long long r = e - MN;
+  const int which = r >= N ? 1 : 0, c = (int)(r - (long long)which * N);
+  float* pg = which ? dgamma : dbeta;
+  const float v[4] = {a.x, a.y, a.z, a.w};
+  const float inv_s = 1.0f / (float)S;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (accumulate_params) pg[c + i] += v[i];
+    else pg[c + i] = v[i];
+    coef[2 * (c + i) + which] = v[i] * inv_s;
   }
-  if (accumulate_params) {
-    dbeta[c] += (float)a;
-    dgamma[c] += (float)b;
-  } else {
-    dbeta[c] = (float)a;
-    dgamma[c] = (float)b;
-  }
-  coef[2 * c] = (float)(a / (double)S);
-  coef[2 * c + 1] = (float)(b / (double)S);
 }
 
 struct Split {
@@ -276,11 +333,13 @@ struct Split {
 inline Split plan(long long S, int N) {
   Split p;
   p.tn = (N + BT - 1) / BT;
-  // ~2 workgroups per CU on the big maps; fewer on the small ones, where the 64 KB partial each workgroup writes
-  // (and the merge re-reads) would otherwise outweigh the operands
-  const long long target = S >= 200000 ? 512 : (S >= 50000 ? 384 : 256);
+  // ~2 workgroups per CU.  A workgroup's time is a chain of (tiles x DMA latency ~3 us) + prologue + epilogue, so the
+  // small maps (blocks 3-4: the whole operand set is 8-56 MB) want FEW tiles per workgroup even though every extra
+  // workgroup costs a 64 KB partial that the merge re-reads: at least 4 tiles (2 on the 7 x 7 maps) per workgroup.
+  const long long target = 512;
   long long ks = (target + p.tn - 1) / p.tn;
-  const long long max_ks = (S + 4 * BK - 1) / (4 * BK);        // at least four LDS tiles per workgroup
+  const long long min_rows = S < 10000 ? 2 * BK : 4 * BK;
+  const long long max_ks = (S + min_rows - 1) / min_rows;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
   long long rows = (S + ks - 1) / ks;
@@ -294,16 +353,36 @@ inline Split plan(long long S, int N) {
 }  // namespace
 
 void mcl_launch_wrw_merge(const float* wpart, int ks, long long MN, float* dW, int accumulate_w, hipStream_t st) {
-  const int nbw = (int)((MN / 4 + 31) / 32);
-  hipLaunchKernelGGL(wrw_merge_kernel, dim3(nbw), dim3(256), 0, st, wpart, (const float*)nullptr, ks, MN, 0, 1LL, dW,
-                     accumulate_w, (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, nbw);
+  const int nb = (int)((MN / 4 + MQ - 1) / MQ);
+  hipLaunchKernelGGL(wrw_merge_kernel, dim3(nb), dim3(256), 0, st, wpart, ks, MN, 0, 1LL, dW, accumulate_w, 0,
+                     (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, MN);
 }
 
 extern "C" int64_t mcl_wrw_workspace_floats(int64_t S, int32_t M, int32_t N) {
   if (S <= 0 || M <= 0 || N <= 0) return -1;
   const Split p = plan(S, N);
-  return (int64_t)p.ks * ((int64_t)M * N + 2 * (int64_t)N) + 2 * (int64_t)N;
+  return (int64_t)p.ks * slab_stride((int64_t)(M < BT ? M : BT) * N, N);
 }
+
+namespace {
+// One 128-row block of output channels: partial kernel + fixed-order merge.
+template <int MODE>
+void launch_wrw(const bf16_t* dz, long long ldz, const bf16_t* x, long long ldx, const float* gamma, const float* beta,
+                const float* mean, const float* rstd, const bf16_t* W1, float* workspace, float* dW, int accumulate_w,
+                float* dgamma, float* dbeta, int accumulate_params, float* coef, long long S, int M, int N,
+                hipStream_t st) {
+  const Split p = plan(S, N);
+  const int ks8 = (p.ks + 7) / 8 * 8;
+  const long long MN = (long long)M * N, slab = slab_stride(MN, N);
+  hipLaunchKernelGGL(wrw_partial_kernel<MODE>, dim3(ks8 * p.tn), dim3(256), 0, st, dz, ldz, x, ldx, gamma, beta, mean,
+                     rstd, W1, workspace, slab, S, M, N, p.rows, p.ks, p.tn);
+  const int sums = MODE == 1 ? 1 : 0;
+  const long long total = MN + (sums ? 2LL * N : 0LL);
+  const int nb = (int)((total / 4 + MQ - 1) / MQ);
+  hipLaunchKernelGGL(wrw_merge_kernel, dim3(nb), dim3(256), 0, st, (const float*)workspace, p.ks, MN, N, S, dW,
+                     accumulate_w, sums, dgamma, dbeta, accumulate_params, coef, slab);
+}
+}  // namespace
 
 // Fused: dW1 (+)= dz^T relu(bn(x)); dgamma/dbeta (+)= BatchNorm backward sums; coef_out[2c], [2c+1] = the two means.
 extern "C" int mcl_dense_bn1_wrw(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
@@ -317,49 +396,40 @@ extern "C" int mcl_dense_bn1_wrw(const void* dz, const void* W1, int32_t C, cons
   if ((C % 8) || (ldx % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
       (reinterpret_cast<uintptr_t>(dW) & 15u) || (reinterpret_cast<uintptr_t>(workspace) & 15u))
     return MCL_EUNSUPPORTED;
-  const int M = 128, N = C;
-  const Split p = plan(S, N);
-  float* wpart = workspace;
-  float* spart = workspace + (int64_t)p.ks * M * N;
-  const int ks8 = (p.ks + 7) / 8 * 8;
-  hipStream_t st = mcl_stream(stream);
-  hipLaunchKernelGGL(wrw_partial_kernel<true>, dim3(ks8 * p.tn), dim3(256), 0, st, (const bf16_t*)dz, 128LL,
-                     (const bf16_t*)x, (long long)ldx, gamma, beta, mean, rstd, (const bf16_t*)W1, wpart, spart,
-                     (long long)S, M, N, p.rows, p.ks, p.tn);
-  const long long MN = (long long)M * N;
-  const int nbw = (int)((MN / 4 + 31) / 32), nbc = (N + 255) / 256;
-  hipLaunchKernelGGL(wrw_merge_kernel, dim3(nbw + nbc), dim3(256), 0, st, (const float*)wpart, (const float*)spart,
-                     p.ks, MN, N, (long long)S, dW, accumulate_w, dgamma, dbeta, accumulate_params, coef_out, nbw);
+  launch_wrw<1>((const bf16_t*)dz, 128LL, (const bf16_t*)x, (long long)ldx, gamma, beta, mean, rstd, (const bf16_t*)W1,
+                workspace, dW, accumulate_w, dgamma, dbeta, accumulate_params, coef_out, (long long)S, 128, C,
+                mcl_stream(stream));
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
 
-// Plain: dW[M][N] (+)= dz[S][M]^T a[S][N]   (transition convolutions; deterministic replacement of the atomics kernel)
-extern "C" int mcl_conv1x1_wrw_det(const void* dz, int64_t ldz, const void* a, int64_t lda, float* workspace, float* dW,
+// dW[M][N] (+)= dz[S][M]^T a'[S][N], a' = a (gamma == NULL: transition convolutions) or relu(a*sc + sh) with the
+// BatchNorm folded to sc = gamma*rstd, sh = beta - mean*sc (all four given: the bottleneck convolution on the side
+// stream) -- the deterministic replacement of the atomics kernel mcl_conv1x1_wrw_bf16.
+extern "C" int mcl_conv1x1_wrw_det(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* gamma,
+                                   const float* beta, const float* mean, const float* rstd, float* workspace, float* dW,
                                    int32_t accumulate_w, int64_t S, int32_t M, int32_t N, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!dz || !a || !dW || !workspace || S <= 0 || M <= 0 || N <= 0) return MCL_EINVAL;
+  const bool pro = gamma || beta || mean || rstd;
+  if (pro && !(gamma && beta && mean && rstd)) return MCL_EINVAL;
   if ((M % 8) || (N % 8) || (ldz % 8) || (lda % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
       (reinterpret_cast<uintptr_t>(a) & 15u) || (reinterpret_cast<uintptr_t>(dW) & 15u) ||
       (reinterpret_cast<uintptr_t>(workspace) & 15u))
     return MCL_EUNSUPPORTED;
   hipStream_t st = mcl_stream(stream);
-  const Split p = plan(S, N);
-  const int ks8 = (p.ks + 7) / 8 * 8;
-  // M > 128 (transition convolutions: 128 / 256 / 512 output channels): one pass per 128 output channels, each with its
-  // own partial set; the merge adds row block by row block
+  // M > 128 (transition convolutions: 128 / 256 / 512 output channels): one pass per 128 output channels; the passes
+  // share the workspace (stream order)
   for (int m0 = 0; m0 < M; m0 += BT) {
     const int mm = M - m0 < BT ? M - m0 : BT;
-    float* wpart = workspace;
-    hipLaunchKernelGGL(wrw_partial_kernel<false>, dim3(ks8 * p.tn), dim3(256), 0, st, (const bf16_t*)dz + m0,
-                       (long long)ldz, (const bf16_t*)a, (long long)lda, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const bf16_t*)nullptr, wpart, (float*)nullptr,
-                       (long long)S, mm, N, p.rows, p.ks, p.tn);
-    const long long MN = (long long)mm * N;
-    const int nbw = (int)((MN / 4 + 31) / 32);
-    hipLaunchKernelGGL(wrw_merge_kernel, dim3(nbw), dim3(256), 0, st, (const float*)wpart, (const float*)nullptr, p.ks,
-                       MN, N, (long long)S, dW + (long long)m0 * N, accumulate_w, (float*)nullptr, (float*)nullptr, 0,
-                       (float*)nullptr, nbw);
+    if (pro)
+      launch_wrw<2>((const bf16_t*)dz + m0, (long long)ldz, (const bf16_t*)a, (long long)lda, gamma, beta, mean, rstd,
+                    (const bf16_t*)nullptr, workspace, dW + (long long)m0 * N, accumulate_w, (float*)nullptr,
+                    (float*)nullptr, 0, (float*)nullptr, (long long)S, mm, N, st);
+    else
+      launch_wrw<0>((const bf16_t*)dz + m0, (long long)ldz, (const bf16_t*)a, (long long)lda, gamma, beta, mean, rstd,
+                    (const bf16_t*)nullptr, workspace, dW + (long long)m0 * N, accumulate_w, (float*)nullptr,
+                    (float*)nullptr, 0, (float*)nullptr, (long long)S, mm, N, st);
   }
   MCL_CHECK_LAUNCH();
   return MCL_OK;

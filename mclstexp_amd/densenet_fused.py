@@ -283,7 +283,10 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
 
 # Deterministic fusion of the bottleneck weight gradient with the BatchNorm-backward reduction (csrc/wrw_fused.hip): one
 # pass over (dz, x) replaces conv1x1_wrw (fp32 atomics) + the reduce launch + its finalize; then the dx pass alone.
-USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "1") != "0"
+# Measured (profiles/r02_*): the Gram fusion does the least total work but it puts the weight gradient ON the critical
+# chain of the backward; with the side stream idle-capable, the shorter chain (reduce + finalize + dx on the main stream,
+# atomics-free weight gradients beside it) wins: 14.87 vs 15.08 ms/step.  Default off; MCL_FUSED_BN1_WRW=1 selects it.
+USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "0") != "0"
 
 
 def _bn1_wrw_ok(w_param: Tensor) -> bool:
@@ -421,13 +424,13 @@ def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Ten
     else:
         tgt = torch.zeros((M, N, 1, 1), device=dz.device, dtype=torch.float32)
         ret = tgt
-    if bn is None and USE_DET_WRW:
+    g_, b_, m_, r_ = (t.data_ptr() for t in bn) if bn is not None else (None, None, None, None)
+    if USE_DET_WRW:
         L = _lib.lib()
         ws = _ws(L.mcl_wrw_workspace_floats(S, min(M, 128), N), dz.device)
-        check(L.mcl_conv1x1_wrw_det(pz, ldz, pa, lda, ws.data_ptr(), tgt.data_ptr(), 1, S, M, N, _stream()),
-              "mcl_conv1x1_wrw_det")
+        check(L.mcl_conv1x1_wrw_det(pz, ldz, pa, lda, g_, b_, m_, r_, ws.data_ptr(), tgt.data_ptr(), 1, S, M, N,
+                                    _stream()), "mcl_conv1x1_wrw_det")
         return ret
-    g_, b_, m_, r_ = (t.data_ptr() for t in bn) if bn is not None else (None, None, None, None)
     check(_lib.lib().mcl_conv1x1_wrw_bf16(pz, ldz, pa, lda, g_, b_, m_, r_, tgt.data_ptr(), N, S, M, N, _stream()),
           "mcl_conv1x1_wrw_bf16")
     return ret

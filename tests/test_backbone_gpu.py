@@ -524,11 +524,25 @@ def test_conv1x1_wrw_det_kernel(S, M, N, lda):
     outs = []
     for acc in (1, 0, 1):
         dW = torch.full((M, N), 0.25, device=DEV)
-        _lib.check(L.mcl_conv1x1_wrw_det(dz.data_ptr(), M, a.data_ptr(), lda, ws.data_ptr(), dW.data_ptr(), acc, S, M, N,
-                                         dn._stream()))
+        _lib.check(L.mcl_conv1x1_wrw_det(dz.data_ptr(), M, a.data_ptr(), lda, None, None, None, None, ws.data_ptr(),
+                                         dW.data_ptr(), acc, S, M, N, dn._stream()))
         assert_close_scaled(dW.cpu(), (ref + (0.25 if acc else 0.0)).cpu(), 2e-5, what=f"wrw det acc={acc}")
         outs.append(dW)
     assert torch.equal(outs[0], outs[2])
+    # BatchNorm + ReLU prologue recomputed in registers (the bottleneck convolution's weight gradient on the side stream)
+    gam = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    bet = (torch.rand(N, generator=g) - 0.5).to(DEV)
+    mu = (torch.rand(N, generator=g) - 0.5).to(DEV)
+    rs = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    dW2 = torch.zeros((M, N), device=DEV)
+    _lib.check(L.mcl_conv1x1_wrw_det(dz.data_ptr(), M, a.data_ptr(), lda, gam.data_ptr(), bet.data_ptr(), mu.data_ptr(),
+                                     rs.data_ptr(), ws.data_ptr(), dW2.data_ptr(), 0, S, M, N, dn._stream()))
+    # the kernel's arithmetic exactly: sc = gamma*rstd (fp32), sh = fmaf(-mean, sc, beta), a' = bf16_rne(relu(fmaf(a, sc,
+    # sh))) -- fused multiply-adds restated through fp64 (products of a bf16/fp32 and an fp32 value are exact there)
+    sc = gam * rs
+    sh = (bet.double() - mu.double() * sc.double()).float()
+    ap = torch.relu(a.double() * sc.double() + sh.double()).float().to(torch.bfloat16)
+    assert_close_scaled(dW2.cpu(), (dz.double().t() @ ap.double()).cpu(), 2e-5, what="wrw det + prologue")
 
 
 @pytest.mark.parametrize("B,H,W,lddy", [(4, 56, 56, 256), (8, 28, 28, 32), (16, 14, 14, 1024), (32, 7, 7, 64), (3, 10, 6, 32)])

@@ -41,6 +41,7 @@ def timeit(fn, n=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default="")
+    ap.add_argument("--only", default="", help="substring filter on the call name")
     args = ap.parse_args()
     rows = []
     g = torch.Generator().manual_seed(0)
@@ -79,6 +80,8 @@ def main():
                                             2 * S * (128 + C) + 2 * S * (128 + 3 * C)),
             "r01 conv1x1_wrw (atomics)": (lambda: L.mcl_conv1x1_wrw_bf16(P(dz), 128, P(x), ld, P(gam), P(bet), P(mu), P(rs), P(dW1),
                                                                          C, S, 128, C, st()), 2 * S * (128 + C)),
+            "conv1x1_wrw_det (prologue, side)": (lambda: L.mcl_conv1x1_wrw_det(P(dz), 128, P(x), ld, P(gam), P(bet), P(mu), P(rs), P(ws),
+                                                                               P(dW1), 1, S, 128, C, st()), 2 * S * (128 + C)),
             "conv3x3_wrw_det": (lambda: L.mcl_dense_conv3x3_wrw_det(P(dy), ld, P(z), S, hw, hw, P(gam), P(bet), P(mu), P(rs), P(ws),
                                                                     P(dW2), 1, st()), 2 * S * 160),
             "r01 conv3x3_wrw (atomics)": (lambda: L.mcl_dense_conv3x3_wrw(P(dy), ld, P(z), S, hw, hw, P(gam), P(bet), P(mu), P(rs),
@@ -88,6 +91,8 @@ def main():
                                           2 * S * (32 + 128 + 128) + 2 * S * 384),
         }
         for name, (fn, nbytes) in calls.items():
+            if args.only and args.only not in name:
+                continue
             if C != SHAPES[[s[0] for s in SHAPES].index(S)][2] and "3x3" in name:
                 continue                                    # the 3x3 kernels do not depend on C_in: once per block
             def run(fn=fn, name=name):
