@@ -351,6 +351,16 @@ int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
                         const float* row_grad, int64_t ld_rg, double lr, double beta1, double beta2, double eps,
                         double weight_decay, double bc1, double bc2, mcl_stream_t stream);
+
+/* Graph-replayable Adam: the step counter (one int64) and the derived constants (8 floats) live on the device.
+ * mcl_adam_consts_update advances the counter and refreshes the constants (one thread, double arithmetic, rounded once
+ * as the host-constant entry points do); the _dev kernels read them, so nothing step-dependent is baked into a launch
+ * and the whole optimizer step can sit inside a captured HIP graph.                                             */
+int mcl_adam_consts_update(int64_t* step, float* consts, double lr, double beta1, double beta2, double eps,
+                           double weight_decay, mcl_stream_t stream);
+int mcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* consts, mcl_stream_t stream);
+int mcl_adam_table_step_dev(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
+                            const float* row_grad, int64_t ld_rg, const float* consts, mcl_stream_t stream);
 /* row_slot maintenance: set row_slot[owner_idx[b]] = b for owners (fill != 0) or back to -1.    */
 int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill, mcl_stream_t stream);
 

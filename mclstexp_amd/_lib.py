@@ -93,6 +93,9 @@ PROTOTYPES = {
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],
     "mcl_adam_step": [c_p, c_p, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
     "mcl_adam_table_step": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_d, c_d, c_d, c_d, c_d, c_d, c_d, c_p],
+    "mcl_adam_consts_update": [c_p, c_p, c_d, c_d, c_d, c_d, c_d, c_p],
+    "mcl_adam_step_dev": [c_p, c_p, c_p, c_p, c_l, c_p, c_p],
+    "mcl_adam_table_step_dev": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
     "mcl_bn_act_avgpool_fwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "mcl_bn_act_avgpool_bwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,

@@ -30,7 +30,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
-                                                   AdamC c) {
+                                                   AdamC c_host, const AdamC* __restrict__ c_dev) {
+  const AdamC c = c_dev ? *c_dev : c_host;      // device-resident constants: the launch can be replayed from a HIP graph
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
   float4* p4 = reinterpret_cast<float4*>(p);
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // unaligned fallback (base pointers not 16-byte aligned)
 __global__ __launch_bounds__(256) void adam_kernel_scalar(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, long long n,
-                                                          AdamC c) {
+                                                          AdamC c_host, const AdamC* __restrict__ c_dev) {
+  const AdamC c = c_dev ? *c_dev : c_host;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     adam1(p[i], g[i], m[i], v[i], c);
@@ -67,7 +69,9 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, float* __restrict__ m,
                                                          float* __restrict__ v, int n_rows, int cols,
                                                          const int* __restrict__ row_slot,
-                                                         const float* __restrict__ rg, long long ldrg, AdamC c) {
+                                                         const float* __restrict__ rg, long long ldrg, AdamC c_host,
+                                                         const AdamC* __restrict__ c_dev) {
+  const AdamC c = c_dev ? *c_dev : c_host;
   if (VEC) {
     constexpr int RPI = 4;
     const int c4 = cols >> 2;
@@ -111,6 +115,27 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
   }
 }
 
+// One thread: advances the device-resident step counter and derives this step's constants from it (double arithmetic,
+// rounded once, exactly as make_consts does on the host).  With the counter on the device the whole optimizer step can
+// be captured in a HIP graph and replayed: nothing step-dependent is baked into the launches.
+__global__ void adam_consts_kernel(long long* __restrict__ step, AdamC* __restrict__ out, double lr, double b1, double b2,
+                                   double eps, double wd) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t = *step + 1;
+  *step = t;
+  const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+  AdamC c;
+  c.lr_over_bc1 = (float)(lr / bc1);
+  c.beta1 = (float)b1;
+  c.beta2 = (float)b2;
+  c.omb1 = (float)(1.0 - b1);
+  c.omb2 = (float)(1.0 - b2);
+  c.eps = (float)eps;
+  c.wd = (float)wd;
+  c.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  *out = c;
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 
 // Scalars arrive as doubles (Python floats on the host side, as in torch.optim) and are rounded once.
@@ -129,23 +154,44 @@ inline AdamC make_consts(double lr, double b1, double b2, double eps, double wd,
 
 }  // namespace
 
+namespace {
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, const AdamC& c, const AdamC* c_dev,
+                hipStream_t st) {
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (al16(p) && al16(g) && al16(m) && al16(v))
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, c, c_dev);
+  else
+    hipLaunchKernelGGL(adam_kernel_scalar, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, c, c_dev);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+int launch_adam_table(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
+                      const float* row_grad, int64_t ld_rg, const AdamC& c, const AdamC* c_dev, hipStream_t st) {
+  // one 4-row group per workgroup (no grid-stride loop): the hardware dispatcher balances 16 K short workgroups
+  // better than 4 K persistent ones -- measured in bench.py on one box: 6.00 vs 5.33 TB/s
+  const int blocks = (n_rows + 3) / 4;
+  const bool vec = (cols % 4 == 0) && (ld_rg % 4 == 0) && al16(p) && al16(m) && al16(v) && al16(row_grad);
+  if (vec)
+    hipLaunchKernelGGL((adam_table_kernel<true>), dim3(blocks), dim3(256), 0, st, p, m, v, n_rows, cols, row_slot,
+                       row_grad, (long long)ld_rg, c, c_dev);
+  else
+    hipLaunchKernelGGL((adam_table_kernel<false>), dim3(blocks), dim3(256), 0, st, p, m, v, n_rows, cols, row_slot,
+                       row_grad, (long long)ld_rg, c, c_dev);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+}  // namespace
+
 extern "C" int mcl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1,
                              double beta2, double eps, double weight_decay, double bc1, double bc2,
                              mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!p || !g || !m || !v || n <= 0 || bc1 <= 0. || bc2 <= 0.) return MCL_EINVAL;
-  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
-  long long blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  if (al16(p) && al16(g) && al16(m) && al16(v))
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), p, g, m, v,
-                       (long long)n, c);
-  else
-    hipLaunchKernelGGL(adam_kernel_scalar, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), p, g, m, v,
-                       (long long)n, c);
-  MCL_CHECK_LAUNCH();
-  return MCL_OK;
+  return launch_adam(p, g, m, v, n, make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2), nullptr,
+                     mcl_stream(stream));
 }
 
 extern "C" int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t cols,
@@ -155,17 +201,33 @@ extern "C" int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows,
   MCL_CLEAR_ERROR();
   if (!p || !m || !v || !row_slot || !row_grad || n_rows <= 0 || cols <= 0 || bc1 <= 0. || bc2 <= 0.)
     return MCL_EINVAL;
-  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2);
-  // one 4-row group per workgroup (no grid-stride loop): the hardware dispatcher balances 16 K short workgroups
-  // better than 4 K persistent ones -- measured in bench.py on one box: 6.00 vs 5.33 TB/s
-  const int blocks = (n_rows + 3) / 4;
-  const bool vec = (cols % 4 == 0) && (ld_rg % 4 == 0) && al16(p) && al16(m) && al16(v) && al16(row_grad);
-  if (vec)
-    hipLaunchKernelGGL((adam_table_kernel<true>), dim3(blocks), dim3(256), 0, mcl_stream(stream), p, m, v, n_rows,
-                       cols, row_slot, row_grad, (long long)ld_rg, c);
-  else
-    hipLaunchKernelGGL((adam_table_kernel<false>), dim3(blocks), dim3(256), 0, mcl_stream(stream), p, m, v, n_rows,
-                       cols, row_slot, row_grad, (long long)ld_rg, c);
+  return launch_adam_table(p, m, v, n_rows, cols, row_slot, row_grad, ld_rg,
+                           make_consts(lr, beta1, beta2, eps, weight_decay, bc1, bc2), nullptr, mcl_stream(stream));
+}
+
+// ---- graph-replayable form: the step counter and the derived constants live on the device
+extern "C" int mcl_adam_consts_update(int64_t* step, float* consts /* 8 floats */, double lr, double beta1, double beta2,
+                                      double eps, double weight_decay, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!step || !consts) return MCL_EINVAL;
+  hipLaunchKernelGGL(adam_consts_kernel, dim3(1), dim3(64), 0, mcl_stream(stream), (long long*)step,
+                     reinterpret_cast<AdamC*>(consts), lr, beta1, beta2, eps, weight_decay);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
+}
+
+extern "C" int mcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* consts,
+                                 mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!p || !g || !m || !v || !consts || n <= 0) return MCL_EINVAL;
+  return launch_adam(p, g, m, v, n, AdamC{}, reinterpret_cast<const AdamC*>(consts), mcl_stream(stream));
+}
+
+extern "C" int mcl_adam_table_step_dev(float* p, float* m, float* v, int32_t n_rows, int32_t cols,
+                                       const int32_t* row_slot, const float* row_grad, int64_t ld_rg,
+                                       const float* consts, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!p || !m || !v || !row_slot || !row_grad || !consts || n_rows <= 0 || cols <= 0) return MCL_EINVAL;
+  return launch_adam_table(p, m, v, n_rows, cols, row_slot, row_grad, ld_rg, AdamC{},
+                           reinterpret_cast<const AdamC*>(consts), mcl_stream(stream));
 }

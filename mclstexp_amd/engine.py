@@ -44,6 +44,7 @@ class TrainStep:
         self.single_graph = bool(single_graph) and can_single
         self._sizes_ex = None
         self._all_regular = True
+        self.opt_in_graph = False
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
@@ -82,9 +83,15 @@ class TrainStep:
                 self.es, self.ei = m.embed(self.static_in)
                 self.loss, d_es, d_ei = m.loss_and_grads(self.es, self.ei)
                 self.opt.zero_grad()
+                if getattr(m, "embedding_grad", "dense") == "rowsparse":
+                    m.sparse_grads["static"] = True          # the captured backward's dout / ix / iy are static buffers
                 torch.autograd.backward((self.es, self.ei), (d_es, d_ei))
-            if getattr(m, "embedding_grad", "dense") == "rowsparse":
-                m.sparse_grads["static"] = True
+                # the optimizer too: FusedAdam keeps its step counter and constants on the device (optim._begin_step), so
+                # its launches replay unchanged -- no eager launches between two replays
+                self.opt_in_graph = hasattr(self.opt, "_begin_step")
+                if self.opt_in_graph:
+                    self.opt.step()
+                    self.opt._step_count -= 1    # capture records launches, it does not run them: the replay counts
             torch.cuda.synchronize()
             return
         with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
@@ -109,8 +116,10 @@ class TrainStep:
         rowsparse = sink is not None and getattr(self.model, "embedding_grad", "dense") == "rowsparse"
         saved = {}
         if rowsparse:
-            saved = {k: sink[k] for k in ("dout", "ix", "iy") if k in sink}
+            saved = {k: sink[k] for k in ("dout", "ix", "iy", "hook") if k in sink}
             sink.clear()
+            if "hook" in saved:
+                sink["hook"] = saved["hook"]
         try:
             return self._eager(batch)
         finally:
@@ -160,7 +169,10 @@ class TrainStep:
             v.copy_(batch[k], non_blocking=True)
         self.ga.replay()
         if self.single_graph:
-            self._reduce_and_step()
+            if self.opt_in_graph:
+                self.opt._step_count += 1        # host mirror of the device step counter
+            else:
+                self._reduce_and_step()
             return self.loss.clone()
         loss, d_es, d_ei = self.model.loss_and_grads(self.es, self.ei)
         self.d_es.copy_(d_es)

@@ -33,9 +33,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._where: Dict[int, tuple] = {}        # id(param) -> (group index, element offset in the flat buffer)
         self._sink: Optional[dict] = None
         self._pver: Dict[int, int] = {}           # id(param) -> autograd version at the last shadow refresh
-        # bench.py sets this to a list to time every adam_table_kernel launch with HIP events recorded on
-        # the launch stream: [(start_event, end_event), ...]
-        self.profile_events: Optional[list] = None
+        # device-resident step counter + derived constants per param group (csrc/adam.hip: mcl_adam_consts_update): nothing
+        # step-dependent is baked into a launch, so step() can be captured in a HIP graph and replayed
+        self._dev: Dict[int, dict] = {}
+        self._began = False                       # this step's constants are already on the device (early table update)
+        self._group_of: Dict[int, int] = {}       # id(param) -> group index
 
     # ------------------------------------------------------------------ wiring
     def attach_model(self, model) -> "FusedAdam":
@@ -47,6 +49,15 @@ class FusedAdam(torch.optim.Optimizer):
                 self._tables[id(emb.weight)] = {"key": key, "param": emb.weight}
         if self.process_group is None:
             self.process_group = getattr(model, "process_group", None)
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                self._group_of[id(p)] = gi
+        # Single process: the position tables are updated as soon as their gradient rows exist -- from inside
+        # PosEmbedAddFn.backward, i.e. on the spot-branch stream while the image backbone's backward is still running on
+        # the main stream (0.5 ms of HBM-bound work off the critical path; under HIP-graph capture a parallel branch).
+        # Data parallel keeps the update in step(): it needs the gathered rows of every rank.
+        if self._sink is not None and self.process_group is None:
+            self._sink["hook"] = self._early_tables
         # load_state_dict() into a live model rewrites the flat fp32 buffer behind the bf16 shadows' back (captured
         # HIP graphs read the shadows directly, so the lazy per-parameter check in shadow() cannot catch that case)
         if hasattr(model, "register_load_state_dict_post_hook"):
@@ -164,27 +175,25 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        self._step_count += 1
-        t = self._step_count
         L = _lib.lib()
         st = ops._stream()
+        self._begin_step()
+        tables_done = self._sink is not None and self._sink.pop("tables_done", False)
         deferred = []
         for gi, group in enumerate(self.param_groups):
-            b1, b2 = group["betas"]
-            lr, eps, wd = group["lr"], group["eps"], group["weight_decay"]
-            bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
             if gi not in self._flat:
                 self._build_flat(gi, group)
             f = self._flat[gi]
             flat_ids = {id(p) for p in f["params"]}
             if f["n"] > 0:
-                deferred.append((f, lr, b1, b2, eps, wd, bc1, bc2))      # after the tables / the pending all-reduce
+                deferred.append((gi, f))                       # after the tables / the pending all-reduce
             for p in group["params"]:
                 if id(p) in flat_ids:
                     continue
                 tab = self._tables.get(id(p))
-                if tab is not None and self._sink is not None and "dout" in self._sink:
-                    self._table_step(L, st, p, tab, lr, b1, b2, eps, wd, bc1, bc2)
+                if tab is not None and self._sink is not None and (tables_done or "dout" in self._sink):
+                    if not tables_done:
+                        self._table_step(L, st, p, tab, gi)
                     continue
                 if p.grad is None:
                     continue                        # torch.optim.Adam skips parameters without a gradient
@@ -195,23 +204,67 @@ class FusedAdam(torch.optim.Optimizer):
                 g = p.grad
                 if g.stride() != p.stride():
                     g = torch.empty_like(p).copy_(g)   # same memory order as p (the update is elementwise)
-                check(L.mcl_adam_step(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
-                                      state["exp_avg_sq"].data_ptr(), p.numel(), lr, b1, b2, eps, wd, bc1, bc2, st),
-                      "mcl_adam_step")
+                check(L.mcl_adam_step_dev(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(),
+                                          state["exp_avg_sq"].data_ptr(), p.numel(),
+                                          self._dev_state(gi, p.device)["consts"].data_ptr(), st), "mcl_adam_step_dev")
         for h in (wait or []):
             h.wait()
-        for f, lr, b1, b2, eps, wd, bc1, bc2 in deferred:
-            check(L.mcl_adam_step(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
-                                  f["n"], lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_step")
+        for gi, f in deferred:
+            check(L.mcl_adam_step_dev(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
+                                      f["n"], self._dev_state(gi, f["p"].device)["consts"].data_ptr(), st),
+                  "mcl_adam_step_dev")
         if self._sink is not None:
             if self._sink.get("static"):
                 # graph-captured backward: dout/ix/iy are static buffers refreshed by every replay
                 for k in ("g_dout", "g_ix", "g_iy"):
                     self._sink.pop(k, None)
             else:
+                hook = self._sink.get("hook")
                 self._sink.clear()
+                if hook is not None:
+                    self._sink["hook"] = hook
+        self._began = False
+        self._step_count += 1
         self._refresh_shadows()
         return loss
+
+    # ------------------------------------------------------------------ device-resident step state
+    def _dev_state(self, gi: int, device) -> dict:
+        d = self._dev.get(gi)
+        if d is None:
+            d = {"step": torch.full((1,), self._step_count, dtype=torch.int64, device=device),
+                 "consts": torch.zeros(8, dtype=torch.float32, device=device)}
+            self._dev[gi] = d
+        return d
+
+    def _begin_step(self) -> None:
+        """Advance the device step counters and refresh the constants -- once per optimisation step, by whoever comes
+        first: the early table update (inside backward) or step()."""
+        if self._began:
+            return
+        self._began = True
+        L = _lib.lib()
+        st = ops._stream()
+        for gi, group in enumerate(self.param_groups):
+            dev = next((p.device for p in group["params"] if p.is_cuda), None)
+            if dev is None:
+                continue
+            d = self._dev_state(gi, dev)
+            b1, b2 = group["betas"]
+            check(L.mcl_adam_consts_update(d["step"].data_ptr(), d["consts"].data_ptr(), group["lr"], b1, b2,
+                                           group["eps"], group["weight_decay"], st), "mcl_adam_consts_update")
+
+    def _early_tables(self) -> None:
+        """Called by ops.PosEmbedAddFn.backward once sink['dout'|'ix'|'iy'] exist (single process)."""
+        if self._sink is None or "dout" not in self._sink:
+            return
+        L = _lib.lib()
+        st = ops._stream()
+        self._begin_step()
+        for tab in self._tables.values():
+            p = tab["param"]
+            self._table_step(L, st, p, tab, self._group_of[id(p)])
+        self._sink["tables_done"] = True
 
     # ------------------------------------------------------------------ tables
     def _gathered(self):
@@ -227,7 +280,7 @@ class FusedAdam(torch.optim.Optimizer):
         s["g_dout"], s["g_ix"], s["g_iy"] = dout, ix, iy
         return dout, ix, iy
 
-    def _table_step(self, L, st, p, tab, lr, b1, b2, eps, wd, bc1, bc2) -> None:
+    def _table_step(self, L, st, p, tab, gi: int) -> None:
         state = self.state[p]
         if not state:
             state["exp_avg"] = torch.zeros_like(p)
@@ -238,13 +291,8 @@ class FusedAdam(torch.optim.Optimizer):
         B = rs.rows.shape[0]
         slot = state["row_slot"]
         check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 1, st), "mcl_row_slot_update")
-        if self.profile_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        check(L.mcl_adam_table_step(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                    p.shape[0], p.shape[1], slot.data_ptr(), rs.rows.data_ptr(), rs.rows.stride(0),
-                                    lr, b1, b2, eps, wd, bc1, bc2, st), "mcl_adam_table_step")
-        if self.profile_events is not None:
-            e1.record()
-            self.profile_events.append((e0, e1))
+        check(L.mcl_adam_table_step_dev(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                                        p.shape[0], p.shape[1], slot.data_ptr(), rs.rows.data_ptr(), rs.rows.stride(0),
+                                        self._dev_state(gi, p.device)["consts"].data_ptr(), st),
+              "mcl_adam_table_step_dev")
         check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 0, st), "mcl_row_slot_update")
