@@ -88,12 +88,16 @@ class TrainStep:
                 torch.autograd.backward((self.es, self.ei), (d_es, d_ei))
                 # the optimizer too: FusedAdam keeps its step counter and constants on the device (optim._begin_step), so
                 # its launches replay unchanged -- no eager launches between two replays
-                self.opt_in_graph = hasattr(self.opt, "_begin_step")
+                self.opt_in_graph = hasattr(self.opt, "_begin_step") and os.environ.get("MCL_OPT_IN_GRAPH", "1") != "0"
                 if self.opt_in_graph:
                     self.opt.step()
                     self.opt._step_count -= 1    # capture records launches, it does not run them: the replay counts
             torch.cuda.synchronize()
             return
+        # two graphs with eager work between them: the early position-table update (a hook inside backward that also
+        # advances the device step counter) would be replayed by graph B AND repeated by the eager step() -> off here
+        if getattr(m, "sparse_grads", None) is not None:
+            m.sparse_grads.pop("hook", None)
         with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
             self.es, self.ei = m.embed(self.static_in)
         self.d_es = torch.zeros_like(self.es)
