@@ -163,6 +163,26 @@ int mcl_infonce_fused_grad(const void* a, int64_t lda, const void* b, int64_t ld
 int mcl_cast_f32_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols,
                          mcl_stream_t stream);
 
+/* ---- fp8 (OCP e4m3) similarity contraction for the InfoNCE (csrc/infonce_fp8.hip; BASELINE configs[4]).
+ * mcl_quant_e4m3_rows: per row one power-of-two scale 2^e (smallest with max|x| <= 448 * 2^e); q = e4m3_rne(x 2^-e),
+ * scale byte = e + 127 (E8M0, what v_mfma_scale_f32_32x32x64_f8f6f4 consumes); optionally the dequantised copy in
+ * bf16 (exactly representable).  x (rows, 256) fp32 row stride ldx; q (rows, 256) bytes row stride ldq; scale bytes
+ * with byte stride ld_scale; deq (rows, 256) bf16 row stride ldd or NULL.  cols must be 256.                       */
+int mcl_quant_e4m3_rows(const float* x, int64_t ldx, int32_t rows, int32_t cols, void* q, int64_t ldq, void* scale,
+                        int64_t ld_scale, void* deq_bf16, int64_t ldd, mcl_stream_t stream);
+int mcl_dequant_e4m3_rows(const void* q, int64_t ldq, const void* scale, int64_t ld_scale, int32_t rows, int32_t cols,
+                          void* deq_bf16, int64_t ldd, mcl_stream_t stream);
+/* lse[r] = log sum_c exp(inv_temp * sum_k (a8[r][k] 2^(sa[r]-127)) (b8[c][k] 2^(sb[c]-127))), logits never in HBM,
+ * fp8 MFMA with hardware block scales, fp32 accumulate and statistics.  a8 (R, 256), b8 (C, 256) e4m3 bytes, row
+ * strides multiples of 16.  workspace: mcl_infonce_fp8_workspace_bytes(R, C).                                      */
+int64_t mcl_infonce_fp8_workspace_bytes(int32_t R, int32_t C);
+int mcl_infonce_fp8_lse(const void* a8, int64_t lda, const void* scale_a, int64_t ld_sa, const void* b8, int64_t ldb,
+                        const void* scale_b, int64_t ld_sb, int32_t R, int32_t C, int32_t dim, float inv_temp, float* lse,
+                        void* workspace, int64_t ws_bytes, mcl_stream_t stream);
+/* diag[r] = inv_temp * a[r] . b[r + diag_off] on bf16 rows (rows whose partner lies outside [0, C) are left untouched) */
+int mcl_infonce_rowdot_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, int32_t R, int32_t C, int32_t dim,
+                            int32_t diag_off, float inv_temp, float* diag, mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K10 DenseNet BatchNorm(+ReLU), channels-last
  * Train-mode nn.BatchNorm2d (+ nn.ReLU) of the torchvision DenseNet-121 feature extractor that
  * model.py:75-76 wraps, on NHWC activations viewed as (S = B*H*W rows) x (C channels) with a row stride

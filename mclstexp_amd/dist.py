@@ -256,6 +256,32 @@ class HipFusedPrims:
         return ops.infonce_fused_grad(a16, b16, inv_t, lse_a, lse_b, coef, diag_off)
 
 
+class HipFp8Prims:
+    """fp8 similarity contraction under data parallelism: the all-gather ships the packed e4m3 rows (256 bytes + the
+    scale byte, 272 B per embedding instead of 1024 B fp32 / 512 B bf16); LSEs on the fp8 MFMA kernel, gradients on the
+    bf16 strip kernel over the (exact) dequantised copies."""
+    width = 272
+
+    @staticmethod
+    def cast(x: Tensor) -> Tensor:
+        from . import ops
+        return ops.quant_e4m3(x, want_deq=False)[0]
+
+    @staticmethod
+    def lse(a8: Tensor, b8: Tensor, inv_t: float, diag_off: int) -> Tuple[Tensor, Tensor]:
+        from . import ops
+        a8c, b8c = a8.contiguous(), b8.contiguous()
+        lse = ops.infonce_fp8_lse(a8c, b8c, inv_t)
+        diag = ops.infonce_rowdot(ops.dequant_e4m3(a8c), ops.dequant_e4m3(b8c), inv_t, diag_off)
+        return lse, diag
+
+    @staticmethod
+    def grad(a8: Tensor, b8: Tensor, inv_t: float, lse_a: Tensor, lse_b: Tensor, coef: float, diag_off: int) -> Tensor:
+        from . import ops
+        return ops.infonce_fused_grad(ops.dequant_e4m3(a8.contiguous()), ops.dequant_e4m3(b8.contiguous()), inv_t,
+                                      lse_a, lse_b, coef, diag_off)
+
+
 def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, pg, prims=HipFusedPrims,
                                sizes: Optional[Sequence[int]] = None) -> Tuple[Tensor, Tensor, Tensor, None]:
     """Same global symmetric InfoNCE as ``dist_infonce_fwd_bwd`` on the fused kernels: the embeddings are rounded
@@ -269,10 +295,11 @@ def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
     b_glob = world * b_loc if sizes is None else sum(sizes)
     doff = rank * b_loc if sizes is None else sum(sizes[:rank])
     inv_t = 1.0 / temperature
-    loc16 = torch.cat([prims.cast(e_spot), prims.cast(e_img)], dim=1)       # (B_loc, 2P) low precision
-    all16 = _all_gather_rows(loc16, pg, sizes)                               # collective 1: (B_glob, 2P)
-    es_loc, ei_loc = loc16[:, :P], loc16[:, P:]                              # row stride 2P: read in place
-    es_all, ei_all = all16[:, :P], all16[:, P:]
+    loc16 = torch.cat([prims.cast(e_spot), prims.cast(e_img)], dim=1)       # (B_loc, 2W) low precision
+    all16 = _all_gather_rows(loc16, pg, sizes)                               # collective 1: (B_glob, 2W)
+    Wc = getattr(prims, "width", P)                                          # columns of one embedding in cast form
+    es_loc, ei_loc = loc16[:, :Wc], loc16[:, Wc:]                            # row stride 2W: read in place
+    es_all, ei_all = all16[:, :Wc], all16[:, Wc:]
     rl, diag = prims.lse(es_loc, ei_all, inv_t, doff)                        # rows of S owned by this rank
     cl, _ = prims.lse(ei_loc, es_all, inv_t, doff)                           # columns of S owned by this rank
     packed = _all_gather_rows(torch.stack([rl, cl, diag], dim=1), pg, sizes)  # collective 2: (B_glob, 3)
@@ -289,8 +316,11 @@ def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
 class DistInfoNCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e_spot, e_img, temperature, pg, stash, fused=False):
-        fn = dist_infonce_fused_fwd_bwd if fused else dist_infonce_fwd_bwd
-        loss, d_es, d_ei, s_rows = fn(e_spot, e_img, temperature, pg)
+        if fused == "fp8":
+            loss, d_es, d_ei, s_rows = dist_infonce_fused_fwd_bwd(e_spot, e_img, temperature, pg, prims=HipFp8Prims)
+        else:
+            fn = dist_infonce_fused_fwd_bwd if fused else dist_infonce_fwd_bwd
+            loss, d_es, d_ei, s_rows = fn(e_spot, e_img, temperature, pg)
         if stash is not None:
             stash["logits"] = s_rows
         ctx.save_for_backward(d_es, d_ei)

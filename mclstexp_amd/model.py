@@ -196,9 +196,9 @@ class _ContrastiveBase(nn.Module):
 
     def _init_common(self, temperature, compute, backbone_dtype, embedding_grad, process_group, infonce="exact"):
         self.temperature = temperature
-        if infonce not in ("exact", "fused"):
-            raise ValueError("infonce must be 'exact' (fp32 logits, reference numerics) or 'fused' (bf16 MFMA, "
-                             "logits never written to HBM)")
+        if infonce not in ("exact", "fused", "fp8"):
+            raise ValueError("infonce must be 'exact' (fp32 logits, reference numerics), 'fused' (bf16 MFMA, logits "
+                             "never written to HBM) or 'fp8' (e4m3 similarity contraction, BASELINE configs[4])")
         self.infonce = infonce
         if embedding_grad not in ("dense", "rowsparse"):
             raise ValueError("embedding_grad must be 'dense' or 'rowsparse'")
@@ -282,9 +282,12 @@ class _ContrastiveBase(nn.Module):
         if self.process_group is not None:
             from . import dist as mdist
             return mdist.DistInfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature),
-                                             self.process_group, stash, self.infonce == "fused")
+                                             self.process_group, stash, self._fused_mode())
         return ops.InfoNCEFn.apply(spot_embeddings, image_embeddings, float(self.temperature), stash,
-                                   self.infonce == "fused")
+                                   self._fused_mode())
+
+    def _fused_mode(self):
+        return {"exact": False, "fused": True, "fp8": "fp8"}[self.infonce]
 
 
     # ---- split form of forward(), used by engine.TrainStep (HIP-graph capture around the collectives)
@@ -301,11 +304,17 @@ class _ContrastiveBase(nn.Module):
         soft = self._soft_clip()
         if soft is not None:
             return ops.soft_clip_fwd_bwd(es, ei, float(self.temperature), soft)
-        fused = self.infonce == "fused"
+        fused = self.infonce != "exact"
         if self.process_group is not None:
             from . import dist as mdist
-            fn = mdist.dist_infonce_fused_fwd_bwd if fused else mdist.dist_infonce_fwd_bwd
-            loss, d_es, d_ei, s = fn(es, ei, float(self.temperature), self.process_group)
+            if self.infonce == "fp8":
+                loss, d_es, d_ei, s = mdist.dist_infonce_fused_fwd_bwd(es, ei, float(self.temperature),
+                                                                       self.process_group, prims=mdist.HipFp8Prims)
+            else:
+                fn = mdist.dist_infonce_fused_fwd_bwd if fused else mdist.dist_infonce_fwd_bwd
+                loss, d_es, d_ei, s = fn(es, ei, float(self.temperature), self.process_group)
+        elif self.infonce == "fp8":
+            loss, d_es, d_ei, s = ops.infonce_fp8_fwd_bwd(es, ei, float(self.temperature))
         elif fused:
             loss, d_es, d_ei, s = ops.infonce_fused_fwd_bwd(es, ei, float(self.temperature))
         else:

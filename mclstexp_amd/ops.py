@@ -472,13 +472,96 @@ def infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
     return loss, d_es, d_ei, None
 
 
+# --------------------------------------------------------------------------- fp8 similarity contraction (configs[4])
+FP8_ROW = FUSED_DIM + 16        # packed row: 256 e4m3 bytes + the E8M0 scale byte, padded to a 16-byte multiple
+
+
+def quant_e4m3(x: Tensor, want_deq: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """fp32 (rows, 256) -> (packed uint8 (rows, 272): e4m3 bytes [:256] + scale byte [256], bf16 dequantised copy).
+    One power-of-two scale per row (csrc/infonce_fp8.hip); the dequantised values are exactly representable in bf16."""
+    x = _rowmajor(x, "x")
+    rows, cols = x.shape
+    if cols != FUSED_DIM:
+        raise RuntimeError(f"the fp8 InfoNCE kernels are built for projection_dim {FUSED_DIM}, got {cols}")
+    packed = torch.zeros((rows, FP8_ROW), device=x.device, dtype=torch.uint8)
+    deq = torch.empty((rows, cols), device=x.device, dtype=torch.bfloat16) if want_deq else None
+    check(_lib.lib().mcl_quant_e4m3_rows(x.data_ptr(), x.stride(0), rows, cols, packed.data_ptr(), FP8_ROW,
+                                         packed.data_ptr() + FUSED_DIM, FP8_ROW, _p(deq), cols if want_deq else 0,
+                                         _stream()), "mcl_quant_e4m3_rows")
+    return packed, deq
+
+
+def _fp8_rows(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 2 or t.stride(1) != 1 or t.shape[1] != FP8_ROW or \
+            t.stride(0) % 16 or t.data_ptr() % 16:
+        raise RuntimeError(f"{name}: expected packed e4m3 rows (uint8, {FP8_ROW} columns, 16-byte aligned rows)")
+    return t
+
+
+def dequant_e4m3(packed: Tensor) -> Tensor:
+    packed = _fp8_rows(packed, "packed")
+    rows = packed.shape[0]
+    deq = torch.empty((rows, FUSED_DIM), device=packed.device, dtype=torch.bfloat16)
+    check(_lib.lib().mcl_dequant_e4m3_rows(packed.data_ptr(), packed.stride(0), packed.data_ptr() + FUSED_DIM,
+                                           packed.stride(0), rows, FUSED_DIM, deq.data_ptr(), FUSED_DIM, _stream()),
+          "mcl_dequant_e4m3_rows")
+    return deq
+
+
+def infonce_fp8_lse(a8: Tensor, b8: Tensor, inv_t: float) -> Tensor:
+    """lse (R,) of S = dequant(a8) dequant(b8)^T * inv_t on the fp8 MFMA (hardware block scales), S never in HBM."""
+    a8, b8 = _fp8_rows(a8, "a8"), _fp8_rows(b8, "b8")
+    R, Cn = a8.shape[0], b8.shape[0]
+    L = _lib.lib()
+    need = L.mcl_infonce_fp8_workspace_bytes(R, Cn)
+    ws = _fused_workspace(R, Cn, a8.device)
+    if ws.numel() < need:
+        ws = torch.empty(int(need), device=a8.device, dtype=torch.uint8)
+    lse = torch.empty((R,), device=a8.device, dtype=torch.float32)
+    check(L.mcl_infonce_fp8_lse(a8.data_ptr(), a8.stride(0), a8.data_ptr() + FUSED_DIM, a8.stride(0), b8.data_ptr(),
+                                b8.stride(0), b8.data_ptr() + FUSED_DIM, b8.stride(0), R, Cn, FUSED_DIM, inv_t,
+                                lse.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "mcl_infonce_fp8_lse")
+    return lse
+
+
+def infonce_rowdot(a16: Tensor, b16: Tensor, inv_t: float, diag_off: int = 0) -> Tensor:
+    a16, b16 = _bf16_rows(a16, "a"), _bf16_rows(b16, "b")
+    R, Cn = a16.shape[0], b16.shape[0]
+    diag = torch.zeros((R,), device=a16.device, dtype=torch.float32)
+    check(_lib.lib().mcl_infonce_rowdot_bf16(a16.data_ptr(), a16.stride(0), b16.data_ptr(), b16.stride(0), R, Cn, FUSED_DIM,
+                                             diag_off, inv_t, diag.data_ptr(), _stream()), "mcl_infonce_rowdot_bf16")
+    return diag
+
+
+def infonce_fp8_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
+                        ) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """Symmetric InfoNCE with the similarity contraction on e4m3 operands (per-row power-of-two scales): the row and
+    column LSEs come from the fp8 MFMA kernel; the closed-form gradient runs the bf16 strip kernel on the dequantised
+    embeddings, which are bit-exact bf16 images of the fp8 operands (so the probabilities it forms are normalised by
+    exactly these LSEs).  Returns (loss, dE_spot, dE_img, None)."""
+    s8, s16 = quant_e4m3(e_spot)
+    i8, i16 = quant_e4m3(e_img)
+    B = s8.shape[0]
+    inv_t = 1.0 / temperature
+    rl = infonce_fp8_lse(s8, i8, inv_t)
+    cl = infonce_fp8_lse(i8, s8, inv_t)
+    diag = infonce_rowdot(s16, i16, inv_t)
+    loss = ((rl - diag).sum() + (cl - diag).sum()) / (2.0 * B)
+    coef = inv_t / (2.0 * B)
+    d_es = infonce_fused_grad(s16, i16, inv_t, rl, cl, coef)
+    d_ei = infonce_fused_grad(i16, s16, inv_t, cl, rl, coef)
+    return loss, d_es, d_ei, None
+
+
 class InfoNCEFn(torch.autograd.Function):
     """loss = 0.5*[CE(S, I) + CE(S^T, I)], S = E_spot E_img^T / T.  Forward and backward are computed
     together (closed-form dS from the two LSE vectors); autograd's backward only scales by grad_output."""
 
     @staticmethod
     def forward(ctx, e_spot, e_img, temperature, stash, fused=False):
-        if fused:
+        if fused == "fp8":
+            loss, d_es, d_ei, S = infonce_fp8_fwd_bwd(e_spot, e_img, temperature)
+        elif fused:
             loss, d_es, d_ei, S = infonce_fused_fwd_bwd(e_spot, e_img, temperature)
         else:
             loss, d_es, d_ei, S = infonce_fwd_bwd(e_spot, e_img, temperature, want_logits=stash is not None)

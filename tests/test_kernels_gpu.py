@@ -359,6 +359,104 @@ def test_infonce_fused_spike_forces_rescale(ops):
     assert_close(lse.cpu(), lse_ref, 1e-3, rtol=1e-5, what="lse with a late spike")
 
 
+# ------------------------------------------------------------------ fp8 similarity contraction (BASELINE configs[4])
+def _quant_ref(x):
+    """The quantiser's contract restated with torch's own OCP e4m3 cast: per row the smallest power-of-two scale 2^e
+    with max|x| <= 448 * 2^e, q = e4m3_rne(x * 2^-e); returns (bytes, e, dequantised fp32)."""
+    amax = x.abs().amax(dim=1)
+    e = torch.ceil(torch.log2(amax.double() / 448.0)).clamp(-126, 126)
+    e = torch.where(amax > 0, e, torch.zeros_like(e))
+    inv = torch.pow(2.0, -e).float()[:, None]
+    q = (x * inv).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), e.to(torch.int64), q.float() * torch.pow(2.0, e).float()[:, None]
+
+
+@pytest.mark.parametrize("rows", [1, 5, 128, 1000])
+def test_quant_e4m3_rows(ops, rows):
+    """Row-scaled e4m3 quantiser: bytes and E8M0 scale bytes equal torch's float8_e4m3fn cast of the scaled rows, the
+    bf16 dequantised copy is exact, dequant(quant) round-trips bit for bit."""
+    g = torch.Generator().manual_seed(rows)
+    x = torch.nn.functional.layer_norm(torch.randn(rows, 256, generator=g), (256,)) * (0.01 + 3.0 * torch.rand(rows, 1, generator=g))
+    if rows > 2:
+        x[1] = 0.0                                         # all-zero row: e = 0, q = 0
+        x[2, 7] = 448.0 * 4.0                              # exactly on a scale boundary
+    packed, deq = ops.quant_e4m3(x.to(DEV))
+    qb, e, dq = _quant_ref(x)
+    assert torch.equal(packed[:, :256].cpu(), qb), "e4m3 bytes"
+    assert torch.equal(packed[:, 256].cpu().to(torch.int64), e + 127), "E8M0 scale bytes"
+    assert torch.equal(deq.float().cpu(), dq), "dequantised copy (exact in bf16)"
+    assert torch.equal(ops.dequant_e4m3(packed).cpu(), deq.cpu())
+    # relative quantisation error of a row: <= 2^-4 of the row maximum scale
+    assert ((dq - x).abs() <= 2.0 ** -4 * x.abs().clamp_min(2.0 ** -9 * torch.pow(2.0, e).float()[:, None]) + 1e-30).all()
+
+
+@pytest.mark.parametrize("R,C,T", [(128, 128, 1.0), (33, 33, 0.5), (256, 1024, 1.0), (200, 333, 2.0), (1, 1, 1.0),
+                                   (129, 2049, 1.0), (2048, 2048, 1.0)])
+def test_infonce_fp8_lse(ops, R, C, T):
+    """fp8 MFMA row LSE (hardware E8M0 block scales, logits never in HBM) vs fp64 logsumexp of the DEQUANTISED operands:
+    2e-4/T absolute -- the products are exact, only the fp32 accumulation order differs; ragged tiles, column splits."""
+    g = torch.Generator().manual_seed(R * 7 + C)
+    a = torch.nn.functional.layer_norm(torch.randn(R, 256, generator=g), (256,))
+    b = torch.nn.functional.layer_norm(torch.randn(C, 256, generator=g), (256,))
+    n = min(R, C)
+    b[:n] += 0.08 * a[:n]
+    inv_t = 1.0 / T
+    a8, a16 = ops.quant_e4m3(a.to(DEV))
+    b8, b16 = ops.quant_e4m3(b.to(DEV))
+    ref = torch.logsumexp((a16.double().cpu() @ b16.double().cpu().t()) * inv_t, dim=1)
+    lse = ops.infonce_fp8_lse(a8, b8, inv_t)
+    assert_close(lse.cpu(), ref, 2e-4 * max(1.0, inv_t), what="fp8 lse")
+    # the bf16 statistics kernel on the dequantised copies sees the same operands
+    lse16, diag16 = ops.infonce_fused_lse(a16, b16, inv_t, 0)
+    assert_close(lse.cpu(), lse16.cpu(), 4e-4 * max(1.0, inv_t), what="fp8 lse vs bf16 kernel on the dequantised copy")
+    diag = ops.infonce_rowdot(a16, b16, inv_t, 0)
+    assert_close(diag.cpu()[:n], diag16.cpu()[:n], 1e-4 * max(1.0, inv_t), what="rowdot")
+
+
+def test_infonce_fp8_loss_and_grads(ops):
+    """Whole symmetric loss in fp8 mode (configs[4] global batch 2048): (1) against the closed form in fp64 on the
+    DEQUANTISED embeddings -- loss 2e-4, gradients 6e-3 of their maximum (bf16 weights in the second contraction);
+    (2) the honest distance from the fp32 loss on the unquantised embeddings: e4m3 keeps 4 significant bits, logits
+    (|S| up to ~90 at T = 1) move by ~0.5, the loss by a few percent -- printed and bounded at 5 %."""
+    from oracle import ref_cpu
+    B = 2048
+    g = torch.Generator().manual_seed(17)
+    es = torch.nn.functional.layer_norm(torch.randn(B, 256, generator=g), (256,))
+    ei = torch.nn.functional.layer_norm(torch.randn(B, 256, generator=g) + 0.15 * es, (256,))
+    loss, d_es, d_ei, _ = ops.infonce_fp8_fwd_bwd(es.to(DEV), ei.to(DEV), 1.0)
+    _, s16 = ops.quant_e4m3(es.to(DEV))
+    _, i16 = ops.quant_e4m3(ei.to(DEV))
+    a = s16.double().cpu().requires_grad_(True)
+    b = i16.double().cpu().requires_grad_(True)
+    ref = ref_cpu.symmetric_infonce(ref_cpu.logits(a, b, 1.0))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    assert_close(d_es.cpu(), a.grad, 6e-3 * float(a.grad.abs().max()) + 2e-3 / B, what="dE_spot (fp8 mode)")
+    assert_close(d_ei.cpu(), b.grad, 6e-3 * float(b.grad.abs().max()) + 2e-3 / B, what="dE_img (fp8 mode)")
+    full = ref_cpu.symmetric_infonce(ref_cpu.logits(es.double(), ei.double(), 1.0)).item()
+    print(f"fp8 InfoNCE B={B}: loss {loss.item():.4f} vs fp32-operand loss {full:.4f} "
+          f"(rel {abs(loss.item() - full) / max(1.0, abs(full)):.2e})")
+    assert abs(loss.item() - full) <= 5e-2 * max(1.0, abs(full))
+
+
+def test_model_fp8_infonce_mode():
+    """mclSTExp_Attention(infonce='fp8'): one training step runs through the fp8 path and lands near the exact mode."""
+    from mclstexp_amd import synth
+    from mclstexp_amd.model import mclSTExp_Attention
+    G, D, B = 171, 1024, 64
+    losses = {}
+    for mode in ("exact", "fp8"):
+        m = mclSTExp_Attention("identity", 1.0, D, G, 256, 8, 64, 2, infonce=mode)
+        m.load_state_dict(synth.make_params(G, D, seed=0))
+        m.to(DEV).train()
+        batch = {k: v.to(DEV) for k, v in synth.make_batch(B, G, image_dim=D, seed=0).items()}
+        loss = m(batch)
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+        losses[mode] = loss.item()
+    assert abs(losses["fp8"] - losses["exact"]) <= 5e-2 * max(1.0, abs(losses["exact"])), losses
+
+
 # ------------------------------------------------------------------ BLEEP soft-target CLIP loss (SURVEY 8 f4)
 @pytest.mark.parametrize("name", ["clip_b8", "clip_b33_t07", "vit_b16_t05"])
 def test_soft_clip_loss_against_reference_fixture(ops, name):

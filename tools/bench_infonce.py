@@ -60,6 +60,14 @@ def main():
                "frac_of_bf16_peak_exec": round(6 * fl / t_all / 2.5e15, 4),
                "lse_call_ms": round(t_lse * 1e3, 4), "lse_call_TFs": round(fl / t_lse / 1e12, 2),
                "grad_call_ms": round(t_grad * 1e3, 4), "grad_call_TFs": round(2 * fl / t_grad / 1e12, 2)}
+        # fp8 similarity contraction (BASELINE configs[4]): e4m3 LSE kernel (K = 64 MFMA, hardware block scales)
+        s8, s16 = ops.quant_e4m3(es)
+        i8, i16 = ops.quant_e4m3(ei)
+        t8_all = timed(lambda: ops.infonce_fp8_fwd_bwd(es, ei, 1.0), it)
+        t8_lse = timed(lambda: ops.infonce_fp8_lse(s8, i8, 1.0), it)
+        out.update({"fp8_ms": round(t8_all * 1e3, 4), "fp8_lse_call_ms": round(t8_lse * 1e3, 4),
+                    "fp8_lse_call_TFs": round(fl / t8_lse / 1e12, 2),
+                    "fp8_lse_frac_of_fp8_peak": round(fl / t8_lse / 5.0e15, 4)})
         if a.unfused and B <= 8192:
             ops.set_compute("f32")
             t_u = timed(lambda: ops.infonce_fwd_bwd(es, ei, 1.0, want_logits=False), max(3, it // 2))
