@@ -424,6 +424,15 @@ int mcl_patch_gather(const void* image_u8, int32_t Hs, int32_t Ws, const int32_t
 int mcl_log_library_size_normalize(const float* counts, int64_t ldx, float* out, int64_t ldy, int32_t rows,
                                    int32_t cols, float rescale, mcl_stream_t stream);
 
+/* HER2ST / cSCC training transform (/root/reference/dataset.py:63-68: ColorJitter(0.5,0.5,0.5), RandomHorizontalFlip,
+ * RandomRotation(180), ToTensor) for a batch of patches cropped from the resident slide, with the random draws supplied:
+ * params = N records of 16 32-bit words {order (2 bits per step: 0 brightness, 1 contrast, 2 saturation), hflip,
+ * rot_mode (0 quarter turns / 1 affine), rot_k, brightness, contrast, saturation (float), a[6] = libImaging's 16.16
+ * fixed-point affine coefficients, 3 pad}.  Bit-exact with PIL (ImageEnhance / Image.rotate NEAREST).  2r <= 232.   */
+int mcl_her2st_train_patches(const void* image_u8, int32_t Hs, int32_t Ws, const int32_t* centers_rc, int32_t N, int32_t r,
+                             const void* params, float divisor, float* out_nchw_f32, void* out_nhwc_bf16,
+                             mcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

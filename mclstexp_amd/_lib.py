@@ -111,6 +111,7 @@ PROTOTYPES = {
     "mcl_conv0_wrw": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p],
     "mcl_bn_act_maxpool_fwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_patch_gather": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_f, c_p, c_p, c_p],
+    "mcl_her2st_train_patches": [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_f, c_p, c_p, c_p],
     "mcl_log_library_size_normalize": [c_p, c_l, c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_l2_normalize_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mcl_topk_rows_max_k": [],

@@ -123,3 +123,15 @@ def synthetic_slide(hs=100, ws=120):
     """Procedural (hs, ws, 3) uint8 'whole-slide image'."""
     u = synth.uniform_tensor("slide", (hs, ws, 3), 0.0, 256.0, 0).numpy()
     return np.clip(np.floor(u), 0, 255).astype(np.uint8)
+
+
+# HER2ST / cSCC training transform (dataset.py:63-68): explicit draws for the golden case (8 patches of 2r = 32 around
+# centres of the synthetic slide, some crossing its border; quarter-turn and generic angles; factors below, at and above 1)
+AUG_CASE = dict(r=16,
+                centers_xy=[(40, 50), (16, 16), (3, 70), (115, 95), (60, 2), (119, 99), (50, 50), (70, 30)],
+                order=[(0, 1, 2), (2, 1, 0), (1, 0, 2), (0, 2, 1), (2, 0, 1), (1, 2, 0), (0, 1, 2), (1, 2, 0)],
+                brightness=[0.5, 1.5, 1.0, 0.73, 1.21, 0.99, 1.37, 0.61],
+                contrast=[1.5, 0.5, 1.0, 1.18, 0.66, 1.45, 0.83, 1.02],
+                saturation=[1.0, 1.49, 0.51, 0.9, 1.3, 0.7, 1.11, 0.58],
+                hflip=[0, 1, 0, 1, 1, 0, 1, 0],
+                angle=[0.0, 37.5, -90.0, 180.0, -133.7, 90.0, 12.25, -179.99])

@@ -176,3 +176,19 @@ def test_input_oracle_matches_pil_fixture():
     y = ref_input.log_library_size_normalize(c)
     assert_close(y[0], np.log10(c[0] * 1000.0 + 1.0), 1e-12, what="log10(x / libsize * 1e4 + 1)")
     assert (y[1] == 0).all()
+
+
+def test_train_augmentation_oracle_matches_pil_fixture():
+    """oracle/ref_input.her2st_train_transform (ColorJitter / flip / arbitrary-angle nearest rotation restated from PIL's
+    ImageEnhance, Blend.c and Geometry.c arithmetic) against PIL's own outputs for explicit draws: bit-exact."""
+    from oracle import ref_input
+    from helpers import AUG_CASE
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "input_augment.npz"))
+    img = synthetic_slide()
+    r = AUG_CASE["r"]
+    got = np.stack([ref_input.her2st_train_transform(ref_input.crop(img, y, x, r), AUG_CASE["order"][i],
+                                                     AUG_CASE["brightness"][i], AUG_CASE["contrast"][i],
+                                                     AUG_CASE["saturation"][i], bool(AUG_CASE["hflip"][i]),
+                                                     AUG_CASE["angle"][i])
+                    for i, (x, y) in enumerate(AUG_CASE["centers_xy"])])
+    assert np.array_equal(got, z["train"])
