@@ -163,6 +163,39 @@ int mcl_infonce_fused_grad(const void* a, int64_t lda, const void* b, int64_t ld
 int mcl_cast_f32_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int32_t cols,
                          mcl_stream_t stream);
 
+/* ---- ViT image encoder on bf16 (csrc/gemm_bf16.hip, csrc/vit_ops.hip; /root/reference/model.py:104-116).
+ * mcl_gemm_bf16: C[b] = epilogue(alpha * A[b] B[b]) with fp32 accumulation on the bf16 MFMA; per-operand storage flags
+ * (bit 0: A stored reduction-major [K][M]; bit 1: B stored reduction-major [K][N]; default: A [M][K], B [N][K]),
+ * bit 2: exact-erf GELU (pre_out != NULL also stores the pre-activation), bit 3: multiply by gelu'(aux), bit 4: fp32
+ * output.  bias [N] fp32, resid [M][N] bf16 (batch stride sRb, 0 = broadcast).  Leading dimensions multiples of 8 (bf16) /
+ * 4 (fp32 C); ragged M, N, K allowed; bf16 C needs ldc >= round_up(N, 8).  ksplit > 1 (fp32 output, batch 1, no
+ * epilogue): the K range is split over workgroups, fp32 slabs in `workspace` (mcl_gemm_bf16_workspace_floats) are
+ * merged in fixed order into C (accumulate != 0: +=) -- the weight-gradient form, deterministic.                      */
+int64_t mcl_gemm_bf16_workspace_floats(int32_t M, int64_t ldc, int32_t ksplit);
+int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void* B, int64_t ldb, int64_t sBb, void* C, int64_t ldc,
+                  int64_t sCb, int32_t M, int32_t N, int32_t K, int32_t batch, float alpha, int32_t flags,
+                  const float* bias, const void* resid, int64_t ldr, int64_t sRb, const void* aux, int64_t ldaux,
+                  void* pre_out, int64_t ldp, int32_t ksplit, float* workspace, int32_t accumulate, mcl_stream_t stream);
+/* LayerNorm over the last dimension D (multiple of 8, <= 1024) on bf16 rows, fp32 affine parameters and statistics. */
+int mcl_ln_bf16_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, float* mean,
+                    float* rstd, int64_t rows, int32_t D, float eps, mcl_stream_t stream);
+/* dx = LayerNorm backward (+ dx_add); dgamma / dbeta (accumulate != 0: +=) merged deterministically.               */
+int64_t mcl_colred_workspace_floats(int64_t rows, int32_t D);
+int mcl_ln_bf16_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* mean,
+                    const float* rstd, const void* dx_add, int64_t ldadd, void* dx, int64_t lddx, float* workspace,
+                    float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D, mcl_stream_t stream);
+/* out[c] (+)= sum over rows of a bf16 (rows, D) matrix (bias gradients), deterministic; D % 4 == 0, D <= 3072.      */
+int mcl_colsum_bf16(const void* x, int64_t ldx, int64_t rows, int32_t D, float* workspace, float* out, int32_t accumulate,
+                    mcl_stream_t stream);
+/* Row softmax in place on bf16 scores (row length n <= 256, row stride ld; padding columns are zeroed) and its
+ * backward in place on dP: dS = P * (dP - sum P dP) * scale.                                                        */
+int mcl_softmax_bf16_fwd(void* s, int64_t ld, int64_t rows, int32_t n, mcl_stream_t stream);
+int mcl_softmax_bf16_bwd(const void* P, void* dP, int64_t ld, int64_t rows, int32_t n, float scale, mcl_stream_t stream);
+/* Patch extraction for the patch-embedding GEMM: out[(b, py, px)][c*p*p + iy*p + ix] (bf16) from an fp32 image
+ * addressed by element strides (sb, sc, sy, sx): NCHW or channels-last.                                            */
+int mcl_vit_patchify(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H, int32_t W,
+                     int32_t p, void* out_bf16, mcl_stream_t stream);
+
 /* ---- fp8 (OCP e4m3) similarity contraction for the InfoNCE (csrc/infonce_fp8.hip; BASELINE configs[4]).
  * mcl_quant_e4m3_rows: per row one power-of-two scale 2^e (smallest with max|x| <= 448 * 2^e); q = e4m3_rne(x 2^-e),
  * scale byte = e + 127 (E8M0, what v_mfma_scale_f32_32x32x64_f8f6f4 consumes); optionally the dequantised copy in

@@ -67,6 +67,16 @@ PROTOTYPES = {
     "mcl_infonce_fused_lse": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p],
     "mcl_infonce_fused_grad": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
     "mcl_cast_f32_to_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
+    "mcl_gemm_bf16_workspace_floats": [c_i, c_l, c_i],
+    "mcl_gemm_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_l, c_l, c_p,
+                      c_l, c_p, c_l, c_i, c_p, c_i, c_p],
+    "mcl_ln_bf16_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_f, c_p],
+    "mcl_colred_workspace_floats": [c_l, c_i],
+    "mcl_ln_bf16_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_p],
+    "mcl_colsum_bf16": [c_p, c_l, c_l, c_i, c_p, c_p, c_i, c_p],
+    "mcl_softmax_bf16_fwd": [c_p, c_l, c_l, c_i, c_p],
+    "mcl_softmax_bf16_bwd": [c_p, c_p, c_l, c_l, c_i, c_f, c_p],
+    "mcl_vit_patchify": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_quant_e4m3_rows": [c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p],
     "mcl_dequant_e4m3_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_l, c_p],
     "mcl_infonce_fp8_workspace_bytes": [c_i, c_i],
@@ -123,7 +133,8 @@ _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int6
              "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64,
              "mcl_wrw_workspace_floats": C.c_int64, "mcl_dense_conv3x3_wrw_workspace_floats": C.c_int64,
-             "mcl_conv0_wrw_workspace_floats": C.c_int64, "mcl_infonce_fp8_workspace_bytes": C.c_int64}
+             "mcl_conv0_wrw_workspace_floats": C.c_int64, "mcl_infonce_fp8_workspace_bytes": C.c_int64,
+             "mcl_gemm_bf16_workspace_floats": C.c_int64, "mcl_colred_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

@@ -40,3 +40,6 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // csrc/wrw_fused.hip: dW[e] (+)= sum_{z < ks} wpart[z*MN + e] in fixed order (deterministic merge of per-workgroup
 // weight-gradient partials); MN a multiple of 4, all pointers 16-byte aligned.  Enqueue only.
 void mcl_launch_wrw_merge(const float* wpart, int ks, long long MN, float* dW, int accumulate_w, hipStream_t st);
+// same with an explicit slab stride (floats)
+void mcl_launch_wrw_merge_strided(const float* wpart, int ks, long long MN, long long stride, float* dW, int accumulate_w,
+                                  hipStream_t st);

@@ -1,0 +1,335 @@
+// bf16 GEMM for the ViT image encoder (/root/reference/model.py:104-116: timm vit_base_patch{32,16}_224) and its
+// backward: every dense contraction of a Transformer block -- QKV / projection / MLP linears (forward, data gradient,
+// weight gradient) and the attention products Q K^T, P V, P^T dO, dO V^T, dS K, dS^T Q -- is this one kernel.
+//
+//     C[b][M][N] = epilogue( alpha * sum_k A[b](m, k) * B[b](k, n) )          fp32 accumulate on v_mfma_f32_32x32x16_bf16
+//
+// Operand storage is described per operand, so no transposed copy is ever made:
+//     A_KMAJOR = 0:  A(m, k) = A[m*lda + k]   (k contiguous; activations [tokens][features])
+//     A_KMAJOR = 1:  A(m, k) = A[k*lda + m]   (reduction-major; dY for a weight gradient, P for dV = P^T dO)
+//     B_KMAJOR = 0:  B(k, n) = B[n*ldb + k]   (k contiguous; nn.Linear weights [out][in] in the forward, K in Q K^T)
+//     B_KMAJOR = 1:  B(k, n) = B[k*ldb + n]   (reduction-major; the weight in a data gradient, V in P V)
+//
+// MI355X mapping: 128 x 128 output tile per workgroup (4 waves, 2 x 2, each 64 x 64 = four 32 x 32 MFMA blocks), K in
+// steps of 64.  Operand tiles (16 KB each) arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) into a
+// double-buffered LDS stage exactly as they lie in HBM -- k-contiguous tiles as 128-byte rows read back with
+// ds_read_b128, reduction-major tiles as 256-byte rows read back with the transposing ds_read_b64_tr_b16 -- with the
+// bank-conflict-avoiding XOR swizzle applied on the DMA's SOURCE address.  Ragged M / N / K: out-of-range rows and
+// chunks are fetched from clamped (valid) addresses and the reduction tail is zeroed in the A fragment, so arbitrary
+// sizes (197 tokens) need no padding copies -- only 16-byte aligned rows (ld % 8 == 0).
+// Workgroup -> tile mapping is XCD-aware: the column tiles of one row panel run back to back on one XCD, so the A panel
+// is fetched once into that XCD's L2.  Split-K (weight gradients: K = 50 k tokens, few output tiles) writes fp32 slabs
+// that mcl_launch_wrw_merge adds in fixed order: deterministic, no atomics.
+// Epilogue (through LDS, so that HBM sees 16-byte row chunks): + bias[n], exact-erf GELU (optionally also storing the
+// pre-activation), * gelu'(aux), + residual; bf16 or fp32 output.
+#include "common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_B = 16384;                 // bytes per operand tile
+constexpr int STAGE_B = 2 * TILE_B;
+
+#define MCL_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ void glds16(const void* src, unsigned dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(dst)
+               : "memory");
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+// ---- k-contiguous tile: [128 rows][64 k] bf16 = 128-byte rows, 16-byte chunk c of row r at physical chunk
+// c ^ ((r >> 1) & 7): 16 consecutive rows of one logical chunk land on 16 distinct 16-byte slots of the 256-byte bank row.
+// Fragment of a 32-row block for the k-step kk (16 deep): lane l reads row (l & 31), k = kk + 8*(l >> 5) .. + 7.
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned char* tile, int row, int kk, int h) {
+  const int c = (kk >> 3) + h;
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+// ---- reduction-major tile: [64 k][128 cols] bf16 = 256-byte rows, chunk c of row r at c ^ ((r & 3) << 2); fragment =
+// 8 consecutive k of column cbase + (lane & 31) through the transposing read (see csrc/wrw_fused.hip frag_sw)
+__device__ __forceinline__ bf16x8 frag_km(const unsigned char* tile, int kbase, int cbase, int lane) {
+  const int i = lane & 15, q = i >> 2;
+  const int lchunk = (cbase + 16 * ((lane >> 4) & 1)) / 8 + ((i & 3) >> 1);
+  const unsigned char* p = tile + (kbase + q) * 256 + ((lchunk ^ (q << 2)) << 4) + (i & 1) * 8;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)p);
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 4 * 256));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+struct GemmB {
+  const bf16_t* A; long long lda, sAb;
+  const bf16_t* B; long long ldb, sBb;
+  void* C; long long ldc, sCb;                  // bf16 (or fp32 when out_f32)
+  int M, N, K, batch;
+  float alpha;
+  const float* bias;                            // [N] or null
+  const bf16_t* resid; long long ldr, sRb;      // + resid[m][n] (bf16) or null
+  const bf16_t* aux; long long ldaux;           // GELU_BWD: pre-activation [m][n]
+  bf16_t* pre_out; long long ldp;               // GELU: also store the pre-activation (bf16) or null
+  int gelu, gelu_bwd, out_f32;
+  int tm, tn, ksplit;                           // tiles in M, N; K slices (slab s at C + s * slab_stride floats)
+  long long k_per_split, slab_stride;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_g(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  // XCD-aware decode (block id % 8 = XCD): row panel = (q / tn) * 8 + xcd, column tile = q % tn
+  const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
+  const int bid = blockIdx.x % per_batch, b = blockIdx.x / per_batch;
+  const int xcd = bid & 7, q = bid >> 3;
+  const int ks = q % g.ksplit, q2 = q / g.ksplit;
+  const int tx = q2 % g.tn, ty = (q2 / g.tn) * 8 + xcd;
+  if (ty >= g.tm) return;
+  const int m0 = ty * BM, n0 = tx * BN;
+  const long long k_begin = (long long)ks * g.k_per_split;
+  const long long k_end = min((long long)g.K, k_begin + g.k_per_split);
+  const int nt = (int)((k_end - k_begin + BK - 1) / BK);
+  const bf16_t* A = g.A + (long long)b * g.sAb;
+  const bf16_t* B = g.B + (long long)b * g.sBb;
+  const unsigned lds_base = (unsigned)(size_t)MCL_LDSP(lds);
+
+  // ---- DMA geometry.  Out-of-range rows / chunks are clamped to valid addresses (finite garbage); the reduction
+  // tail is zeroed in the A fragment, M / N tails are never stored.
+  auto dma_tile = [&](int t, int stage) {
+    const long long k0 = k_begin + (long long)t * BK;
+    const unsigned dA = lds_base + stage * STAGE_B, dB = dA + TILE_B;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = wave + 4 * u;                                  // piece index 0..15 (1 KB each)
+      if (!A_KMAJOR) {                                             // 8 rows (m) x 128 B
+        const int row = 8 * p + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        long long m = m0 + row;  m = m < g.M ? m : g.M - 1;
+        long long k = k0 + lc * 8;  k = k < g.K ? k : 0;
+        glds16(A + m * g.lda + k, __builtin_amdgcn_readfirstlane(dA + p * 1024));
+      } else {                                                     // 4 rows (k) x 256 B
+        const int row = 4 * p + (lane >> 4);
+        const int lc = (lane & 15) ^ (((lane >> 4) & 3) << 2);
+        long long k = k0 + row;  k = k < g.K ? k : g.K - 1;
+        long long m = m0 + lc * 8;  m = m < g.M ? m : 0;
+        glds16(A + k * g.lda + m, __builtin_amdgcn_readfirstlane(dA + p * 1024));
+      }
+      if (!B_KMAJOR) {
+        const int row = 8 * p + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        long long n = n0 + row;  n = n < g.N ? n : g.N - 1;
+        long long k = k0 + lc * 8;  k = k < g.K ? k : 0;
+        glds16(B + n * g.ldb + k, __builtin_amdgcn_readfirstlane(dB + p * 1024));
+      } else {
+        const int row = 4 * p + (lane >> 4);
+        const int lc = (lane & 15) ^ (((lane >> 4) & 3) << 2);
+        long long k = k0 + row;  k = k < g.K ? k : g.K - 1;
+        long long n = n0 + lc * 8;  n = n < g.N ? n : 0;
+        glds16(B + k * g.ldb + n, __builtin_amdgcn_readfirstlane(dB + p * 1024));
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (nt > 0) dma_tile(0, 0);
+  if (nt > 1) dma_tile(1, 1);
+  for (int t = 0; t < nt; ++t) {
+    if (t == 0 && nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t >= 1 && t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);
+    const unsigned char* tA = lds + (t & 1) * STAGE_B;
+    const unsigned char* tB = tA + TILE_B;
+    const int kvalid = (int)min((long long)BK, k_end - (k_begin + (long long)t * BK));
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!A_KMAJOR) fa[i] = frag_kc(tA, wm * 64 + i * 32 + l31, kk, h);
+        else fa[i] = frag_km(tA, kk + 8 * h, wm * 64 + i * 32, lane);
+      }
+      if (kvalid < BK) {                             // reduction tail: zero A beyond K (B's clamped reads are finite)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kk + 8 * h + e >= kvalid) fa[i][e] = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!B_KMAJOR) fb[j] = frag_kc(tB, wn * 64 + j * 32 + l31, kk, h);
+        else fb[j] = frag_km(tB, kk + 8 * h, wn * 64 + j * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                   // every wave is done with the operand stages: reuse them
+
+  // ---- epilogue through LDS: wave tile 64 x 64 fp32 (4 x 16 KB = exactly the two operand stages)
+  constexpr int EP = 64;
+  float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        et[row * EP + j * 32 + l31] = acc[i][j][r] * g.alpha;
+      }
+  // (a wave reads back only what it wrote: no workgroup barrier needed; LDS ops of a wave complete in order)
+  const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+  const int cch = lane & 7;                          // 8 chunks of 8 columns per 64-column row
+#pragma unroll 2
+  for (int rr = lane >> 3; rr < 64; rr += 8) {
+    const int m = mw + rr, n = nw + cch * 8;
+    if (m >= g.M || n >= g.N) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (g.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (n + e < g.N) v[e] += g.bias[n + e];
+    }
+    if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
+      float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + (long long)b * g.sCb +
+                 (long long)m * g.ldc + n;
+      if (n + 8 <= g.N) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
+      }
+      continue;
+    }
+    if (g.pre_out) {
+      *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+          u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    }
+    if (g.gelu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (g.gelu_bwd) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] *= gelu_g(bf_lo(a[e]));
+        v[2 * e + 1] *= gelu_g(bf_hi(a[e]));
+      }
+    }
+    if (g.resid) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b * g.sRb + (long long)m * g.ldr + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] += bf_lo(a[e]);
+        v[2 * e + 1] += bf_hi(a[e]);
+      }
+    }
+    // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
+    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + (long long)b * g.sCb + (long long)m * g.ldc + n) =
+        u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+  }
+}
+
+}  // namespace
+
+// flags: bit 0 A reduction-major, bit 1 B reduction-major, bit 2 GELU, bit 3 multiply by gelu'(aux), bit 4 fp32 output
+extern "C" int64_t mcl_gemm_bf16_workspace_floats(int32_t M, int64_t ldc, int32_t ksplit) {
+  if (M <= 0 || ldc <= 0 || ksplit <= 1) return 0;
+  return (int64_t)ksplit * ((int64_t)M * ldc + 64);
+}
+
+extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void* B, int64_t ldb, int64_t sBb, void* C,
+                             int64_t ldc, int64_t sCb, int32_t M, int32_t N, int32_t K, int32_t batch, float alpha,
+                             int32_t flags, const float* bias, const void* resid, int64_t ldr, int64_t sRb, const void* aux,
+                             int64_t ldaux, void* pre_out, int64_t ldp, int32_t ksplit, float* workspace,
+                             int32_t accumulate, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return MCL_EINVAL;
+  const bool akm = flags & 1, bkm = flags & 2, gelu = flags & 4, gbwd = flags & 8, f32 = flags & 16;
+  if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(B) & 15u) ||
+      (reinterpret_cast<uintptr_t>(C) & 15u) || (sAb % 8) || (sBb % 8))
+    return MCL_EUNSUPPORTED;
+  if (!f32 && ((ldc % 8) || ldc < (N + 7) / 8 * 8)) return MCL_EUNSUPPORTED;
+  if (f32 && (ldc % 4)) return MCL_EUNSUPPORTED;
+  if (gbwd && (!aux || (ldaux % 8))) return MCL_EINVAL;
+  if (resid && (ldr % 8)) return MCL_EUNSUPPORTED;
+  if (pre_out && (ldp % 8)) return MCL_EUNSUPPORTED;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > 1 && (!f32 || !workspace || batch != 1 || bias || resid || gelu || gbwd || pre_out)) return MCL_EINVAL;
+  GemmB g;
+  g.A = (const bf16_t*)A; g.lda = lda; g.sAb = sAb;
+  g.B = (const bf16_t*)B; g.ldb = ldb; g.sBb = sBb;
+  g.C = C; g.ldc = ldc; g.sCb = sCb;
+  g.M = M; g.N = N; g.K = K; g.batch = batch;
+  g.alpha = alpha; g.bias = bias;
+  g.resid = (const bf16_t*)resid; g.ldr = ldr; g.sRb = sRb;
+  g.aux = (const bf16_t*)aux; g.ldaux = ldaux;
+  g.pre_out = (bf16_t*)pre_out; g.ldp = ldp;
+  g.gelu = gelu; g.gelu_bwd = gbwd; g.out_f32 = f32;
+  g.tm = (M + BM - 1) / BM; g.tn = (N + BN - 1) / BN; g.ksplit = ksplit;
+  long long kps = (K + ksplit - 1) / ksplit;
+  kps = (kps + BK - 1) / BK * BK;
+  g.k_per_split = kps;
+  g.ksplit = (int)((K + kps - 1) / kps);
+  g.slab_stride = 0;
+  hipStream_t st = mcl_stream(stream);
+  float* final_c = (float*)C;
+  if (g.ksplit > 1) {
+    g.slab_stride = (long long)M * ldc + 64;          // (+64: never a power-of-two stride, see csrc/wrw_fused.hip)
+    g.C = workspace;
+  }
+  const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
+  const dim3 grid((unsigned)(per_batch * batch));
+#define MCL_LAUNCH(AK, BKM) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM>), grid, dim3(256), 0, st, g)
+  if (!akm && !bkm) MCL_LAUNCH(false, false);
+  else if (!akm && bkm) MCL_LAUNCH(false, true);
+  else if (akm && !bkm) MCL_LAUNCH(true, false);
+  else MCL_LAUNCH(true, true);
+#undef MCL_LAUNCH
+  if (g.ksplit > 1) {
+    // slabs are [M][ldc] fp32 at stride slab_stride; merge adds them in fixed order (+= when accumulate)
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    mcl_launch_wrw_merge_strided(workspace, g.ksplit, (long long)M * ldc, g.slab_stride, final_c, accumulate, st);
+  }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}

@@ -72,7 +72,11 @@ __device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g
 // Image.blend(in1 = degenerate, in2 = image, alpha): (UINT8)(in1 + alpha*(in2 - in1)) in fp32 with the product and the
 // sum rounded separately (no FMA contraction: libImaging is plain C), truncated; clipped to [0, 255] when extrapolating.
 __device__ __forceinline__ int blend1(int in1, int in2, float alpha, bool interp) {
-  const float t = __fadd_rn((float)in1, __fmul_rn(alpha, (float)(in2 - in1)));
+  // hipcc contracts a*b + c into one FMA by default (and HIP's __fmul_rn / __fadd_rn are plain operators): two
+  // roundings are part of the result here (rare ties otherwise land one grey level off PIL's)
+#pragma clang fp contract(off)
+  const float prod = alpha * (float)(in2 - in1);
+  const float t = (float)in1 + prod;
   if (interp) return (int)t & 255;
   return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
 }

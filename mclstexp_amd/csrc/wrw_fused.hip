@@ -358,6 +358,13 @@ void mcl_launch_wrw_merge(const float* wpart, int ks, long long MN, float* dW, i
                      (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, MN);
 }
 
+void mcl_launch_wrw_merge_strided(const float* wpart, int ks, long long MN, long long stride, float* dW, int accumulate_w,
+                                  hipStream_t st) {
+  const int nb = (int)((MN / 4 + MQ - 1) / MQ);
+  hipLaunchKernelGGL(wrw_merge_kernel, dim3(nb), dim3(256), 0, st, wpart, ks, MN, 0, 1LL, dW, accumulate_w, 0,
+                     (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, stride);
+}
+
 extern "C" int64_t mcl_wrw_workspace_floats(int64_t S, int32_t M, int32_t N) {
   if (S <= 0 || M <= 0 || N <= 0) return -1;
   const Split p = plan(S, N);

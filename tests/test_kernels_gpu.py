@@ -386,15 +386,17 @@ def test_quant_e4m3_rows(ops, rows):
     assert torch.equal(packed[:, 256].cpu().to(torch.int64), e + 127), "E8M0 scale bytes"
     assert torch.equal(deq.float().cpu(), dq), "dequantised copy (exact in bf16)"
     assert torch.equal(ops.dequant_e4m3(packed).cpu(), deq.cpu())
-    # relative quantisation error of a row: <= 2^-4 of the row maximum scale
-    assert ((dq - x).abs() <= 2.0 ** -4 * x.abs().clamp_min(2.0 ** -9 * torch.pow(2.0, e).float()[:, None]) + 1e-30).all()
+    # round-to-nearest error: half a unit in the last of e4m3's 4 significant bits, or half a subnormal step (2^-10 2^e)
+    assert ((dq - x).abs() <= torch.maximum(2.0 ** -4 * x.abs(), 2.0 ** -10 * torch.pow(2.0, e).float()[:, None])).all()
 
 
 @pytest.mark.parametrize("R,C,T", [(128, 128, 1.0), (33, 33, 0.5), (256, 1024, 1.0), (200, 333, 2.0), (1, 1, 1.0),
                                    (129, 2049, 1.0), (2048, 2048, 1.0)])
 def test_infonce_fp8_lse(ops, R, C, T):
     """fp8 MFMA row LSE (hardware E8M0 block scales, logits never in HBM) vs fp64 logsumexp of the DEQUANTISED operands:
-    2e-4/T absolute -- the products are exact, only the fp32 accumulation order differs; ragged tiles, column splits."""
+    2e-3/T absolute.  The products are exact, but v_mfma_scale_f32_32x32x64_f8f6f4 sums its 64 products per instruction
+    with less internal precision than an fp32 FMA chain: measured 9e-4 at |S| ~ 100 (30 fp32 ulps), against 1e-4 for
+    the bf16 MFMA on the same operands.  Ragged tiles, column splits."""
     g = torch.Generator().manual_seed(R * 7 + C)
     a = torch.nn.functional.layer_norm(torch.randn(R, 256, generator=g), (256,))
     b = torch.nn.functional.layer_norm(torch.randn(C, 256, generator=g), (256,))
@@ -405,17 +407,18 @@ def test_infonce_fp8_lse(ops, R, C, T):
     b8, b16 = ops.quant_e4m3(b.to(DEV))
     ref = torch.logsumexp((a16.double().cpu() @ b16.double().cpu().t()) * inv_t, dim=1)
     lse = ops.infonce_fp8_lse(a8, b8, inv_t)
-    assert_close(lse.cpu(), ref, 2e-4 * max(1.0, inv_t), what="fp8 lse")
+    assert_close(lse.cpu(), ref, 2e-3 * max(1.0, inv_t), what="fp8 lse")
     # the bf16 statistics kernel on the dequantised copies sees the same operands
     lse16, diag16 = ops.infonce_fused_lse(a16, b16, inv_t, 0)
-    assert_close(lse.cpu(), lse16.cpu(), 4e-4 * max(1.0, inv_t), what="fp8 lse vs bf16 kernel on the dequantised copy")
+    assert_close(lse.cpu(), lse16.cpu(), 2e-3 * max(1.0, inv_t), what="fp8 lse vs bf16 kernel on the dequantised copy")
     diag = ops.infonce_rowdot(a16, b16, inv_t, 0)
     assert_close(diag.cpu()[:n], diag16.cpu()[:n], 1e-4 * max(1.0, inv_t), what="rowdot")
 
 
 def test_infonce_fp8_loss_and_grads(ops):
     """Whole symmetric loss in fp8 mode (configs[4] global batch 2048): (1) against the closed form in fp64 on the
-    DEQUANTISED embeddings -- loss 2e-4, gradients 6e-3 of their maximum (bf16 weights in the second contraction);
+    DEQUANTISED embeddings -- loss 1e-3 (the fp8 MFMA's internal accumulation, see test_infonce_fp8_lse), gradients
+    6e-3 of their maximum (bf16 weights in the second contraction);
     (2) the honest distance from the fp32 loss on the unquantised embeddings: e4m3 keeps 4 significant bits, logits
     (|S| up to ~90 at T = 1) move by ~0.5, the loss by a few percent -- printed and bounded at 5 %."""
     from oracle import ref_cpu
@@ -430,7 +433,7 @@ def test_infonce_fp8_loss_and_grads(ops):
     b = i16.double().cpu().requires_grad_(True)
     ref = ref_cpu.symmetric_infonce(ref_cpu.logits(a, b, 1.0))
     ref.backward()
-    assert abs(loss.item() - ref.item()) < 2e-4 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
+    assert abs(loss.item() - ref.item()) < 1e-3 * max(1.0, abs(ref.item())), (loss.item(), ref.item())
     assert_close(d_es.cpu(), a.grad, 6e-3 * float(a.grad.abs().max()) + 2e-3 / B, what="dE_spot (fp8 mode)")
     assert_close(d_ei.cpu(), b.grad, 6e-3 * float(b.grad.abs().max()) + 2e-3 / B, what="dE_img (fp8 mode)")
     full = ref_cpu.symmetric_infonce(ref_cpu.logits(es.double(), ei.double(), 1.0)).item()
