@@ -167,13 +167,15 @@ int mcl_cast_f32_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int6
  * mcl_gemm_bf16: C[b] = epilogue(alpha * A[b] B[b]) with fp32 accumulation on the bf16 MFMA; per-operand storage flags
  * (bit 0: A stored reduction-major [K][M]; bit 1: B stored reduction-major [K][N]; default: A [M][K], B [N][K]),
  * bit 2: exact-erf GELU (pre_out != NULL also stores the pre-activation), bit 3: multiply by gelu'(aux), bit 4: fp32
- * output.  bias [N] fp32, resid [M][N] bf16 (batch stride sRb, 0 = broadcast).  Leading dimensions multiples of 8 (bf16) /
+ * output.  Two-level batch: problem bi = (bi / batch2, bi % batch2) with strides (s?b, s?b2) -- (image, head) for the
+ * attention products.  bias [N] fp32, resid [M][N] bf16 (outer-batch stride sRb, 0 = broadcast).  Leading dimensions multiples of 8 (bf16) /
  * 4 (fp32 C); ragged M, N, K allowed; bf16 C needs ldc >= round_up(N, 8).  ksplit > 1 (fp32 output, batch 1, no
  * epilogue): the K range is split over workgroups, fp32 slabs in `workspace` (mcl_gemm_bf16_workspace_floats) are
  * merged in fixed order into C (accumulate != 0: +=) -- the weight-gradient form, deterministic.                      */
 int64_t mcl_gemm_bf16_workspace_floats(int32_t M, int64_t ldc, int32_t ksplit);
 int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void* B, int64_t ldb, int64_t sBb, void* C, int64_t ldc,
-                  int64_t sCb, int32_t M, int32_t N, int32_t K, int32_t batch, float alpha, int32_t flags,
+                  int64_t sCb, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t batch2, int64_t sAb2, int64_t sBb2,
+                  int64_t sCb2, float alpha, int32_t flags,
                   const float* bias, const void* resid, int64_t ldr, int64_t sRb, const void* aux, int64_t ldaux,
                   void* pre_out, int64_t ldp, int32_t ksplit, float* workspace, int32_t accumulate, mcl_stream_t stream);
 /* LayerNorm over the last dimension D (multiple of 8, <= 1024) on bf16 rows, fp32 affine parameters and statistics. */

@@ -68,8 +68,8 @@ PROTOTYPES = {
     "mcl_infonce_fused_grad": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
     "mcl_cast_f32_to_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
     "mcl_gemm_bf16_workspace_floats": [c_i, c_l, c_i],
-    "mcl_gemm_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_l, c_l, c_p,
-                      c_l, c_p, c_l, c_i, c_p, c_i, c_p],
+    "mcl_gemm_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_f, c_i, c_p,
+                      c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_i, c_p],
     "mcl_ln_bf16_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_l, c_i, c_f, c_p],
     "mcl_colred_workspace_floats": [c_l, c_i],
     "mcl_ln_bf16_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_p],

@@ -77,10 +77,10 @@ __device__ __forceinline__ bf16x8 frag_km(const unsigned char* tile, int kbase, 
 }
 
 struct GemmB {
-  const bf16_t* A; long long lda, sAb;
-  const bf16_t* B; long long ldb, sBb;
-  void* C; long long ldc, sCb;                  // bf16 (or fp32 when out_f32)
-  int M, N, K, batch;
+  const bf16_t* A; long long lda, sAb, sAb2;
+  const bf16_t* B; long long ldb, sBb, sBb2;
+  void* C; long long ldc, sCb, sCb2;            // bf16 (or fp32 when out_f32)
+  int M, N, K, batch, batch2;                   // batch index bi -> (bi / batch2, bi % batch2): strides s?b, s?b2
   float alpha;
   const float* bias;                            // [N] or null
   const bf16_t* resid; long long ldr, sRb;      // + resid[m][n] (bf16) or null
@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
   const long long k_begin = (long long)ks * g.k_per_split;
   const long long k_end = min((long long)g.K, k_begin + g.k_per_split);
   const int nt = (int)((k_end - k_begin + BK - 1) / BK);
-  const bf16_t* A = g.A + (long long)b * g.sAb;
-  const bf16_t* B = g.B + (long long)b * g.sBb;
+  const int b1 = b / g.batch2, b2 = b % g.batch2;
+  const bf16_t* A = g.A + (long long)b1 * g.sAb + (long long)b2 * g.sAb2;
+  const bf16_t* B = g.B + (long long)b1 * g.sBb + (long long)b2 * g.sBb2;
+  const long long c_off = (long long)b1 * g.sCb + (long long)b2 * g.sCb2;
   const unsigned lds_base = (unsigned)(size_t)MCL_LDSP(lds);
 
   // ---- DMA geometry.  Out-of-range rows / chunks are clamped to valid addresses (finite garbage); the reduction
@@ -228,8 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
         if (n + e < g.N) v[e] += g.bias[n + e];
     }
     if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
-      float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + (long long)b * g.sCb +
-                 (long long)m * g.ldc + n;
+      float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
       if (n + 8 <= g.N) {
         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
       }
     }
     if (g.resid) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b * g.sRb + (long long)m * g.ldr + n);
+      const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[2 * e] += bf_lo(a[e]);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
       }
     }
     // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
-    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + (long long)b * g.sCb + (long long)m * g.ldc + n) =
+    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
         u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
   }
 }
@@ -277,15 +278,16 @@ extern "C" int64_t mcl_gemm_bf16_workspace_floats(int32_t M, int64_t ldc, int32_
 }
 
 extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void* B, int64_t ldb, int64_t sBb, void* C,
-                             int64_t ldc, int64_t sCb, int32_t M, int32_t N, int32_t K, int32_t batch, float alpha,
+                             int64_t ldc, int64_t sCb, int32_t M, int32_t N, int32_t K, int32_t batch, int32_t batch2,
+                             int64_t sAb2, int64_t sBb2, int64_t sCb2, float alpha,
                              int32_t flags, const float* bias, const void* resid, int64_t ldr, int64_t sRb, const void* aux,
                              int64_t ldaux, void* pre_out, int64_t ldp, int32_t ksplit, float* workspace,
                              int32_t accumulate, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return MCL_EINVAL;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch2 <= 0 || (batch % batch2)) return MCL_EINVAL;
   const bool akm = flags & 1, bkm = flags & 2, gelu = flags & 4, gbwd = flags & 8, f32 = flags & 16;
   if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(B) & 15u) ||
-      (reinterpret_cast<uintptr_t>(C) & 15u) || (sAb % 8) || (sBb % 8))
+      (reinterpret_cast<uintptr_t>(C) & 15u) || (sAb % 8) || (sBb % 8) || (sAb2 % 8) || (sBb2 % 8) || (sCb % 4) || (sCb2 % 4))
     return MCL_EUNSUPPORTED;
   if (!f32 && ((ldc % 8) || ldc < (N + 7) / 8 * 8)) return MCL_EUNSUPPORTED;
   if (f32 && (ldc % 4)) return MCL_EUNSUPPORTED;
@@ -295,10 +297,10 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 1 && (!f32 || !workspace || batch != 1 || bias || resid || gelu || gbwd || pre_out)) return MCL_EINVAL;
   GemmB g;
-  g.A = (const bf16_t*)A; g.lda = lda; g.sAb = sAb;
-  g.B = (const bf16_t*)B; g.ldb = ldb; g.sBb = sBb;
-  g.C = C; g.ldc = ldc; g.sCb = sCb;
-  g.M = M; g.N = N; g.K = K; g.batch = batch;
+  g.A = (const bf16_t*)A; g.lda = lda; g.sAb = sAb; g.sAb2 = sAb2;
+  g.B = (const bf16_t*)B; g.ldb = ldb; g.sBb = sBb; g.sBb2 = sBb2;
+  g.C = C; g.ldc = ldc; g.sCb = sCb; g.sCb2 = sCb2;
+  g.M = M; g.N = N; g.K = K; g.batch = batch; g.batch2 = batch2;
   g.alpha = alpha; g.bias = bias;
   g.resid = (const bf16_t*)resid; g.ldr = ldr; g.sRb = sRb;
   g.aux = (const bf16_t*)aux; g.ldaux = ldaux;

@@ -236,6 +236,10 @@ class _ContrastiveBase(nn.Module):
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and not encoder.training
                 and image.is_cuda and self.backbone_dtype == torch.bfloat16 and not torch.is_grad_enabled()):
             return encoder.forward_eval_fused(image, torch.bfloat16)      # inference: running statistics
+        if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder_VIT) and image.is_cuda
+                and self.backbone_dtype == torch.bfloat16):
+            from .vit_fused import vit_features_fused           # ViT on the hand-written bf16 kernels (csrc/gemm_bf16.hip)
+            return vit_features_fused(encoder.model, image)
         if self.backbone_dtype is not None and self.backbone_dtype != torch.float32:
             if image.dim() == 4:
                 image = image.contiguous(memory_format=torch.channels_last)

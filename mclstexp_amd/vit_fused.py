@@ -1,0 +1,268 @@
+"""ViT image encoder (/root/reference/model.py:104-116: timm ``vit_base_patch{32,16}_224``,
+``num_classes=0, global_pool='avg'``) executed on the hand-written bf16 kernels: every dense contraction -- patch
+embedding, QKV / projection / MLP linears, the attention products, all data and weight gradients -- is
+``mcl_gemm_bf16`` (csrc/gemm_bf16.hip); LayerNorm, softmax, bias-gradient column sums and patch extraction are the row
+kernels of csrc/vit_ops.hip.  Same module tree and parameters as ``backbones.VisionTransformer`` (timm layout: reference
+checkpoints load); only the execution differs.  Forward AND hand-scheduled backward of the whole encoder are one
+``torch.autograd.Function`` -- the reference obtains the backward from autograd (train.py:38).
+
+Activations are bf16 (B, T, D) with T = patches + 1 (class token first); parameters stay fp32 masters, the kernels read
+bf16 copies (FusedAdam's flat shadow when one is attached, densenet_fused._weight).  Attention scores are materialised in
+bf16 (heads x T x T per image, rows padded to a multiple of 16): < 1 % of the encoder's FLOPs at T = 197, so one GEMM
+kernel serves everything.  Weight / bias / LayerNorm parameter gradients are deterministic (split-K slabs and column
+partials merged in fixed order) and go straight into ``.grad`` when the parameter owns a dense fp32 one.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from . import densenet_fused as _dn
+from .densenet_fused import _direct_grad_ok, _ws
+
+Tensor = torch.Tensor
+BF = torch.bfloat16
+A_KM, B_KM, GELU, GELU_BWD, OUT_F32 = 1, 2, 4, 8, 16
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor], off: int = 0) -> Optional[int]:
+    return None if t is None else t.data_ptr() + off * t.element_size()
+
+
+def gemm(A: Tensor, B: Tensor, C: Tensor, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, flags: int = 0,
+         a_off: int = 0, b_off: int = 0, c_off: int = 0, batch: int = 1, batch2: int = 1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+         alpha: float = 1.0, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0, sRb: int = 0,
+         r_off: int = 0, aux: Optional[Tensor] = None, ldaux: int = 0, pre_out: Optional[Tensor] = None, ldp: int = 0,
+         ksplit: int = 1, accumulate: bool = False) -> None:
+    """mcl_gemm_bf16 with element offsets / strides (see include/mclstexp_hip.h)."""
+    L = _lib.lib()
+    ws = None
+    if ksplit > 1:
+        ws = _ws(L.mcl_gemm_bf16_workspace_floats(M, ldc, ksplit), C.device)
+    check(L.mcl_gemm_bf16(_ptr(A, a_off), lda, sA[0], _ptr(B, b_off), ldb, sB[0], _ptr(C, c_off), ldc, sC[0], M, N, K,
+                          batch, batch2, sA[1], sB[1], sC[1], alpha, flags, _ptr(bias), _ptr(resid, r_off), ldr, sRb,
+                          _ptr(aux), ldaux, _ptr(pre_out), ldp, ksplit, _ptr(ws), int(accumulate), _st()),
+          "mcl_gemm_bf16")
+
+
+def _w16(w: Tensor) -> Tensor:
+    """bf16 copy of a 2-D weight: FusedAdam's flat shadow view when one is attached (one cast per step for all weights),
+    else a cast."""
+    prov = _dn._weight_provider
+    if prov is not None:
+        v = prov(w, BF)
+        if v is not None and v.is_contiguous():
+            return v
+    return w.detach().to(BF).contiguous()
+
+
+def _ksplit(m_out: int, n_out: int) -> int:
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    return max(2, min(16, (512 + tiles - 1) // tiles))
+
+
+def _grad_target(p: Tensor):
+    """(tensor to write, accumulate?, value to return to autograd)."""
+    if _direct_grad_ok(p) and p.grad.is_contiguous():
+        return p.grad, True, None
+    g = torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+    return g, False, g
+
+
+def linear_wgrad(dy: Tensor, x: Tensor, w: Tensor, rows: int):
+    """dW[out][in] (+)= dy^T x over ``rows`` tokens (both operands reduction-major, split-K, fixed-order merge)."""
+    n_out, n_in = w.shape[0], w[0].numel()
+    tgt, acc, ret = _grad_target(w)
+    gemm(dy, x, tgt, n_out, n_in, rows, dy.shape[-1], x.shape[-1], n_in, flags=A_KM | B_KM | OUT_F32,
+         ksplit=_ksplit(n_out, n_in), accumulate=acc)
+    return ret
+
+
+def bias_grad(dy: Tensor, b: Tensor, rows: int):
+    D = b.numel()
+    tgt, acc, ret = _grad_target(b)
+    L = _lib.lib()
+    ws = _ws(L.mcl_colred_workspace_floats(rows, D), dy.device)
+    check(L.mcl_colsum_bf16(dy.data_ptr(), dy.shape[-1], rows, D, ws.data_ptr(), tgt.data_ptr(), int(acc), _st()),
+          "mcl_colsum_bf16")
+    return ret
+
+
+def ln_fwd(x: Tensor, ln: torch.nn.LayerNorm, rows: int):
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(_lib.lib().mcl_ln_bf16_fwd(x.data_ptr(), D, ln.weight.data_ptr(), ln.bias.data_ptr(), y.data_ptr(), D,
+                                     mean.data_ptr(), rstd.data_ptr(), rows, D, float(ln.eps), _st()), "mcl_ln_bf16_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy: Tensor, x: Tensor, ln: torch.nn.LayerNorm, mean: Tensor, rstd: Tensor, dx_add: Optional[Tensor], rows: int):
+    """(dx [+ dx_add], dgamma-return, dbeta-return)."""
+    D = x.shape[-1]
+    dx = torch.empty_like(x)
+    tg, acc_g, ret_g = _grad_target(ln.weight)
+    tb, acc_b, ret_b = _grad_target(ln.bias)
+    assert acc_g == acc_b
+    L = _lib.lib()
+    ws = _ws(L.mcl_colred_workspace_floats(rows, D), x.device)
+    check(L.mcl_ln_bf16_bwd(dy.data_ptr(), D, x.data_ptr(), D, ln.weight.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                            _ptr(dx_add), D if dx_add is not None else 0, dx.data_ptr(), D, ws.data_ptr(), tg.data_ptr(),
+                            tb.data_ptr(), int(acc_g), rows, D, _st()), "mcl_ln_bf16_bwd")
+    return dx, ret_g, ret_b
+
+
+class ViTFn(torch.autograd.Function):
+    """features (B, D) fp32 = VisionTransformer(image) up to and including the mean pool over the patch tokens (the
+    final ``fc_norm`` runs on ops.LayerNormFn, fp32).  ``vit`` (the module) rides along for shapes and parameter
+    objects; its parameters are passed explicitly so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, image, vit, *params):
+        dev = image.device
+        pe = vit.patch_embed.proj
+        p = pe.kernel_size[0]
+        B, _, H, W = image.shape
+        nph, npw = H // p, W // p
+        npatch, T = nph * npw, nph * npw + 1
+        D = pe.out_channels
+        K0 = 3 * p * p
+        heads = vit.blocks[0].attn.num_heads
+        dh = D // heads
+        M = B * T
+        Tp = (T + 15) // 16 * 16
+        L = _lib.lib()
+        img = image if image.dtype == torch.float32 else image.float()
+        # patches with a zero row at the class-token position: (B, T, K0); the weight gradient of the patch embedding
+        # is then ONE reduction over all B*T rows
+        patches = torch.zeros((B, T, K0), device=dev, dtype=BF)
+        tmp = torch.empty((B * npatch, K0), device=dev, dtype=BF)
+        check(L.mcl_vit_patchify(img.data_ptr(), img.stride(0), img.stride(1), img.stride(2), img.stride(3), B, H, W, p,
+                                 tmp.data_ptr(), _st()), "mcl_vit_patchify")
+        patches[:, 1:].copy_(tmp.view(B, npatch, K0))
+        pos16 = vit.pos_embed.detach().to(BF).reshape(T, D).contiguous()
+        x = torch.empty((B, T, D), device=dev, dtype=BF)
+        wpe = pe.weight.detach().contiguous().reshape(D, K0).to(BF)       # (c, iy, ix) order whatever the memory format
+        gemm(patches, wpe, x, npatch, D, K0, K0, K0, D, a_off=K0, c_off=D, batch=B, sA=(T * K0, 0), sC=(T * D, 0),
+             bias=pe.bias, resid=pos16, ldr=D, sRb=0, r_off=D)
+        x[:, 0] = (vit.cls_token.detach().reshape(D) + vit.pos_embed.detach().reshape(T, D)[0]).to(BF)
+        saved = []
+        scale = dh ** -0.5
+        for blk in vit.blocks:
+            a, m = blk.attn, blk.mlp
+            u1, mean1, rstd1 = ln_fwd(x, blk.norm1, M)
+            qkv = torch.empty((B, T, 3 * D), device=dev, dtype=BF)
+            gemm(u1, _w16(a.qkv.weight), qkv, M, 3 * D, D, D, D, 3 * D, bias=a.qkv.bias)
+            P = torch.empty((B * heads, T, Tp), device=dev, dtype=BF)
+            gemm(qkv, qkv, P, T, T, dh, 3 * D, 3 * D, Tp, b_off=D, batch=B * heads, batch2=heads,
+                 sA=(T * 3 * D, dh), sB=(T * 3 * D, dh), sC=(heads * T * Tp, T * Tp), alpha=scale)
+            check(L.mcl_softmax_bf16_fwd(P.data_ptr(), Tp, B * heads * T, T, _st()), "mcl_softmax_bf16_fwd")
+            o = torch.empty((B, T, D), device=dev, dtype=BF)
+            gemm(P, qkv, o, T, dh, T, Tp, 3 * D, D, flags=B_KM, b_off=2 * D, batch=B * heads, batch2=heads,
+                 sA=(heads * T * Tp, T * Tp), sB=(T * 3 * D, dh), sC=(T * D, dh))
+            x1 = torch.empty_like(x)
+            gemm(o, _w16(a.proj.weight), x1, M, D, D, D, D, D, bias=a.proj.bias, resid=x, ldr=D, sRb=0)
+            u2, mean2, rstd2 = ln_fwd(x1, blk.norm2, M)
+            Dh = m.fc1.out_features
+            h1 = torch.empty((B, T, Dh), device=dev, dtype=BF)
+            pre = torch.empty((B, T, Dh), device=dev, dtype=BF)
+            gemm(u2, _w16(m.fc1.weight), h1, M, Dh, D, D, D, Dh, flags=GELU, bias=m.fc1.bias, pre_out=pre, ldp=Dh)
+            x2 = torch.empty_like(x)
+            gemm(h1, _w16(m.fc2.weight), x2, M, D, Dh, Dh, Dh, D, bias=m.fc2.bias, resid=x1, ldr=D, sRb=0)
+            saved += [x, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h1]
+            x = x2
+        feat = x[:, 1:].float().mean(dim=1)                        # global_pool='avg' over the patch tokens
+        ctx.save_for_backward(patches, *saved)
+        ctx.vit = vit
+        ctx.dims = (B, T, D, K0, heads, dh, Tp, npatch)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        vit = ctx.vit
+        B, T, D, K0, heads, dh, Tp, npatch = ctx.dims
+        M = B * T
+        t = ctx.saved_tensors
+        patches, saved = t[0], t[1:]
+        dev = dfeat.device
+        L = _lib.lib()
+        scale = dh ** -0.5
+        dx = torch.zeros((B, T, D), device=dev, dtype=BF)
+        dx[:, 1:] = (dfeat / float(npatch)).to(BF).unsqueeze(1)
+        grads = {}
+        nblk = len(vit.blocks)
+        for li in range(nblk - 1, -1, -1):
+            blk = vit.blocks[li]
+            a, m = blk.attn, blk.mlp
+            x, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h1 = saved[13 * li: 13 * li + 13]
+            Dh = m.fc1.out_features
+            # MLP
+            grads[m.fc2.weight] = linear_wgrad(dx, h1, m.fc2.weight, M)
+            grads[m.fc2.bias] = bias_grad(dx, m.fc2.bias, M)
+            dpre = torch.empty((B, T, Dh), device=dev, dtype=BF)
+            gemm(dx, _w16(m.fc2.weight), dpre, M, Dh, D, D, Dh, Dh, flags=B_KM | GELU_BWD, aux=pre, ldaux=Dh)
+            grads[m.fc1.weight] = linear_wgrad(dpre, u2, m.fc1.weight, M)
+            grads[m.fc1.bias] = bias_grad(dpre, m.fc1.bias, M)
+            du2 = torch.empty((B, T, D), device=dev, dtype=BF)
+            gemm(dpre, _w16(m.fc1.weight), du2, M, D, Dh, Dh, D, D, flags=B_KM)
+            dx1, grads[blk.norm2.weight], grads[blk.norm2.bias] = ln_bwd(du2, x1, blk.norm2, mean2, rstd2, dx, M)
+            # attention output projection
+            grads[a.proj.weight] = linear_wgrad(dx1, o, a.proj.weight, M)
+            grads[a.proj.bias] = bias_grad(dx1, a.proj.bias, M)
+            do = torch.empty((B, T, D), device=dev, dtype=BF)
+            gemm(dx1, _w16(a.proj.weight), do, M, D, D, D, D, D, flags=B_KM)
+            # attention core, per (image, head)
+            dqkv = torch.empty((B, T, 3 * D), device=dev, dtype=BF)
+            nb = B * heads
+            sP = (heads * T * Tp, T * Tp)
+            sQ = (T * 3 * D, dh)
+            sO = (T * D, dh)
+            gemm(P, do, dqkv, T, dh, T, Tp, D, 3 * D, flags=A_KM | B_KM, c_off=2 * D, batch=nb, batch2=heads,
+                 sA=sP, sB=sO, sC=sQ)                                                   # dV = P^T dO
+            dP = torch.empty((B * heads, T, Tp), device=dev, dtype=BF)
+            gemm(do, qkv, dP, T, T, dh, D, 3 * D, Tp, b_off=2 * D, batch=nb, batch2=heads, sA=sO, sB=sQ, sC=sP)   # dO V^T
+            check(L.mcl_softmax_bf16_bwd(P.data_ptr(), dP.data_ptr(), Tp, B * heads * T, T, scale, _st()),
+                  "mcl_softmax_bf16_bwd")
+            gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=B_KM, b_off=D, batch=nb, batch2=heads,
+                 sA=sP, sB=sQ, sC=sQ)                                                   # dQ = dS K
+            gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=A_KM | B_KM, c_off=D, batch=nb, batch2=heads,
+                 sA=sP, sB=sQ, sC=sQ)                                                   # dK = dS^T Q
+            grads[a.qkv.weight] = linear_wgrad(dqkv, u1, a.qkv.weight, M)
+            grads[a.qkv.bias] = bias_grad(dqkv, a.qkv.bias, M)
+            du1 = torch.empty((B, T, D), device=dev, dtype=BF)
+            gemm(dqkv, _w16(a.qkv.weight), du1, M, D, 3 * D, 3 * D, D, D, flags=B_KM)
+            dx, grads[blk.norm1.weight], grads[blk.norm1.bias] = ln_bwd(du1, x, blk.norm1, mean1, rstd1, dx1, M)
+        # embeddings: position table and class token (fp32 sums over the batch), patch projection
+        dxf = dx.float()
+        dpos = dxf.sum(dim=0, keepdim=True)
+        grads[vit.pos_embed] = dpos
+        grads[vit.cls_token] = dpos[:, :1].clone()
+        pe = vit.patch_embed.proj
+        dxp = dx.clone()
+        dxp[:, 0] = 0                                            # class-token rows carry no patch
+        gw = linear_wgrad(dxp, patches, pe.weight, M)
+        grads[pe.weight] = None if gw is None else gw.view_as(pe.weight)
+        grads[pe.bias] = bias_grad(dxp, pe.bias, M)
+        return (None, None, *[grads.get(prm) for prm in _param_list(vit)])
+
+
+def _param_list(vit) -> List[Tensor]:
+    """The encoder's trainable parameters in module order, without fc_norm (which runs outside ViTFn)."""
+    skip = {id(vit.fc_norm.weight), id(vit.fc_norm.bias)}
+    return [p for p in vit.parameters() if p.requires_grad and id(p) not in skip]
+
+
+def vit_features_fused(vit, image: Tensor) -> Tensor:
+    """``VisionTransformer.forward`` (timm: global_pool='avg', fc_norm) on the bf16 kernels; (B, D) fp32."""
+    if not image.is_cuda:
+        raise RuntimeError("vit_features_fused: input is on the CPU; the fused ViT path is GPU-only")
+    feat = ViTFn.apply(image, vit, *_param_list(vit))
+    return ops.LayerNormFn.apply(feat, vit.fc_norm.weight, vit.fc_norm.bias, vit.fc_norm.eps)

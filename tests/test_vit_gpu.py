@@ -1,0 +1,162 @@
+"""ViT image encoder on the hand-written bf16 kernels (csrc/gemm_bf16.hip, csrc/vit_ops.hip, mclstexp_amd/vit_fused.py)
+against fp64 torch on the same bf16 data.  pytest -m gpu."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(*shape, generator=g) - 0.5) * 2 * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (197, 197, 64), (300, 200, 136), (1000, 768, 768), (64, 72, 200)])
+@pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_layouts(M, N, K, akm, bkm):
+    """All four operand storage combinations, ragged M / N / K, leading dimensions wider than the matrix."""
+    from mclstexp_amd import vit_fused as vf
+    lda = ((M if akm else K) + 7) // 8 * 8 + 8
+    ldb = ((N if bkm else K) + 7) // 8 * 8 + 16
+    ldc = (N + 7) // 8 * 8 + 8
+    A = _r(K if akm else M, lda, seed=1).to(BF).to(DEV)
+    B = _r(K if bkm else N, ldb, seed=2).to(BF).to(DEV)
+    C = torch.full((M, ldc), 7.0, device=DEV, dtype=BF)
+    vf.gemm(A, B, C, M, N, K, lda, ldb, ldc, flags=akm * vf.A_KM | bkm * vf.B_KM, alpha=0.5)
+    a = (A[:K, :M].t() if akm else A[:M, :K]).double()
+    b = (B[:K, :N] if bkm else B[:N, :K].t()).double()
+    ref = 0.5 * (a @ b)
+    assert_close(C[:, :N].float().cpu(), ref.cpu(), 2e-3, 2 ** -8, what=f"gemm akm={akm} bkm={bkm}")
+    if ldc - (N + 7) // 8 * 8 > 0:
+        assert (C[:, (N + 7) // 8 * 8:] == 7.0).all()               # columns beyond the padded row are untouched
+
+
+def test_gemm_bf16_epilogues_and_batch():
+    """bias + GELU (+ stored pre-activation), gelu' multiply, residual add, two-level batch with strides, fp32 output,
+    split-K with accumulation (deterministic)."""
+    from mclstexp_amd import vit_fused as vf
+    M, N, K = 300, 264, 200
+    A = _r(M, K, seed=3).to(BF).to(DEV)
+    W = _r(N, K, seed=4, scale=0.2).to(BF).to(DEV)
+    bias = _r(N, seed=5).to(DEV)
+    res = _r(M, N, seed=6).to(BF).to(DEV)
+    pre = torch.empty((M, N), device=DEV, dtype=BF)
+    h = torch.empty((M, N), device=DEV, dtype=BF)
+    vf.gemm(A, W, h, M, N, K, K, K, N, flags=vf.GELU, bias=bias, pre_out=pre, ldp=N)
+    ref_pre = A.double() @ W.double().t() + bias.double()
+    assert_close(pre.float().cpu(), ref_pre.cpu(), 2e-3, 2 ** -8, what="pre-activation")
+    assert_close(h.float().cpu(), torch.nn.functional.gelu(ref_pre).cpu(), 3e-3, 2 ** -7, what="gelu")
+    y = torch.empty((M, N), device=DEV, dtype=BF)
+    vf.gemm(A, W, y, M, N, K, K, K, N, bias=bias, resid=res, ldr=N)
+    assert_close(y.float().cpu(), (ref_pre + res.double()).cpu(), 3e-3, 2 ** -8, what="bias + residual")
+    dy = _r(M, N, seed=7).to(BF).to(DEV)
+    dx = torch.empty((M, K), device=DEV, dtype=BF)
+    aux = _r(M, K, seed=8, scale=2.0).to(BF).to(DEV)
+    vf.gemm(dy, W, dx, M, K, N, N, K, K, flags=vf.B_KM | vf.GELU_BWD, aux=aux, ldaux=K)
+    xa = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(xa).sum().backward()
+    assert_close(dx.float().cpu(), ((dy.double() @ W.double()) * xa.grad).cpu(), 3e-3, 2 ** -7, what="dgrad * gelu'")
+    # weight gradient: split-K, accumulate, bit-reproducible
+    dW = torch.full((N, K), 0.25, device=DEV)
+    outs = []
+    for _ in range(2):
+        dW = torch.full((N, K), 0.25, device=DEV)
+        vf.gemm(dy, A, dW, N, K, M, N, K, K, flags=vf.A_KM | vf.B_KM | vf.OUT_F32, ksplit=4, accumulate=True)
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[1])
+    assert_close_scaled(dW.cpu(), (dy.double().t() @ A.double() + 0.25).cpu(), 2e-5, what="split-K weight gradient")
+    # two-level batch: (image, head) strided slices of a qkv-like buffer
+    Bn, Hn, T, dh = 3, 4, 37, 64
+    Dm = Hn * dh
+    qkv = _r(Bn, T, 3 * Dm, seed=9).to(BF).to(DEV)
+    Tp = 48
+    S = torch.zeros((Bn * Hn, T, Tp), device=DEV, dtype=BF)
+    vf.gemm(qkv, qkv, S, T, T, dh, 3 * Dm, 3 * Dm, Tp, b_off=Dm, batch=Bn * Hn, batch2=Hn, sA=(T * 3 * Dm, dh),
+            sB=(T * 3 * Dm, dh), sC=(Hn * T * Tp, T * Tp), alpha=0.125)
+    q = qkv[:, :, :Dm].reshape(Bn, T, Hn, dh).permute(0, 2, 1, 3).double()
+    k = qkv[:, :, Dm:2 * Dm].reshape(Bn, T, Hn, dh).permute(0, 2, 1, 3).double()
+    ref = 0.125 * q @ k.transpose(-1, -2)
+    assert_close(S.view(Bn, Hn, T, Tp)[..., :T].float().cpu(), ref.cpu(), 3e-3, 2 ** -8, what="batched scores")
+
+
+def test_vit_row_kernels():
+    from mclstexp_amd import _lib, vit_fused as vf
+    L = _lib.lib()
+    rows, D = 333, 768
+    x = _r(rows, D, seed=1, scale=2.0).to(BF).to(DEV)
+    ln = torch.nn.LayerNorm(D, eps=1e-6).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.uniform_(-0.3, 0.3)
+    y, mean, rstd = vf.ln_fwd(x, ln, rows)
+    x64 = x.double().requires_grad_(True)
+    ln64 = copy.deepcopy(ln).double()
+    ref = ln64(x64)
+    assert_close(y.float().cpu(), ref.detach().cpu(), 2e-3, 2 ** -8, what="layernorm fwd")
+    dy = _r(rows, D, seed=2).to(BF).to(DEV)
+    add = _r(rows, D, seed=3).to(BF).to(DEV)
+    ref.backward(dy.double())
+    dx, dg, db = vf.ln_bwd(dy, x, ln, mean, rstd, add, rows)
+    assert_close(dx.float().cpu(), (x64.grad + add.double()).cpu(), 4e-3, 2 ** -7, what="layernorm dx + add")
+    assert_close_scaled(dg.cpu(), ln64.weight.grad.cpu(), 2e-3, what="dgamma")
+    assert_close_scaled(db.cpu(), ln64.bias.grad.cpu(), 2e-3, what="dbeta")
+    b = torch.nn.Parameter(torch.zeros(2304, device=DEV))
+    d2 = _r(rows, 2304, seed=4).to(BF).to(DEV)
+    g = vf.bias_grad(d2, b, rows)
+    assert_close_scaled(g.cpu(), d2.double().sum(0).cpu(), 1e-5, what="bias grad")
+    # softmax fwd / bwd in place, padded rows
+    R, n, ld = 500, 197, 208
+    s = torch.zeros((R, ld), device=DEV, dtype=BF)
+    s[:, :n] = _r(R, n, seed=5, scale=4.0).to(BF).to(DEV)
+    s0 = s.clone()
+    _lib.check(L.mcl_softmax_bf16_fwd(s.data_ptr(), ld, R, n, vf._st()))
+    p64 = torch.softmax(s0[:, :n].double(), dim=1)
+    assert_close(s[:, :n].float().cpu(), p64.cpu(), 1e-3, 2 ** -8, what="softmax")
+    assert (s[:, n:] == 0).all()
+    dp = torch.zeros((R, ld), device=DEV, dtype=BF)
+    dp[:, :n] = _r(R, n, seed=6).to(BF).to(DEV)
+    dp0 = dp.clone()
+    _lib.check(L.mcl_softmax_bf16_bwd(s.data_ptr(), dp.data_ptr(), ld, R, n, 0.125, vf._st()))
+    pp = s[:, :n].double()
+    refd = pp * (dp0[:, :n].double() - (pp * dp0[:, :n].double()).sum(1, keepdim=True)) * 0.125
+    assert_close(dp[:, :n].float().cpu(), refd.cpu(), 1e-4, 2 ** -7, what="softmax bwd")
+
+
+@pytest.mark.parametrize("name,B", [("vit_base_patch32_224", 6), ("vit_base_patch16_224", 3)])
+def test_vit_fused_matches_fp64_module(name, B):
+    """Whole encoder forward + backward on the bf16 kernels vs an fp64 run of the same module (timm layout restated in
+    backbones.py): features 3e-2 of max|feature|, parameter gradients median relative deviation 3e-2, max 0.25."""
+    from mclstexp_amd.backbones import ImageEncoder_VIT
+    from mclstexp_amd.vit_fused import vit_features_fused
+    torch.manual_seed(0)
+    enc = ImageEncoder_VIT(name)
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))             # non-trivial biases / LayerNorm parameters
+    x = _r(B, 3, 224, 224, seed=5).abs().to(DEV)
+    dy = _r(B, 768, seed=6).to(DEV)
+    ref64 = copy.deepcopy(enc).double().to(DEV).train()
+    y64 = ref64(x.double())
+    y64.backward(dy.double())
+    fus = copy.deepcopy(enc).to(DEV).train()
+    y = vit_features_fused(fus.model, x)
+    y.backward(dy)
+    scale = y64.abs().max().item()
+    err = (y.double() - y64).abs().max().item() / scale
+    devs, names = [], []
+    for (n, p64), (_, q) in zip(ref64.named_parameters(), fus.named_parameters()):
+        assert q.grad is not None, n
+        devs.append(((q.grad.double() - p64.grad).abs().max() / (p64.grad.abs().max() + 1e-30)).item())
+        names.append(n)
+    devs = np.array(devs)
+    print(f"{name} B={B}: feature err {err:.2e}; grad rel-dev median {np.median(devs):.2e} max {devs.max():.2e} "
+          f"({names[int(devs.argmax())]})")
+    assert err <= 3e-2, err
+    assert np.median(devs) <= 3e-2 and devs.max() <= 0.25, (np.median(devs), devs.max(), names[int(devs.argmax())])
