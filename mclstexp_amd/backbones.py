@@ -312,10 +312,19 @@ class ImageEncoder_VIT(nn.Module):
         return self.model(x)
 
 
+class ImageEncoder_VIT16(ImageEncoder_VIT):
+    """Extension (not a reference selector value): ViT-B/16, the model BASELINE.json configs[2] names; the reference's
+    'vit' is timm's vit_base_patch32_224 (model.py:106)."""
+
+    def __init__(self):
+        super().__init__("vit_base_patch16_224")
+
+
 ENCODERS = {
     "resnet50": ImageEncoder_Resnet,
     "densenet121": ImageEncoder,
     "vit": ImageEncoder_VIT,
+    "vit_b16": ImageEncoder_VIT16,
     "res18": ImageEncdoer_res18,
     "res101": ImageEncdoer_res101,
 }

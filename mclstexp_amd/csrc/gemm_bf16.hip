@@ -10,9 +10,11 @@
 //     B_KMAJOR = 0:  B(k, n) = B[n*ldb + k]   (k contiguous; nn.Linear weights [out][in] in the forward, K in Q K^T)
 //     B_KMAJOR = 1:  B(k, n) = B[k*ldb + n]   (reduction-major; the weight in a data gradient, V in P V)
 //
-// MI355X mapping: 128 x 128 output tile per workgroup (4 waves, 2 x 2, each 64 x 64 = four 32 x 32 MFMA blocks), K in
-// steps of 64.  Operand tiles (16 KB each) arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) into a
-// double-buffered LDS stage exactly as they lie in HBM -- k-contiguous tiles as 128-byte rows read back with
+// MI355X mapping: 256 x 256 output tile per workgroup (8 waves, 2 x 4, each 128 x 64 = eight 32 x 32 MFMA blocks, 128
+// accumulator registers), K in steps of 64: 128 flop per byte staged -- a 128 x 128 tile (64 flop/B) needs ~39 TB/s of
+// L2 -> LDS traffic at MFMA peak and measured 335 TF/s.  Operand tiles (two 16 KB sub-tiles of 128 rows / columns each)
+// arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip) into a double-buffered 2 x 64 KB LDS stage exactly as
+// they lie in HBM -- k-contiguous tiles as 128-byte rows read back with
 // ds_read_b128, reduction-major tiles as 256-byte rows read back with the transposing ds_read_b64_tr_b16 -- with the
 // bank-conflict-avoiding XOR swizzle applied on the DMA's SOURCE address.  Ragged M / N / K: out-of-range rows and
 // chunks are fetched from clamped (valid) addresses and the reduction tail is zeroed in the A fragment, so arbitrary
@@ -34,9 +36,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_B = 16384;                 // bytes per operand tile
-constexpr int STAGE_B = 2 * TILE_B;
+constexpr int BK = 64;
+constexpr int SUB_B = 16384;                  // bytes per 128-row (or 128-column) operand sub-tile
 
 #define MCL_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -97,18 +98,39 @@ __device__ __forceinline__ float gelu_g(float x) {
   return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE_B];
+// SUBS = 2: 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each) -- the large linears.  SUBS = 1: 128 x 128 tile, 4 waves
+// (2 x 2, 64 x 64 each), two workgroups per CU -- the batched attention products (197 x 197 x 64 per image and head:
+// a 256 x 256 tile would be 41 % padding and one workgroup per CU).
+template <bool A_KMAJOR, bool B_KMAJOR, int SUBS>
+__global__ __launch_bounds__(256 * SUBS) void gemm_bf16_kernel(GemmB g) {
+  constexpr int BM = 128 * SUBS, BN = 128 * SUBS;
+  constexpr int TILE_B = SUBS * SUB_B, STAGE_B = 2 * TILE_B;
+  constexpr int NI = 2 * SUBS;                 // 32-row blocks per wave
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // 2 stages x (A tile + B tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
-  // XCD-aware decode (block id % 8 = XCD): row panel = (q / tn) * 8 + xcd, column tile = q % tn
-  const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
-  const int bid = blockIdx.x % per_batch, b = blockIdx.x / per_batch;
-  const int xcd = bid & 7, q = bid >> 3;
-  const int ks = q % g.ksplit, q2 = q / g.ksplit;
-  const int tx = q2 % g.tn, ty = (q2 / g.tn) * 8 + xcd;
-  if (ty >= g.tm) return;
+  const int wm = SUBS == 2 ? wave >> 2 : wave >> 1, wn = SUBS == 2 ? wave & 3 : wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  int b, ks, tx, ty;
+  if (g.tm >= 8) {
+    // XCD-aware decode (block id % 8 = XCD): row panel = (q / tn) * 8 + xcd, column tile = q % tn
+    const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
+    const int bid = blockIdx.x % per_batch;
+    b = blockIdx.x / per_batch;
+    const int xcd = bid & 7, q = bid >> 3;
+    ks = q % g.ksplit;
+    const int q2 = q / g.ksplit;
+    tx = q2 % g.tn;
+    ty = (q2 / g.tn) * 8 + xcd;
+    if (ty >= g.tm) return;
+  } else {                                     // few row panels (batched small problems): plain decode, no padding
+    const int per_batch = g.tm * g.tn * g.ksplit;
+    const int bid = blockIdx.x % per_batch;
+    b = blockIdx.x / per_batch;
+    ks = bid % g.ksplit;
+    const int q2 = bid / g.ksplit;
+    tx = q2 % g.tn;
+    ty = q2 / g.tn;
+  }
   const int m0 = ty * BM, n0 = tx * BN;
   const long long k_begin = (long long)ks * g.k_per_split;
   const long long k_end = min((long long)g.K, k_begin + g.k_per_split);
@@ -119,46 +141,47 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
   const long long c_off = (long long)b1 * g.sCb + (long long)b2 * g.sCb2;
   const unsigned lds_base = (unsigned)(size_t)MCL_LDSP(lds);
 
-  // ---- DMA geometry.  Out-of-range rows / chunks are clamped to valid addresses (finite garbage); the reduction
-  // tail is zeroed in the A fragment, M / N tails are never stored.
+  // ---- DMA geometry: 32 pieces of 1 KB per operand tile (16 per sub-tile); wave w issues pieces w, w+8, w+16, w+24.
+  // Out-of-range rows / chunks are clamped to valid addresses (finite garbage); the reduction tail is zeroed in the A
+  // fragment, M / N tails are never stored.
   auto dma_tile = [&](int t, int stage) {
     const long long k0 = k_begin + (long long)t * BK;
     const unsigned dA = lds_base + stage * STAGE_B, dB = dA + TILE_B;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int p = wave + 4 * u;                                  // piece index 0..15 (1 KB each)
+      const int p = wave + 4 * SUBS * u, sub = p >> 4, pp = p & 15;
       if (!A_KMAJOR) {                                             // 8 rows (m) x 128 B
-        const int row = 8 * p + (lane >> 3);
+        const int row = 8 * pp + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        long long m = m0 + row;  m = m < g.M ? m : g.M - 1;
+        long long m = m0 + sub * 128 + row;  m = m < g.M ? m : g.M - 1;
         long long k = k0 + lc * 8;  k = k < g.K ? k : 0;
         glds16(A + m * g.lda + k, __builtin_amdgcn_readfirstlane(dA + p * 1024));
       } else {                                                     // 4 rows (k) x 256 B
-        const int row = 4 * p + (lane >> 4);
+        const int row = 4 * pp + (lane >> 4);
         const int lc = (lane & 15) ^ (((lane >> 4) & 3) << 2);
         long long k = k0 + row;  k = k < g.K ? k : g.K - 1;
-        long long m = m0 + lc * 8;  m = m < g.M ? m : 0;
+        long long m = m0 + sub * 128 + lc * 8;  m = m < g.M ? m : 0;
         glds16(A + k * g.lda + m, __builtin_amdgcn_readfirstlane(dA + p * 1024));
       }
       if (!B_KMAJOR) {
-        const int row = 8 * p + (lane >> 3);
+        const int row = 8 * pp + (lane >> 3);
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        long long n = n0 + row;  n = n < g.N ? n : g.N - 1;
+        long long n = n0 + sub * 128 + row;  n = n < g.N ? n : g.N - 1;
         long long k = k0 + lc * 8;  k = k < g.K ? k : 0;
         glds16(B + n * g.ldb + k, __builtin_amdgcn_readfirstlane(dB + p * 1024));
       } else {
-        const int row = 4 * p + (lane >> 4);
+        const int row = 4 * pp + (lane >> 4);
         const int lc = (lane & 15) ^ (((lane >> 4) & 3) << 2);
         long long k = k0 + row;  k = k < g.K ? k : g.K - 1;
-        long long n = n0 + lc * 8;  n = n < g.N ? n : 0;
+        long long n = n0 + sub * 128 + lc * 8;  n = n < g.N ? n : 0;
         glds16(B + k * g.ldb + n, __builtin_amdgcn_readfirstlane(dB + p * 1024));
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -171,101 +194,107 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmB g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t >= 1 && t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);
-    const unsigned char* tA = lds + (t & 1) * STAGE_B;
-    const unsigned char* tB = tA + TILE_B;
+    // this wave's 128-row sub-tile of A / 128-column sub-tile of B and its offsets inside them
+    const unsigned char* tA = lds + (t & 1) * STAGE_B + (SUBS == 2 ? wm * SUB_B : 0);
+    const unsigned char* tB = lds + (t & 1) * STAGE_B + TILE_B + (SUBS == 2 ? (wn >> 1) * SUB_B : 0);
+    const int ra = SUBS == 2 ? 0 : wm * 64;
+    const int cb = SUBS == 2 ? (wn & 1) * 64 : wn * 64;
     const int kvalid = (int)min((long long)BK, k_end - (k_begin + (long long)t * BK));
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[NI], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!A_KMAJOR) fa[i] = frag_kc(tA, wm * 64 + i * 32 + l31, kk, h);
-        else fa[i] = frag_km(tA, kk + 8 * h, wm * 64 + i * 32, lane);
+      for (int i = 0; i < NI; ++i) {
+        if (!A_KMAJOR) fa[i] = frag_kc(tA, ra + i * 32 + l31, kk, h);
+        else fa[i] = frag_km(tA, kk + 8 * h, ra + i * 32, lane);
       }
       if (kvalid < BK) {                             // reduction tail: zero A beyond K (B's clamped reads are finite)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (kk + 8 * h + e >= kvalid) fa[i][e] = 0;
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (!B_KMAJOR) fb[j] = frag_kc(tB, wn * 64 + j * 32 + l31, kk, h);
-        else fb[j] = frag_km(tB, kk + 8 * h, wn * 64 + j * 32, lane);
+        if (!B_KMAJOR) fb[j] = frag_kc(tB, cb + j * 32 + l31, kk, h);
+        else fb[j] = frag_km(tB, kk + 8 * h, cb + j * 32, lane);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   }
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
 
-  // ---- epilogue through LDS: wave tile 64 x 64 fp32 (4 x 16 KB = exactly the two operand stages)
+  // ---- epilogue through LDS in halves of 64 rows: wave tile half 64 x 64 fp32 (16 KB per wave = the operand stages)
   constexpr int EP = 64;
   float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        et[row * EP + j * 32 + l31] = acc[i][j][r] * g.alpha;
-      }
-  // (a wave reads back only what it wrote: no workgroup barrier needed; LDS ops of a wave complete in order)
-  const int mw = m0 + wm * 64, nw = n0 + wn * 64;
   const int cch = lane & 7;                          // 8 chunks of 8 columns per 64-column row
-#pragma unroll 2
-  for (int rr = lane >> 3; rr < 64; rr += 8) {
-    const int m = mw + rr, n = nw + cch * 8;
-    if (m >= g.M || n >= g.N) continue;
-    const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    if (g.bias) {
+#pragma unroll 1
+  for (int half = 0; half < SUBS; ++half) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (n + e < g.N) v[e] += g.bias[n + e];
-    }
-    if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
-      float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
-      if (n + 8 <= g.N) {
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          et[row * EP + j * 32 + l31] = (half == 0 ? acc[ii][j][r] : acc[NI - 2 + ii][j][r]) * g.alpha;
+        }
+    // (a wave reads back only what it wrote: no workgroup barrier needed; LDS ops of a wave complete in order)
+    const int mw = m0 + wm * (64 * SUBS) + half * 64, nw = n0 + wn * 64;
+#pragma unroll 2
+    for (int rr = lane >> 3; rr < 64; rr += 8) {
+      const int m = mw + rr, n = nw + cch * 8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < g.N) v[e] += g.bias[n + e];
       }
-      continue;
-    }
-    if (g.pre_out) {
-      *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+      if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
+        float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
+        if (n + 8 <= g.N) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
+        }
+        continue;
+      }
+      if (g.pre_out) {
+        *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      }
+      if (g.gelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (g.gelu_bwd) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] *= gelu_g(bf_lo(a[e]));
+          v[2 * e + 1] *= gelu_g(bf_hi(a[e]));
+        }
+      }
+      if (g.resid) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += bf_lo(a[e]);
+          v[2 * e + 1] += bf_hi(a[e]);
+        }
+      }
+      // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
           u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
     }
-    if (g.gelu) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-    }
-    if (g.gelu_bwd) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] *= gelu_g(bf_lo(a[e]));
-        v[2 * e + 1] *= gelu_g(bf_hi(a[e]));
-      }
-    }
-    if (g.resid) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[2 * e] += bf_lo(a[e]);
-        v[2 * e + 1] += bf_hi(a[e]);
-      }
-    }
-    // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
-    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
-        u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
   }
 }
 
@@ -306,7 +335,10 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   g.aux = (const bf16_t*)aux; g.ldaux = ldaux;
   g.pre_out = (bf16_t*)pre_out; g.ldp = ldp;
   g.gelu = gelu; g.gelu_bwd = gbwd; g.out_f32 = f32;
-  g.tm = (M + BM - 1) / BM; g.tn = (N + BN - 1) / BN; g.ksplit = ksplit;
+  // small problems (batched attention products) take the 128 x 128 tile, two workgroups per CU
+  const int subs = (M <= 512 && N <= 512) ? 1 : 2;
+  const int BMh = 128 * subs;
+  g.tm = (M + BMh - 1) / BMh; g.tn = (N + BMh - 1) / BMh; g.ksplit = ksplit;
   long long kps = (K + ksplit - 1) / ksplit;
   kps = (kps + BK - 1) / BK * BK;
   g.k_per_split = kps;
@@ -318,9 +350,23 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
     g.slab_stride = (long long)M * ldc + 64;          // (+64: never a power-of-two stride, see csrc/wrw_fused.hip)
     g.C = workspace;
   }
-  const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
+  const int per_batch = (g.tm >= 8 ? ((g.tm + 7) / 8) * 8 : g.tm) * g.tn * g.ksplit;
   const dim3 grid((unsigned)(per_batch * batch));
-#define MCL_LAUNCH(AK, BKM) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM>), grid, dim3(256), 0, st, g)
+  const size_t lds_bytes = (size_t)4 * subs * SUB_B;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define MCL_ATTR(AK, BKM, SB) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AK, BKM, SB>), \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SUB_B)
+    MCL_ATTR(false, false, 1); MCL_ATTR(false, true, 1); MCL_ATTR(true, false, 1); MCL_ATTR(true, true, 1);
+    MCL_ATTR(false, false, 2); MCL_ATTR(false, true, 2); MCL_ATTR(true, false, 2); MCL_ATTR(true, true, 2);
+#undef MCL_ATTR
+    attr_set = true;
+  }
+#define MCL_LAUNCH(AK, BKM)                                                                                          \
+  do {                                                                                                               \
+    if (subs == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, 2>), grid, dim3(512), lds_bytes, st, g);           \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, 1>), grid, dim3(256), lds_bytes, st, g);                     \
+  } while (0)
   if (!akm && !bkm) MCL_LAUNCH(false, false);
   else if (!akm && bkm) MCL_LAUNCH(false, true);
   else if (akm && !bkm) MCL_LAUNCH(true, false);

@@ -130,45 +130,72 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16_t* __restrict
   }
 }
 
-// Column reductions over the rows: MODE 0: part[wg][0][c] = sum_r dy[r][c] (bias gradient);
-// MODE 1: part[wg][0][c] = sum_r dy * xhat (dgamma), part[wg][1][c] = sum_r dy (dbeta).
-// A workgroup walks rows wg, wg + G, ...; thread t owns columns t, t + 256, ... (coalesced 512-byte row segments).
+// Column reductions over the rows: MODE 0: slab[0][c] = sum_r dy[r][c] (bias gradient);
+// MODE 1: slab[0][c] = sum_r dy * xhat (dgamma), slab[1][c] = sum_r dy (dbeta).
+// A thread owns 8 consecutive columns (16-byte loads); a workgroup covers RP = max(1, 256 / (D/8)) rows per pass and
+// walks the rows with stride G * RP; every (workgroup, row lane) pair writes its own slab (merged in fixed order).
 template <int MODE>
 __global__ __launch_bounds__(256) void colred_kernel(const bf16_t* __restrict__ dy, long long lddy,
                                                      const bf16_t* __restrict__ x, long long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     long long rows, int D, float* __restrict__ part, long long slab) {
-  constexpr int MAXC = 12;                    // D <= 3072
-  float a[MAXC], b[MAXC];
+                                                     long long rows, int D, float* __restrict__ part, long long slab,
+                                                     int RP) {
+  constexpr int U = 2;                        // chunk passes per row: D <= 2 * 256 * 8 = 4096
+  const int nch = D >> 3;
+  const int rl = nch < 256 ? threadIdx.x / nch : 0;
+  const int c0 = nch < 256 ? threadIdx.x % nch : threadIdx.x;
+  const bool lane_on = rl < RP;
+  float a[U][8], b[U][8];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) a[i] = b[i] = 0.0f;
-  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
-    float mu = 0.0f, rs = 0.0f;
-    if (MODE == 1) {
-      mu = mean[r];
-      rs = rstd[r];
-    }
+  for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-      const int c = threadIdx.x + 256 * i;
-      if (c < D) {
-        const float d = bf2f(dy[r * lddy + c]);
-        if (MODE == 1) {
-          a[i] = fmaf(d, (bf2f(x[r * ldx + c]) - mu) * rs, a[i]);
-          b[i] += d;
-        } else {
-          a[i] += d;
+    for (int i = 0; i < 8; ++i) a[u][i] = b[u][i] = 0.0f;
+  if (lane_on) {
+    for (long long r = (long long)blockIdx.x * RP + rl; r < rows; r += (long long)gridDim.x * RP) {
+      float mu = 0.0f, rs = 0.0f;
+      if (MODE == 1) {
+        mu = mean[r];
+        rs = rstd[r];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + 256 * u;
+        if (c < nch) {
+          const uint4 wd = *reinterpret_cast<const uint4*>(dy + r * lddy + c * 8);
+          const unsigned dd[4] = {wd.x, wd.y, wd.z, wd.w};
+          if (MODE == 1) {
+            const uint4 wx = *reinterpret_cast<const uint4*>(x + r * ldx + c * 8);
+            const unsigned xx[4] = {wx.x, wx.y, wx.z, wx.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float d0 = __uint_as_float(dd[i] << 16), d1 = __uint_as_float(dd[i] & 0xFFFF0000u);
+              a[u][2 * i] = fmaf(d0, (__uint_as_float(xx[i] << 16) - mu) * rs, a[u][2 * i]);
+              a[u][2 * i + 1] = fmaf(d1, (__uint_as_float(xx[i] & 0xFFFF0000u) - mu) * rs, a[u][2 * i + 1]);
+              b[u][2 * i] += d0;
+              b[u][2 * i + 1] += d1;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              a[u][2 * i] += __uint_as_float(dd[i] << 16);
+              a[u][2 * i + 1] += __uint_as_float(dd[i] & 0xFFFF0000u);
+            }
+          }
         }
       }
     }
-  }
-  float* p = part + (long long)blockIdx.x * slab;
+    float* p = part + ((long long)blockIdx.x * RP + rl) * slab;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int c = threadIdx.x + 256 * i;
-    if (c < D) {
-      p[c] = a[i];
-      if (MODE == 1) p[D + c] = b[i];
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 256 * u;
+      if (c < nch) {
+        *reinterpret_cast<float4*>(p + c * 8) = make_float4(a[u][0], a[u][1], a[u][2], a[u][3]);
+        *reinterpret_cast<float4*>(p + c * 8 + 4) = make_float4(a[u][4], a[u][5], a[u][6], a[u][7]);
+        if (MODE == 1) {
+          *reinterpret_cast<float4*>(p + D + c * 8) = make_float4(b[u][0], b[u][1], b[u][2], b[u][3]);
+          *reinterpret_cast<float4*>(p + D + c * 8 + 4) = make_float4(b[u][4], b[u][5], b[u][6], b[u][7]);
+        }
+      }
     }
   }
 }
@@ -262,10 +289,24 @@ extern "C" int mcl_ln_bf16_fwd(const void* x, int64_t ldx, const float* gamma, c
   return MCL_OK;
 }
 
+namespace {
+struct ColPlan {
+  int G, RP;
+};
+inline ColPlan colplan(long long rows, int D) {
+  ColPlan p;
+  const int nch = D >> 3;
+  p.RP = nch < 256 ? 256 / nch : 1;
+  long long g = (rows + p.RP - 1) / p.RP;
+  p.G = (int)(g < 1024 ? g : 1024);
+  return p;
+}
+}  // namespace
+
 extern "C" int64_t mcl_colred_workspace_floats(int64_t rows, int32_t D) {
   if (rows <= 0 || D <= 0) return -1;
-  const int64_t G = rows < 512 ? rows : 512;
-  return G * (2 * (int64_t)D + 64);
+  const ColPlan p = colplan(rows, D);
+  return (int64_t)p.G * p.RP * (2 * (int64_t)D + 64);
 }
 
 // dx (+ dx_add) and, merged in fixed order, dgamma / dbeta (accumulate != 0: +=).  workspace: mcl_colred_workspace_floats.
@@ -284,12 +325,12 @@ extern "C" int mcl_ln_bf16_bwd(const void* dy, int64_t lddy, const void* x, int6
   hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dy,
                      (long long)lddy, (const bf16_t*)x, (long long)ldx, gamma, mean, rstd, (const bf16_t*)dx_add,
                      (long long)ldadd, (bf16_t*)dx, (long long)lddx, (long long)rows, D);
-  const int G = (int)(rows < 512 ? rows : 512);
+  const ColPlan cp = colplan(rows, D);
   const long long slab = 2LL * D + 64;
-  hipLaunchKernelGGL((colred_kernel<1>), dim3(G), dim3(256), 0, st, (const bf16_t*)dy, (long long)lddy, (const bf16_t*)x,
-                     (long long)ldx, mean, rstd, (long long)rows, D, workspace, slab);
-  mcl_launch_wrw_merge_strided(workspace, G, D, slab, dgamma, accumulate, st);
-  mcl_launch_wrw_merge_strided(workspace + D, G, D, slab, dbeta, accumulate, st);
+  hipLaunchKernelGGL((colred_kernel<1>), dim3(cp.G), dim3(256), 0, st, (const bf16_t*)dy, (long long)lddy,
+                     (const bf16_t*)x, (long long)ldx, mean, rstd, (long long)rows, D, workspace, slab, cp.RP);
+  mcl_launch_wrw_merge_strided(workspace, cp.G * cp.RP, D, slab, dgamma, accumulate, st);
+  mcl_launch_wrw_merge_strided(workspace + D, cp.G * cp.RP, D, slab, dbeta, accumulate, st);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
@@ -299,14 +340,16 @@ extern "C" int mcl_colsum_bf16(const void* x, int64_t ldx, int64_t rows, int32_t
                                int32_t accumulate, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!x || !workspace || !out || rows <= 0 || D <= 0) return MCL_EINVAL;
-  if ((D % 4) || D > 3072 || (reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+  if ((D % 8) || D > 4096 || (ldx % 8) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return MCL_EUNSUPPORTED;
   hipStream_t st = mcl_stream(stream);
-  const int G = (int)(rows < 512 ? rows : 512);
+  const ColPlan cp = colplan(rows, D);
   const long long slab = 2LL * D + 64;
-  hipLaunchKernelGGL((colred_kernel<0>), dim3(G), dim3(256), 0, st, (const bf16_t*)x, (long long)ldx, (const bf16_t*)nullptr,
-                     0LL, (const float*)nullptr, (const float*)nullptr, (long long)rows, D, workspace, slab);
-  mcl_launch_wrw_merge_strided(workspace, G, D, slab, out, accumulate, st);
+  hipLaunchKernelGGL((colred_kernel<0>), dim3(cp.G), dim3(256), 0, st, (const bf16_t*)x, (long long)ldx,
+                     (const bf16_t*)nullptr, 0LL, (const float*)nullptr, (const float*)nullptr, (long long)rows, D,
+                     workspace, slab, cp.RP);
+  mcl_launch_wrw_merge_strided(workspace, cp.G * cp.RP, D, slab, out, accumulate, st);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -64,8 +64,8 @@ def _w16(w: Tensor) -> Tensor:
 
 
 def _ksplit(m_out: int, n_out: int) -> int:
-    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
-    return max(2, min(16, (512 + tiles - 1) // tiles))
+    tiles = ((m_out + 255) // 256) * ((n_out + 255) // 256)
+    return max(2, min(64, (256 + tiles - 1) // tiles))
 
 
 def _grad_target(p: Tensor):
