@@ -319,6 +319,31 @@ def embed_rowgrad(d_out: Tensor, idx: Tensor) -> RowSparseGrad:
     return RowSparseGrad(owner, rows)
 
 
+# Positions outside [0, table rows) are clamped by the kernel and flagged in a device word instead of raising in the middle
+# of an enqueue-only step; ``check_position_errors`` turns the flag into nn.Embedding's IndexError at a point where the
+# host synchronises anyway (train() does it with the loss.item() of its meter).
+_pos_err = {}
+
+
+def position_error_flag(device) -> Tensor:
+    t = _pos_err.get(device.index)
+    if t is None:
+        t = torch.zeros(1, device=device, dtype=torch.int32)
+        _pos_err[device.index] = t
+    return t
+
+
+def check_position_errors(device=None) -> None:
+    """Raises IndexError if any batch since the last check held a position outside the tables (host sync)."""
+    for idx, t in list(_pos_err.items()):
+        if device is not None and device.index != idx:
+            continue
+        if int(t.item()) != 0:
+            t.zero_()
+            raise IndexError("index out of range in self: a batch held a position outside [0, 65536) "
+                             "(the reference's nn.Embedding raises here, model.py:232-233)")
+
+
 class PosEmbedAddFn(torch.autograd.Function):
     """out = expr + x_table[pos[:,0].long()] + y_table[pos[:,1].long()].
 
@@ -332,6 +357,8 @@ class PosEmbedAddFn(torch.autograd.Function):
     def forward(ctx, expr, pos, x_table, y_table, sparse_sink):
         expr = _rowmajor(expr, "expression")
         B, G = expr.shape
+        if pos.is_cuda and pos.dtype != torch.float32:
+            pos = pos.to(torch.float32)              # integer grid / pixel coordinates (nn.Embedding takes .long())
         pos = _chk(pos, "position").contiguous()
         if pos.shape != (B, 2):
             raise RuntimeError(f"position must be ({B}, 2), got {tuple(pos.shape)}")
@@ -342,7 +369,8 @@ class PosEmbedAddFn(torch.autograd.Function):
         iy = torch.empty((B,), device=expr.device, dtype=torch.int32)
         check(_lib.lib().mcl_pos_embed_add_fwd(expr.data_ptr(), expr.stride(0), pos.data_ptr(), xt.data_ptr(),
                                                yt.data_ptr(), G, xt.shape[0], out.data_ptr(), G, ix.data_ptr(),
-                                               iy.data_ptr(), None, B, G, _stream()), "mcl_pos_embed_add_fwd")
+                                               iy.data_ptr(), position_error_flag(expr.device).data_ptr(), B, G,
+                                               _stream()), "mcl_pos_embed_add_fwd")
         ctx.save_for_backward(ix, iy)
         ctx.n_rows = xt.shape[0]
         ctx.sink = sparse_sink

@@ -18,7 +18,7 @@ from typing import Iterable, Optional
 
 import torch
 
-from . import synth
+from . import ops, synth
 from .model import mclSTExp_Attention
 from .optim import FusedAdam
 from .utils import AvgMeter, get_lr
@@ -104,6 +104,7 @@ def train(model, train_dataLoader: Iterable, optimizer, epoch: int, log_every: i
         if step % log_every == 0:
             count = batch["image"].size(0)
             loss_meter.update(loss.item(), count)
+            ops.check_position_errors()          # nn.Embedding's IndexError, at the sync point the meter forces anyway
     return loss_meter
 
 

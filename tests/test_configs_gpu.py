@@ -257,8 +257,26 @@ def test_cfg4_backbone_full_batch_properties():
     err = (y2 - y1[perm]).abs().max().item() / y1.abs().max().item()
     assert err <= 8e-2, err                       # measured 4e-2: bf16 re-rounding of the re-ordered BatchNorm sums
     devs = np.array([((g2[n] - g1[n]).abs().max() / (g1[n].abs().max() + 1e-30)).item() for n in g1])
-    print(f"B=256 256px: permutation feature dev {err:.2e}; grad dev median {np.median(devs):.2e} max {devs.max():.2e}")
-    assert np.median(devs) <= 5e-2
+    # Parameter gradients of this random-init net under a random upstream gradient are sums of almost cancelling terms:
+    # ANY bf16 execution moves them by tens of percent when the summation order changes.  The yardstick is therefore the
+    # stock bf16-autocast module path put through the same permutation: the fused path must be as permutation-stable.
+    ref = copy.deepcopy(enc)
+    for p in ref.parameters():
+        p.grad = None
+
+    def run_ref(xx, dd):
+        for p in ref.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ref(xx.contiguous(memory_format=torch.channels_last)).float()
+        y.backward(dd)
+        return {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+
+    r1, r2 = run_ref(x, dy), run_ref(x[perm].contiguous(), dy[perm].contiguous())
+    devs_ref = np.array([((r2[n] - r1[n]).abs().max() / (r1[n].abs().max() + 1e-30)).item() for n in r1])
+    print(f"B=256 256px: permutation feature dev {err:.2e}; grad dev median fused {np.median(devs):.2e} "
+          f"stock {np.median(devs_ref):.2e}; max fused {devs.max():.2e} stock {devs_ref.max():.2e}")
+    assert np.median(devs) <= 2.0 * np.median(devs_ref) + 1e-3, (np.median(devs), np.median(devs_ref))
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]

@@ -497,3 +497,20 @@ def test_soft_clip_loss_large_batch_vs_oracle(ops):
     assert_close(loss.item(), ref.item(), 1e-4, what="loss")
     assert_close_scaled(d_es.cpu(), a.grad, 5e-5, what="d_es")
     assert_close_scaled(d_ei.cpu(), b.grad, 5e-5, what="d_ei")
+
+
+def test_out_of_range_position_raises_like_nn_embedding(ops):
+    """positions outside the tables are clamped by the kernel but must not train the wrong rows silently:
+    the device flag turns into nn.Embedding's IndexError at the next check; integer position tensors are accepted."""
+    G = 16
+    xt = torch.zeros(65536, G, device=DEV)
+    yt = torch.zeros(65536, G, device=DEV)
+    expr = torch.ones(3, G, device=DEV)
+    ops.check_position_errors()
+    out = ops.PosEmbedAddFn.apply(expr, torch.tensor([[1, 2], [3, 4], [5, 6]], device=DEV), xt, yt, None)   # int64 positions
+    assert torch.equal(out, expr)
+    ops.check_position_errors()                                   # in range: nothing raised
+    ops.PosEmbedAddFn.apply(expr, torch.tensor([[1.0, 2.0], [70000.0, 4.0], [5.0, -3.0]], device=DEV), xt, yt, None)
+    with pytest.raises(IndexError):
+        ops.check_position_errors()
+    ops.check_position_errors()                                   # the flag was cleared
