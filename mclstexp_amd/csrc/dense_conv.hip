@@ -729,8 +729,10 @@ extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z
 
 // Deterministic form: per-workgroup fp32 partials (32 x 1152 each) in the workspace + a fixed-order merge launch.
 static inline int wrw3_grid(int64_t S, int ntile) {
-  // one partial of 147 KB per workgroup is written and re-read by the merge: fewer, longer pixel ranges on the small maps
-  const int gmax = S >= 200000 ? 256 : (S >= 50000 ? 128 : 64);
+  // Two workgroups per CU on the large maps: the kernel stages each slab synchronously, so a second resident
+  // workgroup is what overlaps one's loads with the other's MFMAs (one per CU measured 133 vs ~75 us in block 1); every
+  // workgroup costs a 147 KB partial that the merge re-reads, hence fewer on the small maps.
+  const int gmax = S >= 200000 ? 512 : (S >= 50000 ? 256 : 96);
   return ntile < gmax ? ntile : gmax;
 }
 

@@ -9,6 +9,7 @@ Reference call sites are cited per function (paths relative to /root/reference/)
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -484,10 +485,20 @@ def infonce_fused_grad(a16: Tensor, b16: Tensor, inv_t: float, lse_a: Tensor, ls
     return dA
 
 
-def infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
+# Below this batch the flash-style kernels are launch-bound (12 small launches, 0.15 ms at B = 128 .. 1024) and the
+# exact fp32 path (5 launches on a B x B matrix that fits L2) is faster AND more accurate: 0.083 ms at B = 128
+# (profiles/r02_infonce_microbench.jsonl).  "fused" therefore means "never materialise the logits where that pays".
+FUSED_MIN_BATCH = int(os.environ.get("MCL_FUSED_MIN_BATCH", "1024"))
+
+
+def infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, min_fused_batch: Optional[int] = None
                           ) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
     """Single-device symmetric InfoNCE on the fused bf16 kernels: (loss, dE_spot, dE_img, None).  Same closed
-    form as ``infonce_fwd_bwd``; the embeddings are rounded to bf16 once, logits never reach HBM."""
+    form as ``infonce_fwd_bwd``; the embeddings are rounded to bf16 once, logits never reach HBM.  Batches below
+    ``min_fused_batch`` (default FUSED_MIN_BATCH) take the exact fp32 kernels instead."""
+    if e_spot.shape[0] < (FUSED_MIN_BATCH if min_fused_batch is None else min_fused_batch):
+        loss, d_es, d_ei, _ = infonce_fwd_bwd(e_spot, e_img, temperature, want_logits=False)
+        return loss, d_es, d_ei, None
     es16, ei16 = cast_bf16(e_spot), cast_bf16(e_img)
     B = es16.shape[0]
     inv_t = 1.0 / temperature
