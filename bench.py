@@ -139,6 +139,20 @@ def _kernel_table():
     return kernel_costs.TABLE
 
 
+def baseline_config_name(args):
+    """Which BASELINE.json config the flags describe (the default flags = configs[1], the metric's own config)."""
+    key = (args.encoder, args.batch, args.image, args.genes)
+    if key == ("densenet121", 128, 224, 1000):
+        return "BASELINE configs[1]"
+    if key == ("densenet121", 8, 112, 785):
+        return "BASELINE configs[0]"
+    if args.encoder in ("vit", "vit_b16") and args.batch == 256:
+        return "BASELINE configs[2] (%s)" % ("ViT-B/32" if args.encoder == "vit" else "ViT-B/16")
+    if key == ("densenet121", 256, 256, 3467):
+        return "BASELINE configs[4] per-GPU shape"
+    return "non-BASELINE configuration"
+
+
 def kernel_roofline(step_fn, n_steps: int, model) -> list:
     """Eager pass: every listed C-ABI call of ``n_steps`` steps is bracketed by HIP events on its launch stream.
     Side streams are switched off for the pass so that each timed launch has the GPU to itself (the durations are
@@ -304,13 +318,14 @@ def main():
             roof["note"] = ("launch unit with the largest time per step; HIP events on the launch stream, eager pass "
                             "after the timed region, side streams off (each launch alone on the GPU)")
         out = {
-            "metric": "training spots/sec (= steps/sec x global batch) at batch 128/GPU, 224px patches, 1000 genes",
+            "metric": "training spots/sec (= steps/sec x global batch) at batch %d/GPU, %dpx patches, %d genes"
+                      % (args.batch, args.image, args.genes),
             "value": round(steps_per_s * gb, 2), "unit": "spots/s", "steps_per_sec": round(steps_per_s, 4),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if bb is not None else "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: train step, batch {args.batch}/GPU, {args.image}x{args.image} "
-                                   f"patches, {args.genes} genes, {args.encoder} image encoder",
+            "config": {"workload": f"{baseline_config_name(args)}: train step, batch {args.batch}/GPU, "
+                                   f"{args.image}x{args.image} patches, {args.genes} genes, {args.encoder} image encoder",
                        "global_batch": gb, "parallelism": f"dp{world}", "backbone_dtype": args.backbone_dtype,
                        "spot_path_mfma": args.compute, "infonce": args.infonce, "hip_graphs": not args.no_graphs,
                        "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",

@@ -313,14 +313,24 @@ def dist_infonce_fused_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float
     return loss, d_es, d_ei, None
 
 
+def dist_infonce_auto(e_spot: Tensor, e_img: Tensor, temperature: float, pg, fused):
+    """Routes the global InfoNCE like the single-process ``ops.InfoNCEFn``: ``fused`` False -> exact fp32 kernels,
+    "fp8" -> e4m3 exchange + fp8 similarity, True -> the flash-style bf16 kernels from a GLOBAL batch of
+    ``ops.FUSED_MIN_BATCH`` pairs, the exact kernels below it (same rule as one process at that batch)."""
+    if fused == "fp8":
+        return dist_infonce_fused_fwd_bwd(e_spot, e_img, temperature, pg, prims=HipFp8Prims)
+    if fused:
+        from . import ops
+        glob = sum(_step_sizes) if _step_sizes is not None else e_spot.shape[0] * td.get_world_size(pg)
+        fused = glob >= ops.FUSED_MIN_BATCH
+    fn = dist_infonce_fused_fwd_bwd if fused else dist_infonce_fwd_bwd
+    return fn(e_spot, e_img, temperature, pg)
+
+
 class DistInfoNCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e_spot, e_img, temperature, pg, stash, fused=False):
-        if fused == "fp8":
-            loss, d_es, d_ei, s_rows = dist_infonce_fused_fwd_bwd(e_spot, e_img, temperature, pg, prims=HipFp8Prims)
-        else:
-            fn = dist_infonce_fused_fwd_bwd if fused else dist_infonce_fwd_bwd
-            loss, d_es, d_ei, s_rows = fn(e_spot, e_img, temperature, pg)
+        loss, d_es, d_ei, s_rows = dist_infonce_auto(e_spot, e_img, temperature, pg, fused)
         if stash is not None:
             stash["logits"] = s_rows
         ctx.save_for_backward(d_es, d_ei)

@@ -311,12 +311,8 @@ class _ContrastiveBase(nn.Module):
         fused = self.infonce != "exact"
         if self.process_group is not None:
             from . import dist as mdist
-            if self.infonce == "fp8":
-                loss, d_es, d_ei, s = mdist.dist_infonce_fused_fwd_bwd(es, ei, float(self.temperature),
-                                                                       self.process_group, prims=mdist.HipFp8Prims)
-            else:
-                fn = mdist.dist_infonce_fused_fwd_bwd if fused else mdist.dist_infonce_fwd_bwd
-                loss, d_es, d_ei, s = fn(es, ei, float(self.temperature), self.process_group)
+            loss, d_es, d_ei, s = mdist.dist_infonce_auto(es, ei, float(self.temperature), self.process_group,
+                                                          self._fused_mode())
         elif self.infonce == "fp8":
             loss, d_es, d_ei, s = ops.infonce_fp8_fwd_bwd(es, ei, float(self.temperature))
         elif fused:

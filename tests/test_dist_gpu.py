@@ -157,7 +157,8 @@ def _rccl_worker(_index, port, ret):
     """Size-1 RCCL group: the full data-parallel step (bf16 embedding all-gather, LSE all-gather, async flat
     all-reduce, gathered table rows, HIP-graph replay around the collectives) on the REAL nccl backend."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-                      MCL_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      MCL_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      MCL_FUSED_MIN_BATCH="0")     # B = 16: keep the bf16 exchange + flash kernels under test
     os.environ.pop("MCL_DIST_BACKEND", None)
     from mclstexp_amd import dist as mdist, synth
     from mclstexp_amd.engine import TrainStep
