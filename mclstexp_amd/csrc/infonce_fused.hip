@@ -85,6 +85,12 @@ struct Dma {
   unsigned base_l;             // (l31 & 16) | ((l31 & 15) ^ (h << 2)): this lane's chunk before the per-piece XOR
   int h, wave, lane, C, ppw;   // ppw = DMA pieces per wave and tile (64 / waves)
   long long ldb_bytes;         // row stride of B in bytes
+  // full-tile fast path: the piece's row pair starts at a WAVE-UNIFORM address (SGPR pair, advanced by two rows per
+  // piece) and the lane adds a 32-bit offset: h rows + its swizzled chunk -- 2 VALU + 2 SALU per piece instead of a
+  // per-lane 64-bit row pointer with an edge select (~13 VALU + exec masking)
+  unsigned hl;                 // h * ldb_bytes
+  int wave_s;                  // wave index, scalar
+  const unsigned char* cur;    // scalar: first row of the next piece
 };
 
 __device__ __forceinline__ void glds16(const void* src, unsigned dst) {
@@ -93,6 +99,15 @@ __device__ __forceinline__ void glds16(const void* src, unsigned dst) {
                : "=&s"(keep)
                : "v"(src), "s"(dst)
                : "memory");
+}
+// saddr form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset
+// (M0 is not saved / restored here: nothing else in these kernels uses it -- checked in the ISA -- and the two extra
+// s_mov per piece are issue slots of a lone wave.)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+               :
+               : "s"(sbase), "v"(voff), "s"(dst)
+               : "memory", "m0");
 }
 __device__ __forceinline__ void glds4(const void* src, unsigned dst) {
   unsigned keep;
@@ -108,8 +123,14 @@ __device__ __forceinline__ void glds4(const void* src, unsigned dst) {
 // Issued as inline asm ON PURPOSE: hipcc cannot prove that a DMA into the OTHER buffer does not alias the LDS
 // it is reading and would drain vmcnt(0) -- the whole prefetch -- mid-tile.  Hidden from its bookkeeping, the DMA
 // is covered by the explicit vmcnt(0) + barrier that ends every iteration (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void dma_piece(const Dma& d, int t, int col0n, unsigned dst_tile) {
+template <bool FAST>
+__device__ __forceinline__ void dma_piece(Dma& d, int t, int col0n, unsigned dst_tile) {
   const unsigned chunk = d.base_l ^ (unsigned)(((t & 1) << 3) | ((t >> 1) & 3));
+  if (FAST) {   // every row of the tile exists: pieces are issued in order t = 0, 1, ..
+    glds16s(d.cur, (chunk << 4) + d.hl, dst_tile + (unsigned)(d.wave_s * d.ppw + t) * 1024u);
+    d.cur += 2 * d.ldb_bytes;
+    return;
+  }
   const int n = d.wave * d.ppw + t;          // piece = tile rows 2n, 2n+1 (ppw is 16 or 8: (2n + h) & 15 == 2t + h)
   const int gcol = col0n + 2 * n + d.h;
   // row pointer without a per-piece 64-bit multiply: (col0n + 2*wave*ppw + h) * ld is per lane and tile, the piece
@@ -134,8 +155,12 @@ __device__ __forceinline__ bf16x8 ld_b(const unsigned char* lds, const int (&a2)
   const int kk = j >> 3, pb = j & 7;
   const unsigned char* p0 = lds + cb * 16384 + kk * 8192 + (pb >> 2) * 256;
   const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p0 + a2[2 * (pb & 3)]));
+#ifdef MCL_EXP_HALF_LDS_B   // timing experiment only (wrong results): half the phase-B LDS traffic
+  const v4s hi = lo;
+#else
   const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (v4s __attribute__((address_space(3)))*)(p0 + 4096 + a2[2 * (pb & 3) + 1]));
+#endif
   bf16x8 bv;
   bv[0] = lo[0]; bv[1] = lo[1]; bv[2] = lo[2]; bv[3] = lo[3];
   bv[4] = hi[0]; bv[5] = hi[1]; bv[6] = hi[2]; bv[7] = hi[3];
@@ -188,14 +213,27 @@ struct EGradPair {
       }
     }
     if (s >= 1 && s <= 32) {    // exponentials of element s-1
+#if defined(MCL_EXP_NOEXP)      // timing experiments only (wrong results)
+      ea1 = xa1 * 0.5f;
+      ea2 = xa2 * 0.5f;
+#elif defined(MCL_EXP_NOE)
+      ea1 = xa1;
+      ea2 = xa2;
+#else
       ea1 = __builtin_amdgcn_exp2f(xa1);
       ea2 = __builtin_amdgcn_exp2f(xa2);
+#endif
     }
     if (s < 32) {               // exponent arguments of element s
       const int i = s & 15;
       const float t = s < 16 ? TE0[i] : TE1[i];
+#ifdef MCL_EXP_NOE
+      xa1 = t;
+      xa2 = s < 16 ? cl0[i] : cl1[i];
+#else
       xa1 = fmaf(t, c.kscale, c.nrl2);
       xa2 = fmaf(t, c.kscale, s < 16 ? cl0[i] : cl1[i]);
+#endif
     }
     // IR-level anchor: without it the (pure) element computations sink below the per-step sched_barriers to the
     // end of the stage and nothing overlaps the MFMAs
@@ -239,11 +277,11 @@ struct EStat {
 // 32 logits MFMAs of blocks CB0, CB0+1 (alternating) [+ E work of blocks ECB, ECB+1] [+ the next tile's DMA].
 // NDMA: DMA pieces of the next tile issued by this wave inside the stage (0 = none).
 // PF0 / PF1: blocks whose column terms are prefetched into eg.cl0 (at step 16) / eg.cl1 (at step 17), or -1.
-template <bool BWD, int CB0, int ECB, bool FIX, int NDMA, int PF0, int PF1>
+template <bool BWD, int CB0, int ECB, bool FIX, int NDMA, int PF0, int PF1, bool FASTDMA>
 __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a1)[8], const bf16x8 (&bfrag)[16],
                                          f32x16& TA0, f32x16& TA1, const f32x16& TE0, const f32x16& TE1, int e_col0,
                                          int e_dcol, int cls_off, EGradPair<FIX>& eg, bf16x8 (&wE0)[2],
-                                         bf16x8 (&wE1)[2], float& run_m, float& run_l, const Ctx& c, const Dma& d,
+                                         bf16x8 (&wE1)[2], float& run_m, float& run_l, const Ctx& c, Dma& d,
                                          int col0n, unsigned dst_tile, unsigned dst_stat) {
   EStat<FIX> s0, s1;
   bf16x8 f[32];
@@ -251,7 +289,14 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
   for (int s = 0; s < 4; ++s) f[s] = ld_a(lds, a1, CB0 + (s & 1), s >> 1);
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
+#ifdef MCL_EXP_HALF_LDS_A   // timing experiment only (wrong results): half the phase-A LDS traffic
+    if (s + 4 < 32) {
+      if (s & 1) f[s + 4] = f[s + 3];
+      else f[s + 4] = ld_a(lds, a1, CB0 + ((s + 4) & 1), (s + 4) >> 1);
+    }
+#else
     if (s + 4 < 32) f[s + 4] = ld_a(lds, a1, CB0 + ((s + 4) & 1), (s + 4) >> 1);
+#endif
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if ((s & 1) == 0) TA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], bfrag[s >> 1], s < 2 ? zero : TA0, 0, 0, 0);
     else TA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], bfrag[s >> 1], s < 2 ? zero : TA1, 0, 0, 0);
@@ -272,7 +317,9 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
     if (BWD && PF0 >= 0 && s == 16) eg.load_cl(eg.cl0, lds, cls_off, PF0, c.h);
     if (BWD && PF1 >= 0 && s == 17) eg.load_cl(eg.cl1, lds, cls_off, PF1, c.h);
     if (NDMA > 0) {   // the next tile's DMA: this wave's NDMA pieces, one per even step
-      if ((s & 1) == 0 && (s >> 1) < NDMA) dma_piece(d, s >> 1, col0n, dst_tile);
+#ifndef MCL_EXP_NODMA
+      if ((s & 1) == 0 && (s >> 1) < NDMA) dma_piece<FASTDMA>(d, s >> 1, col0n, dst_tile);
+#endif
       if (BWD && s == 1) dma_stat(d, col0n, dst_stat);
     }
     MCL_PIN();
@@ -354,6 +401,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
   d.base_l = (unsigned)((l31 & 16) | ((l31 & 15) ^ (h << 2)));
   d.h = h; d.wave = wave; d.lane = lane; d.C = C; d.ppw = PPW;
   d.ldb_bytes = ldb * 2;
+  d.hl = (unsigned)(h * (ldb * 2));
+  d.wave_s = __builtin_amdgcn_readfirstlane(wave);
+  d.cur = d.gbase;
 
   // LDS byte offsets (relative to lds[]) of this lane's reads in the CURRENT buffer; flipped by ^TILE_B per tile.
   // phase A: row l31 of a 32-row block, logical chunk 2*ks + h  ->  physical ((2*ks) ^ (h ^ f(l31))) | (ks >> 3) << 4
@@ -393,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
 
   // first tile: plain (not interleaved) DMA
 #pragma unroll
-  for (int t = 0; t < PPW; ++t) dma_piece(d, t, ct0 * TC, lds_base);
+  for (int t = 0; t < PPW; ++t) dma_piece<false>(d, t, ct0 * TC, lds_base);
   if (BWD) dma_stat(d, ct0 * TC, lds_base + 2 * TILE_B);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -415,8 +465,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
     it_b = nIt;
   }
 
+#ifdef MCL_EXP_NOBARRIER   // timing experiment only (racy)
+#define MCL_EXP_BARRIER()
+#else
+#define MCL_EXP_BARRIER() __syncthreads()
+#endif
   bf16x8 w0[2], w1[2], w2[2], w3[2];
-#define MCL_TILE_ITER(FIXV)                                                                                       \
+#define MCL_TILE_ITER(FIXV, FD)                                                                                    \
   {                                                                                                               \
     const int col0 = (ct0 + it) * TC;                                                                             \
     const int col0n = (ct0 + min(it + 1, nIt - 1)) * TC; /* last iteration re-fetches its own tile: no branch */  \
@@ -426,14 +481,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
     /* launder the lane constant of the DMA source address: otherwise the per-piece offsets are hoisted out of */ \
     /* the tile loop, spilled, and every reload's compiler-inserted vmcnt(0) drains the hand-placed DMA        */ \
     Dma dl = d;                                                                                                   \
-    asm volatile("" : "+v"(dl.base_l), "+v"(dl.h), "+v"(dl.wave));                                                \
+    asm volatile("" : "+v"(dl.base_l), "+v"(dl.h), "+v"(dl.wave), "+v"(dl.hl));                                   \
+    if (FD) dl.cur = d.gbase + (long long)(col0n + 2 * d.wave_s * PPW) * d.ldb_bytes;                             \
     f32x16 T0, T1;                                                                                                \
     EGradPair<FIXV> eg;                                                                                           \
     if (BWD) {                                                                                                    \
       f32x16 T2, T3;                                                                                              \
-      stage_aa<true, 0, -1, FIXV, PPW, 0, 1>(lds, a1, bfrag, T0, T1, T0, T1, col0, dcol, cls_off, eg, w0, w1,    \
+      stage_aa<true, 0, -1, FIXV, PPW, 0, 1, FD>(lds, a1, bfrag, T0, T1, T0, T1, col0, dcol, cls_off, eg, w0, w1,    \
                                               run_m, run_l, c, dl, col0n, dst_tile, dst_stat);                     \
-      stage_aa<true, 2, 0, FIXV, 0, 2, -1>(lds, a1, bfrag, T2, T3, T0, T1, col0, dcol, cls_off, eg, w0, w1,   \
+      stage_aa<true, 2, 0, FIXV, 0, 2, -1, FD>(lds, a1, bfrag, T2, T3, T0, T1, col0, dcol, cls_off, eg, w0, w1,   \
                                                run_m, run_l, c, dl, col0n, dst_tile, dst_stat);                    \
       stage_bb<0, 2, FIXV, 3>(lds, a2, w0, w1, acc, T2, T3, col0, dcol, cls_off, eg, w2, w3, c);                  \
       stage_bb<2, -1, FIXV, -1>(lds, a2, w2, w3, acc, T2, T3, col0, dcol, cls_off, eg, w2, w3, c);                \
@@ -441,13 +497,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
       asm volatile("" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));                                \
       asm volatile("" : "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]));                                \
     } else {                                                                                                      \
-      stage_aa<false, 0, 2, FIXV, PPW, -1, -1>(lds, a1, bfrag, T0, T1, Tp2, Tp3, col0 - TC, dcol, cls_off, eg,   \
+      stage_aa<false, 0, 2, FIXV, PPW, -1, -1, FD>(lds, a1, bfrag, T0, T1, Tp2, Tp3, col0 - TC, dcol, cls_off, eg,   \
                                                 w0, w1, run_m, run_l, c, dl, col0n, dst_tile, dst_stat);           \
-      stage_aa<false, 2, 0, FIXV, 0, -1, -1>(lds, a1, bfrag, Tp2, Tp3, T0, T1, col0, dcol, cls_off, eg, w0,   \
+      stage_aa<false, 2, 0, FIXV, 0, -1, -1, FD>(lds, a1, bfrag, Tp2, Tp3, T0, T1, col0, dcol, cls_off, eg, w0,   \
                                                  w1, run_m, run_l, c, dl, col0n, dst_tile, dst_stat);              \
     }                                                                                                             \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
-    __syncthreads();                                                                                              \
+    MCL_EXP_BARRIER();                                                                                            \
     buf ^= 1;                                                                                                     \
     cls_off ^= STAT_STRIDE;                                                                                       \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                               \
@@ -455,12 +511,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
       if (BWD) a2[q] ^= TILE_B;                                                                                   \
     }                                                                                                             \
   }
+  // Iterations whose PREFETCH targets a ragged tile (the last two of the split that owns the right edge, when C is
+  // not a multiple of the tile) take the generic per-lane DMA addressing, on the fix-up body (valid for any tile);
+  // all others use the scalar-base fast DMA.
+  const int it_e = ((ct0 + nIt) * TC > C) ? max(0, nIt - 2) : nIt;
   int it = 0;
-  for (; it < it_a; ++it) MCL_TILE_ITER(false)
-  for (; it < it_b; ++it) MCL_TILE_ITER(true)
   if (BWD) {
-    for (; it < nIt; ++it) MCL_TILE_ITER(false)
+    for (; it < min(it_a, it_e); ++it) MCL_TILE_ITER(false, true)
+    for (; it < min(it_b, it_e); ++it) MCL_TILE_ITER(true, true)
+    for (; it < it_e; ++it) MCL_TILE_ITER(false, true)
+  } else {
+    for (; it < it_e; ++it) MCL_TILE_ITER(false, true)
   }
+  for (; it < nIt; ++it) MCL_TILE_ITER(true, false)
 #undef MCL_TILE_ITER
 
   if (!BWD) {
