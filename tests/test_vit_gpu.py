@@ -110,22 +110,24 @@ def test_vit_row_kernels():
     d2 = _r(rows, 2304, seed=4).to(BF).to(DEV)
     g = vf.bias_grad(d2, b, rows)
     assert_close_scaled(g.cpu(), d2.double().sum(0).cpu(), 1e-5, what="bias grad")
-    # softmax fwd / bwd in place, padded rows
-    R, n, ld = 500, 197, 208
-    s = torch.zeros((R, ld), device=DEV, dtype=BF)
-    s[:, :n] = _r(R, n, seed=5, scale=4.0).to(BF).to(DEV)
-    s0 = s.clone()
-    _lib.check(L.mcl_softmax_bf16_fwd(s.data_ptr(), ld, R, n, vf._st()))
-    p64 = torch.softmax(s0[:, :n].double(), dim=1)
-    assert_close(s[:, :n].float().cpu(), p64.cpu(), 1e-3, 2 ** -8, what="softmax")
-    assert (s[:, n:] == 0).all()
-    dp = torch.zeros((R, ld), device=DEV, dtype=BF)
-    dp[:, :n] = _r(R, n, seed=6).to(BF).to(DEV)
-    dp0 = dp.clone()
-    _lib.check(L.mcl_softmax_bf16_bwd(s.data_ptr(), dp.data_ptr(), ld, R, n, 0.125, vf._st()))
-    pp = s[:, :n].double()
-    refd = pp * (dp0[:, :n].double() - (pp * dp0[:, :n].double()).sum(1, keepdim=True)) * 0.125
-    assert_close(dp[:, :n].float().cpu(), refd.cpu(), 1e-4, 2 ** -7, what="softmax bwd")
+    # softmax fwd / bwd in place, padded rows: (197, 208) / (50, 56) take the 16-byte half-wave kernels, odd leading
+    # dimensions the scalar ones; the padding columns hold garbage on entry and exact zeros on exit
+    for R, n, ld in ((500, 197, 208), (37, 197, 199), (301, 50, 56), (64, 50, 51), (9, 256, 256)):
+        s = torch.full((R, ld), 7.0, device=DEV, dtype=BF)
+        s[:, :n] = _r(R, n, seed=5, scale=4.0).to(BF).to(DEV)
+        s0 = s.clone()
+        _lib.check(L.mcl_softmax_bf16_fwd(s.data_ptr(), ld, R, n, vf._st()))
+        p64 = torch.softmax(s0[:, :n].double(), dim=1)
+        assert_close(s[:, :n].float().cpu(), p64.cpu(), 1e-3, 2 ** -8, what="softmax %s" % ((R, n, ld),))
+        assert (s[:, n:] == 0).all()
+        dp = torch.full((R, ld), -3.0, device=DEV, dtype=BF)
+        dp[:, :n] = _r(R, n, seed=6).to(BF).to(DEV)
+        dp0 = dp.clone()
+        _lib.check(L.mcl_softmax_bf16_bwd(s.data_ptr(), dp.data_ptr(), ld, R, n, 0.125, vf._st()))
+        pp = s[:, :n].double()
+        refd = pp * (dp0[:, :n].double() - (pp * dp0[:, :n].double()).sum(1, keepdim=True)) * 0.125
+        assert_close(dp[:, :n].float().cpu(), refd.cpu(), 1e-4, 2 ** -7, what="softmax bwd %s" % ((R, n, ld),))
+        assert (dp[:, n:] == 0).all()
 
 
 @pytest.mark.parametrize("name,B", [("vit_base_patch32_224", 6), ("vit_base_patch16_224", 3)])
