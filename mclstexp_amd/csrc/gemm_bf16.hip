@@ -49,6 +49,14 @@ __device__ __forceinline__ void glds16(const void* src, unsigned dst) {
                : "memory");
 }
 
+// saddr form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset (M0 is used by nothing else here)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+               :
+               : "s"(sbase), "v"(voff), "s"(dst)
+               : "memory", "m0");
+}
+
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
@@ -179,6 +187,41 @@ __global__ __launch_bounds__(256 * SUBS) void gemm_bf16_kernel(GemmB g) {
     }
   };
 
+  // Interior tiles (every row / column of the tile exists, K range a multiple of BK): the pieces of a wave differ only
+  // by a wave-uniform row offset, so the source address is an SGPR base (advanced per K-tile) + ONE per-lane 32-bit
+  // offset per operand -- ~5 instructions per piece instead of ~20 (per-lane 64-bit pointers with clamps).
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const bool interior = m0 + BM <= g.M && n0 + BN <= g.N && (k_end - k_begin) % BK == 0 &&
+                        g.lda * 16 < (1ll << 31) && g.ldb * 16 < (1ll << 31);
+  unsigned voffA, voffB;
+  {
+    const int pp1 = wave_s & 1;                                    // parity of every piece index of this wave
+    if (!A_KMAJOR) voffA = (unsigned)((lane >> 3) * g.lda * 2) + (unsigned)((((lane & 7) ^ ((4 * pp1 + (lane >> 4)) & 7))) << 4);
+    else voffA = (unsigned)((lane >> 4) * g.lda * 2) + (unsigned)(((lane & 15) ^ (((lane >> 4) & 3) << 2)) << 4);
+    if (!B_KMAJOR) voffB = (unsigned)((lane >> 3) * g.ldb * 2) + (unsigned)((((lane & 7) ^ ((4 * pp1 + (lane >> 4)) & 7))) << 4);
+    else voffB = (unsigned)((lane >> 4) * g.ldb * 2) + (unsigned)(((lane & 15) ^ (((lane >> 4) & 3) << 2)) << 4);
+  }
+  auto dma_tile_fast = [&](int t, int stage) {
+    const long long k0 = k_begin + (long long)t * BK;
+    const unsigned dA = lds_base + stage * STAGE_B, dB = dA + TILE_B;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = wave_s + 4 * SUBS * u, sub = p >> 4, pp = p & 15;
+      const unsigned char* pa = reinterpret_cast<const unsigned char*>(
+          !A_KMAJOR ? A + (long long)(m0 + sub * 128 + 8 * pp) * g.lda + k0
+                    : A + (k0 + 4 * pp) * g.lda + (m0 + sub * 128));
+      const unsigned char* pb = reinterpret_cast<const unsigned char*>(
+          !B_KMAJOR ? B + (long long)(n0 + sub * 128 + 8 * pp) * g.ldb + k0
+                    : B + (k0 + 4 * pp) * g.ldb + (n0 + sub * 128));
+      glds16s(pa, voffA, dA + p * 1024);
+      glds16s(pb, voffB, dB + p * 1024);
+    }
+  };
+  auto dma = [&](int t, int stage) {
+    if (interior) dma_tile_fast(t, stage);
+    else dma_tile(t, stage);
+  };
+
   f32x16 acc[NI][2];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -187,13 +230,13 @@ __global__ __launch_bounds__(256 * SUBS) void gemm_bf16_kernel(GemmB g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  if (nt > 0) dma_tile(0, 0);
-  if (nt > 1) dma_tile(1, 1);
+  if (nt > 0) dma(0, 0);
+  if (nt > 1) dma(1, 1);
   for (int t = 0; t < nt; ++t) {
     if (t == 0 && nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t >= 1 && t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);
+    if (t >= 1 && t + 1 < nt) dma(t + 1, (t + 1) & 1);
     // this wave's 128-row sub-tile of A / 128-column sub-tile of B and its offsets inside them
     const unsigned char* tA = lds + (t & 1) * STAGE_B + (SUBS == 2 ? wm * SUB_B : 0);
     const unsigned char* tB = lds + (t & 1) * STAGE_B + TILE_B + (SUBS == 2 ? (wn >> 1) * SUB_B : 0);
