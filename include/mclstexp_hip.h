@@ -69,10 +69,16 @@ typedef struct mcl_gemm_args {
   float* pre_out; int64_t ldp;           /* NULL or (M,N): pre-activation store (batch must be 1) */
   const float* aux; int64_t ldaux;       /* (M,N) for MCL_EPI_GELU_BWD (batch must be 1) */
   int32_t compute;       /* MCL_COMPUTE_* */
-  int32_t reserved;
+  int32_t ksplit;        /* 0 / 1: one pass.  > 1: K is cut into that many slices whose fp32 partials go to
+                            `workspace` and a second launch adds them in fixed order and applies the epilogue
+                            (deterministic; for skinny problems such as the spot path's M = batch of 128 spots) */
+  float* workspace;      /* >= mcl_gemm_workspace_floats(M, N, batch, ksplit) floats when ksplit > 1, else unused */
 } mcl_gemm_args;
 
 int mcl_gemm(const mcl_gemm_args* args, mcl_stream_t stream);
+/* Slices that give a problem with few 64x64 output tiles ~256 workgroups (1 = do not split). */
+int32_t mcl_gemm_auto_ksplit(int32_t M, int32_t N, int32_t K, int32_t batch);
+int64_t mcl_gemm_workspace_floats(int32_t M, int32_t N, int32_t batch, int32_t ksplit);
 
 /* ---------------------------------------------------------------- K1 position-embedding add
  * model.py:230-235:  out[b,:] = expr[b,:] + X[(long)pos[b,0],:] + Y[(long)pos[b,1],:]

@@ -40,7 +40,8 @@ class GemmArgs(C.Structure):
         ("resid", c_p), ("ldr", c_l), ("sRb", c_l),
         ("pre_out", c_p), ("ldp", c_l),
         ("aux", c_p), ("ldaux", c_l),
-        ("compute", c_i), ("reserved", c_i),
+        ("compute", c_i), ("ksplit", c_i),
+        ("workspace", c_p),
     ]
 
 
@@ -52,6 +53,8 @@ PROTOTYPES = {
     "mcl_abi_version": [],
     "mcl_error_string": [c_i],
     "mcl_gemm": [C.POINTER(GemmArgs), c_p],
+    "mcl_gemm_auto_ksplit": [c_i, c_i, c_i, c_i],
+    "mcl_gemm_workspace_floats": [c_i, c_i, c_i, c_i],
     "mcl_pos_embed_add_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p],
     "mcl_embed_rowgrad": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
     "mcl_embed_scatter_rows": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
@@ -134,7 +137,8 @@ _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_bn_workspace_floats": C.c_int6
              "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64,
              "mcl_wrw_workspace_floats": C.c_int64, "mcl_dense_conv3x3_wrw_workspace_floats": C.c_int64,
              "mcl_conv0_wrw_workspace_floats": C.c_int64, "mcl_infonce_fp8_workspace_bytes": C.c_int64,
-             "mcl_gemm_bf16_workspace_floats": C.c_int64, "mcl_colred_workspace_floats": C.c_int64}
+             "mcl_gemm_bf16_workspace_floats": C.c_int64, "mcl_colred_workspace_floats": C.c_int64,
+             "mcl_gemm_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

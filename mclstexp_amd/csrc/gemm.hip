@@ -30,6 +30,8 @@ struct GemmP {
   const float* resid; long long ldr, sRb;
   float* pre_out; long long ldp;
   const float* aux; long long ldaux;
+  int batch, ksplit, kchunk;     // split-K: slice s covers k in [s*kchunk, min(K, (s+1)*kchunk)), kchunk % BK == 0
+  float* ws;                     // split-K partials [ksplit][batch][M][N]
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int bz = blockIdx.z;
+  const int bz = blockIdx.z % p.batch, ksl = blockIdx.z / p.batch;
+  const int kbeg = ksl * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   const float* __restrict__ A = p.A + (long long)bz * p.sAb;
   const float* __restrict__ B = p.B + (long long)bz * p.sBb;
 
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
   float ra[8], rb[8];
-  const int nk = (p.K + BK - 1) / BK;
-  load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, 0, p.M, p.K, tid);
-  load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, 0, p.N, p.K, tid);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, kbeg, p.M, kend, tid);
+  load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, kbeg, p.N, kend, tid);
 
   const int arow = wm * 32 + (lane & 31);
   const int brow = wn * 32 + (lane & 31);
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
     store_slice<BKC>(rb, Bs, tid);
     __syncthreads();
     if (kt + 1 < nk) {
-      load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, (kt + 1) * BK, p.M, p.K, tid);
-      load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, (kt + 1) * BK, p.N, p.K, tid);
+      load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, kbeg + (kt + 1) * BK, p.M, kend, tid);
+      load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, kbeg + (kt + 1) * BK, p.N, kend, tid);
     }
     if (!BF16) {
 #pragma unroll
@@ -157,6 +160,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
   // epilogue: acc[r] -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the wave's 32x32 block
   const int col = n0 + wn * 32 + (lane & 31);
   if (col >= p.N) return;
+  if (p.ksplit > 1) {   // raw partial of this K slice; the epilogue runs in gemm_splitk_epilogue_kernel
+    float* __restrict__ W = p.ws + ((long long)ksl * p.batch + bz) * p.M * p.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < p.M) W[(long long)row * p.N + col] = acc[r];
+    }
+    return;
+  }
   float* __restrict__ C = p.C + (long long)bz * p.sCb;
   const float* __restrict__ R = p.resid ? p.resid + (long long)bz * p.sRb : nullptr;
   const float bias = p.bias ? p.bias[col] : 0.0f;
@@ -174,9 +186,29 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
   }
 }
 
+// Split-K second pass: fixed-order sum of the K slices + the same epilogue as the one-pass kernel (deterministic).
+__global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmP p) {
+  const long long MN = (long long)p.M * p.N, total = MN * p.batch;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int bz = (int)(q / MN);
+    const long long e = q - (long long)bz * MN;
+    const int row = (int)(e / p.N), col = (int)(e - (long long)row * p.N);
+    float a = 0.0f;
+    for (int s = 0; s < p.ksplit; ++s) a += p.ws[((long long)s * p.batch + bz) * MN + e];
+    float v = p.alpha * a + (p.bias ? p.bias[col] : 0.0f);
+    if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
+    if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
+    if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
+    if (p.resid) v += p.resid[(long long)bz * p.sRb + (long long)row * p.ldr + col];
+    float* C = p.C + (long long)bz * p.sCb + (long long)row * p.ldc + col;
+    if (p.flags & MCL_EPI_ACCUM) v += *C;
+    *C = v;
+  }
+}
+
 template <bool AKC, bool BKC, bool VEC>
 void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch), block(NT);
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch * p.ksplit), block(NT);
   if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true>), grid, block, 0, st, p);
   else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false>), grid, block, 0, st, p);
 }
@@ -202,6 +234,8 @@ extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
   if ((a->flags & MCL_EPI_GELU_BWD) && !a->aux) return MCL_EINVAL;
   if (a->compute != MCL_COMPUTE_F32 && a->compute != MCL_COMPUTE_BF16) return MCL_EUNSUPPORTED;
   if (a->batch > 65535) return MCL_EUNSUPPORTED;
+  const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
+  if (ksplit > 1 && (!a->workspace || (long long)a->batch * ksplit > 65535 || ksplit > 64)) return MCL_EINVAL;
 
   GemmP p;
   p.M = a->M; p.N = a->N; p.K = a->K;
@@ -211,6 +245,8 @@ extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
   p.alpha = a->alpha; p.flags = a->flags; p.bias = a->bias;
   p.resid = a->resid; p.ldr = a->ldr; p.sRb = a->sRb;
   p.pre_out = a->pre_out; p.ldp = a->ldp; p.aux = a->aux; p.ldaux = a->ldaux;
+  p.batch = a->batch; p.ksplit = ksplit; p.ws = a->workspace;
+  p.kchunk = ksplit > 1 ? (((a->K + ksplit - 1) / ksplit + BK - 1) / BK) * BK : a->K;
 
   // prefer the k-contiguous reading when a dimension of extent-1 stride is ambiguous
   const bool AKC = akc, BKC = bkc;
@@ -223,6 +259,29 @@ extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
   else if (AKC && !BKC) launch1<true, false>(p, a->batch, vec, bf16, st);
   else if (!AKC && BKC) launch1<false, true>(p, a->batch, vec, bf16, st);
   else launch1<false, false>(p, a->batch, vec, bf16, st);
+  if (ksplit > 1) {
+    const long long total = (long long)a->M * a->N * a->batch;
+    const unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3(nb), dim3(256), 0, st, p);
+  }
   MCL_CHECK_LAUNCH();
   return MCL_OK;
+}
+
+// K slices that bring a skinny problem (the spot path: M = batch of 128 spots) to >= ~256 workgroups: a 64 x 64 tile
+// over K = 1000 is a chain of 500 dependent fp32 MFMAs (13 us) however few tiles there are.  1 = do not split.
+extern "C" int32_t mcl_gemm_auto_ksplit(int32_t M, int32_t N, int32_t K, int32_t batch) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 1;
+  const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+  if (tiles >= 128 || K < 256) return 1;
+  long long ks = 256 / tiles;
+  if (ks > K / 128) ks = K / 128;
+  if (ks > 8) ks = 8;
+  if (ks * batch > 65535) ks = 65535 / batch;
+  return ks < 1 ? 1 : (int32_t)ks;
+}
+
+extern "C" int64_t mcl_gemm_workspace_floats(int32_t M, int32_t N, int32_t batch, int32_t ksplit) {
+  if (M <= 0 || N <= 0 || batch <= 0) return -1;
+  return ksplit > 1 ? (int64_t)ksplit * batch * M * N : 0;
 }

@@ -63,6 +63,9 @@ def _p(t: Optional[Tensor]) -> Optional[int]:
 
 
 # --------------------------------------------------------------------------- GEMM
+SPLIT_K = os.environ.get("MCL_GEMM_SPLITK", "1") != "0"     # A/B switch for the split-K path of mcl_gemm
+
+
 def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, sAb: int, B: Tensor, sBk: int,
              sBn: int, sBb: int, Cmat: Tensor, ldc: int, sCb: int, alpha: float = 1.0, flags: int = 0,
              bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0, sRb: int = 0,
@@ -80,6 +83,10 @@ def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, 
     a.pre_out, a.ldp = _p(pre_out), ldp
     a.aux, a.ldaux = _p(aux), ldaux
     a.compute = _compute_mode if compute is None else compute
+    ks = _lib.lib().mcl_gemm_auto_ksplit(M, N, K, batch) if SPLIT_K else 1
+    if ks > 1:    # skinny problem (M = a batch of spots): K slices + fixed-order merge fill the chip
+        ws = torch.empty(ks * batch * M * N, device=Cmat.device, dtype=torch.float32)
+        a.ksplit, a.workspace = ks, ws.data_ptr()
     check(_lib.lib().mcl_gemm(C.byref(a), _stream()), "mcl_gemm")
 
 
@@ -117,12 +124,26 @@ def linear_bwd_data(dy: Tensor, W: Tensor, gelu_bwd_aux: Optional[Tensor] = None
     return dx
 
 
-def linear_bwd_weight(dy: Tensor, x: Tensor) -> Tensor:
-    """dW = dy^T x  (N, K)."""
+# When a weight already owns a dense fp32 .grad (FusedAdam's flat bucket, zeroed every step) its gradient GEMM adds
+# straight into it and autograd gets None: no temporary, no AccumulateGrad add kernel (12 of them per spot-path step).
+DIRECT_PARAM_GRADS = os.environ.get("MCL_DIRECT_GRADS", "1") != "0"
+
+
+def _direct_grad_ok(p) -> bool:
+    g = getattr(p, "grad", None)
+    return (DIRECT_PARAM_GRADS and g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape
+            and g.is_contiguous() and p.is_contiguous() and not g.requires_grad)
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor, param: Optional[Tensor] = None) -> Optional[Tensor]:
+    """dW = dy^T x  (N, K); with ``param`` (the weight Parameter) owning a dense .grad: param.grad += dW, returns None."""
     dy, x = _rowmajor(dy, "dy"), _rowmajor(x, "x")
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M
+    if param is not None and param.shape == (N, K) and _direct_grad_ok(param):
+        gemm_raw(N, K, M, 1, dy, 1, dy.stride(0), 0, x, x.stride(0), 1, 0, param.grad, K, 0, flags=EPI_ACCUM)
+        return None
     dW = torch.empty((N, K), device=dy.device, dtype=torch.float32)
     gemm_raw(N, K, M, 1, dy, 1, dy.stride(0), 0, x, x.stride(0), 1, 0, dW, K, 0)
     return dW
@@ -241,6 +262,7 @@ class AttnBlockFn(torch.autograd.Function):
         x2, _ = linear_fwd(h, w2, b2, resid=x1)
         ctx.save_for_backward(x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h)
         ctx.heads, ctx.dim_head = heads, dim_head
+        ctx.wparams = (wqkv, wo, w1, w2)   # the Parameter objects themselves: their .grad may be written directly
         return x2
 
     @staticmethod
@@ -248,19 +270,20 @@ class AttnBlockFn(torch.autograd.Function):
         (x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h) = ctx.saved_tensors
         dx2 = _rowmajor(dx2, "dx2")
         # ff: x2 = h W2^T + b2 + x1
-        dw2 = linear_bwd_weight(dx2, h)
+        p_qkv, p_o, p_1, p_2 = ctx.wparams
+        dw2 = linear_bwd_weight(dx2, h, p_2)
         db2 = colsum(dx2)
         dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
-        dw1 = linear_bwd_weight(dpre, u2)
+        dw1 = linear_bwd_weight(dpre, u2, p_1)
         db1 = colsum(dpre)
         du2 = linear_bwd_data(dpre, w1)
         dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2)
         # attn: x1 = o Wo^T + bo + x
-        dwo = linear_bwd_weight(dx1, o)
+        dwo = linear_bwd_weight(dx1, o, p_o)
         dbo = colsum(dx1)
         do = linear_bwd_data(dx1, wo)
         dqkv = attention_core_bwd(do, qkv, P, ctx.heads, ctx.dim_head)
-        dwqkv = linear_bwd_weight(dqkv, u1)
+        dwqkv = linear_bwd_weight(dqkv, u1, p_qkv)
         du1 = linear_bwd_data(dqkv, wqkv)
         dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1)
         return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None
@@ -277,16 +300,17 @@ class ProjectionHeadFn(torch.autograd.Function):
         z, _ = linear_fwd(a, wf, bf, resid=p)
         e, mean, rstd = layernorm_fwd(z, g, be)
         ctx.save_for_backward(x, wp, wf, g, p, a, z, mean, rstd)
+        ctx.wparams = (wp, wf)
         return e
 
     @staticmethod
     def backward(ctx, de):
         x, wp, wf, g, p, a, z, mean, rstd = ctx.saved_tensors
         dz, dg, dbe = layernorm_bwd(_rowmajor(de, "de"), z, g, mean, rstd)
-        dwf = linear_bwd_weight(dz, a)
+        dwf = linear_bwd_weight(dz, a, ctx.wparams[1])
         dbf = colsum(dz)
         dp = linear_bwd_data(dz, wf, gelu_bwd_aux=p, resid=dz)
-        dwp = linear_bwd_weight(dp, x)
+        dwp = linear_bwd_weight(dp, x, ctx.wparams[0])
         dbp = colsum(dp)
         dx = linear_bwd_data(dp, wp) if ctx.needs_input_grad[0] else None
         return dx, dwp, dbp, dwf, dbf, dg, dbe

@@ -64,6 +64,37 @@ def test_gemm_epilogues(ops):
     assert_close_scaled(y2.cpu(), 0.25 * (x.double() @ W.double().t()), 2e-6, what="alpha, no bias")
 
 
+def test_gemm_splitk_matches_one_pass_and_is_deterministic(ops):
+    """Skinny problems (M = a batch of spots) run as K slices + a fixed-order merge with the epilogue."""
+    from mclstexp_amd import _lib
+    from oracle import ref_cpu
+    L = _lib.lib()
+    M, N, K = 128, 1536, 1000
+    assert L.mcl_gemm_auto_ksplit(M, N, K, 1) > 1 and L.mcl_gemm_auto_ksplit(4096, 4096, 1000, 1) == 1
+    assert L.mcl_gemm_workspace_floats(M, N, 1, 5) == 5 * M * N
+    x, W, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K)), _rand(N, seed=3), _rand(M, N, seed=5)
+    xd, Wd, bd, rd = x.to(DEV), W.to(DEV), b.to(DEV), r.to(DEV)
+    outs = []
+    for split in (True, False, True):
+        ops.SPLIT_K = split
+        try:
+            outs.append(ops.linear_fwd(xd, Wd, bd, gelu=True, save_pre=True, resid=rd))
+        finally:
+            ops.SPLIT_K = True
+    (y_s, pre_s), (y_1, pre_1), (y_s2, pre_s2) = outs
+    assert torch.equal(y_s, y_s2) and torch.equal(pre_s, pre_s2)                 # run-to-run bit-identical
+    pre_ref = x.double() @ W.double().t() + b.double()
+    assert_close_scaled(pre_s.cpu(), pre_ref, 2e-6, what="split-K pre-activation")
+    assert_close_scaled(y_s.cpu(), ref_cpu.gelu_erf(pre_ref) + r.double(), 2e-6, what="split-K gelu + resid")
+    assert_close_scaled(y_s.cpu(), y_1.cpu().double(), 1e-6, what="split-K vs one pass")
+    # ragged K slices and a batched problem (batch * ksplit workgroup layers)
+    A3, B3 = _rand(3, 40, 500, seed=6).to(DEV), _rand(3, 500, 70, seed=7).to(DEV)
+    C3 = torch.empty(3, 40, 70, device=DEV)
+    ops.gemm_raw(40, 70, 500, 3, A3, 500, 1, 40 * 500, B3, 70, 1, 500 * 70, C3, 70, 40 * 70)
+    assert L.mcl_gemm_auto_ksplit(40, 70, 500, 3) > 1
+    assert_close_scaled(C3.cpu(), A3.cpu().double() @ B3.cpu().double(), 2e-6, what="batched split-K")
+
+
 def test_gemm_unaligned_views(ops):
     """Operands that are strided views (q/k/v slices of qkv) and 4-byte-aligned-only bases."""
     B, H, d = 19, 3, 64
