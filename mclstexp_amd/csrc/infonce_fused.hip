@@ -289,7 +289,9 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
   for (int s = 0; s < 4; ++s) f[s] = ld_a(lds, a1, CB0 + (s & 1), s >> 1);
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-#ifdef MCL_EXP_HALF_LDS_A   // timing experiment only (wrong results): half the phase-A LDS traffic
+#ifdef MCL_EXP_NO_LDS_A
+    if (s + 4 < 32) f[s + 4] = f[s];
+#elif defined(MCL_EXP_HALF_LDS_A)   // timing experiment only (wrong results): half the phase-A LDS traffic
     if (s + 4 < 32) {
       if (s & 1) f[s + 4] = f[s + 3];
       else f[s + 4] = ld_a(lds, a1, CB0 + ((s + 4) & 1), (s + 4) >> 1);
@@ -304,6 +306,7 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
       if (BWD) {
         eg.step(s, ECB, c, TE0, TE1, e_col0, e_dcol, wE0, wE1);
       } else {
+#ifndef MCL_EXP_NOSTAT
         const int i = s & 15;
         if (s < 16) {
           s0.step(c, TE0, ECB, i, e_col0, run_m);
@@ -312,6 +315,9 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
           s1.step(c, TE1, ECB + 1, i, e_col0, run_m);
           if (i == 15) s1.finish(run_m, run_l);
         }
+#else
+        if (s == 31) run_l += TE0[3] + TE1[5];   // keep the logits alive
+#endif
       }
     }
     if (BWD && PF0 >= 0 && s == 16) eg.load_cl(eg.cl0, lds, cls_off, PF0, c.h);
