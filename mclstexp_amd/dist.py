@@ -48,6 +48,11 @@ def init_from_env() -> Tuple[Optional[td.ProcessGroup], int, int]:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+        # single node over the loopback rendezvous: the container's hostname may not resolve, so do not let gloo (size
+        # exchange of ragged shards) or the RCCL bootstrap pick an interface by hostname
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     if not td.is_initialized():
         backend = os.environ.get("MCL_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
