@@ -126,6 +126,9 @@ def cpu_baseline(args, budget_s: float):
                 "sample": f"cpu baseline exceeded its {limit:.0f} s wall-clock limit"}
 
 
+_RESULT_FD = 1
+
+
 def log(msg: str) -> None:
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -222,6 +225,12 @@ def main():
     if args.launch_check:
         return launch_check()
 
+    # stdout carries exactly ONE line, the JSON result: libraries that print from C (RCCL's version banner at
+    # communicator creation) are pointed at stderr for the whole run; the result goes out through the saved descriptor
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     from mclstexp_amd import dist as mdist
     pg, rank, world = mdist.init_from_env()
     if not torch.cuda.is_available():
@@ -341,7 +350,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             log("gpu done: %.2f ms/step; timing the CPU oracle baseline" % out["ms_per_step"])
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_budget_s)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(_RESULT_FD, (json.dumps(out) + "\n").encode())
     mdist.shutdown()
 
 
