@@ -20,6 +20,7 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -215,7 +216,7 @@ class _ContrastiveBase(nn.Module):
     # backward) shares nothing with the image branch until the loss: run it on a side stream so it overlaps the
     # DenseNet kernels.  Autograd replays each branch's backward on the stream its forward ran on, and under HIP-graph
     # capture the fork/join becomes a parallel branch of both graphs.
-    overlap_branches = True
+    overlap_branches = os.environ.get("MCL_OVERLAP_BRANCHES", "1") != "0"
     _branch_streams: Dict[int, "torch.cuda.Stream"] = {}
 
     def _branch_stream(self, device) -> Optional["torch.cuda.Stream"]:
