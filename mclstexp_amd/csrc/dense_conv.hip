@@ -727,6 +727,181 @@ extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z
   return MCL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round-2 form of the 3x3 weight gradient ("one kernel row per workgroup"), deterministic.
+//
+// The slab kernel above stages 128 + 2W + 2 rows of z per 128-pixel tile (1.9x the tile at W = 56) synchronously,
+// selects a zero row per (pixel, tap) with ~8 VALU per MFMA, and leaves 147 KB of fp32 partials per workgroup for the
+// merge (75 MB at 512 workgroups): with staging AND masks compiled out it still needed 69 us in block 1 where the MFMAs
+// need 12.  Here a workgroup owns ONE kernel row ky (3 taps, 384 of the 1152 columns) of a strided set of pixel tiles:
+//   * the z rows a tile needs for its three kx taps are the 130 consecutive pixels [p0 + (ky-1)W - 1, +130): no halo;
+//   * border handling moves to the OTHER operand: dy is staged three times (8 KB each), each copy zeroed where the
+//     pixel's (ky, kx) neighbour leaves the image -- the MFMA loop has no masks and no address selects at all;
+//   * the next tile's raw rows are fetched into registers while the current tile is multiplied;
+//   * the three ky workgroups of a pixel group run next to each other on one XCD (z is re-read from that L2) and write
+//     disjoint column ranges of ONE 32 x 1152 partial: a third of the partial traffic per pixel group.
+// Wave w owns input channels 32w..32w+31 of all three taps (48 accumulator registers).
+constexpr int W3K_ROWS = T3 + 2;                         // staged z rows per tile
+constexpr int W3K_LDS = W3K_ROWS * 256 + 3 * T3 * 64;    // z tile + three masked dy tiles = 57,856 B: two per CU
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __restrict__ dy, long long lddy,
+                                                                const bf16_t* __restrict__ z, long long S, int H, int W,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, int ntile, int G,
+                                                                float* __restrict__ wpart) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[W3K_LDS];
+  typedef short v4s __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  // XCD-aware decode (block id % 8 = XCD): the three kernel rows of one pixel group sit in consecutive slots of one XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ky = slot % 3, g = (slot / 3) * 8 + xcd;
+  if (g >= G) return;
+  unsigned char* zt = lds;                               // [130][128 ch] bf16, 256-byte rows, chunk ^ (row & 15)
+  unsigned char* dyt = lds + W3K_ROWS * 256;             // [3 kx][128][32] bf16, 64-byte rows, chunk ^ ((row >> 1) & 3)
+  const int Si = (int)S;
+
+  const int cc = tid & 15, rz = tid >> 4;                // z staging: chunk, first row (rows rz + 16 i, i < 9)
+  const int rd = tid >> 1, cd = (tid & 1) * 2;           // dy staging: pixel row, first of two chunks
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cc * 8 + i;
+    sc[i] = gamma[c] * rstd[c];
+    sh[i] = fmaf(-mean[c], sc[i], beta[c]);
+  }
+  f32x16 acc[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+
+  // transposing-read lane geometry (as in conv3x3_wrw_kernel): lane i = lane & 15 supplies pixel row (i >> 2) [+4 for the
+  // second read] of the 8-pixel k-group 8h, 4 channels at (i & 3)*4 of the 16-channel half (lane >> 4) & 1
+  const int i15 = lane & 15, q = i15 >> 2, jj = i15 & 3;
+  const int half16 = 16 * ((lane >> 4) & 1);
+  const int byte = (jj & 1) * 8;
+  int bz_lo[3], bz_hi[3];                                // z-tile read offsets per kx (+ 4096 per 16-pixel k-step)
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int chunk = wave * 4 + ((half16 + jj * 4) >> 3);
+    const int r0 = 8 * h + q + kx, r1 = r0 + 4;
+    bz_lo[kx] = r0 * 256 + ((chunk ^ (r0 & 15)) << 4) + byte;
+    bz_hi[kx] = r1 * 256 + ((chunk ^ (r1 & 15)) << 4) + byte;
+  }
+  const int dchunk = (half16 + jj * 4) >> 3;
+
+  // raw rows of one tile -> registers (zeros outside [0, S) and for tile >= ntile)
+  auto fetch = [&](uint4 (&zv)[9], uint4 (&dv)[2], int tile) {
+    const int p0 = tile * T3;
+    const int qs = p0 + (ky - 1) * W - 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int j = rz + 16 * i;
+      const int p = qs + j;
+      zv[i] = (tile < ntile && j < W3K_ROWS && p >= 0 && p < Si)
+                  ? *reinterpret_cast<const uint4*>(z + (long long)p * C3_IN + cc * 8)
+                  : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int p = p0 + rd;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      dv[u] = (tile < ntile && p < Si) ? *reinterpret_cast<const uint4*>(dy + (long long)p * lddy + (cd + u) * 8)
+                                       : make_uint4(0u, 0u, 0u, 0u);
+  };
+  // registers -> LDS: BN+ReLU on z, three border-masked copies of dy
+  auto stage = [&](const uint4 (&zv)[9], const uint4 (&dv)[2], int tile) {
+    const int p0 = tile * T3;
+    const int qs = p0 + (ky - 1) * W - 1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int j = rz + 16 * i;
+      if (j < W3K_ROWS) {
+        const int p = qs + j;
+        const bool ok = p >= 0 && p < Si;                // (rows outside the tensor: exact zeros, not relu(shift))
+        *reinterpret_cast<uint4*>(zt + j * 256 + ((cc ^ (j & 15)) << 4)) =
+            ok ? bn_relu_chunk(zv[i], sc, sh) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    const int p = p0 + rd;
+    const int x = p % W, y = (p / W) % H;
+    const bool vy = (unsigned)(y + ky - 1) < (unsigned)H && p < Si;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const bool v = vy && (unsigned)(x + kx - 1) < (unsigned)W;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        *reinterpret_cast<uint4*>(dyt + kx * (T3 * 64) + rd * 64 + (((cd + u) ^ ((rd >> 1) & 3)) << 4)) =
+            v ? dv[u] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto multiply = [&]() {
+#pragma unroll 2
+    for (int ks = 0; ks < 8; ++ks) {                     // 16 pixels per step
+      const int r_lo = ks * 16 + 8 * h + q, r_hi = r_lo + 4;
+      const int da_lo = r_lo * 64 + ((dchunk ^ ((r_lo >> 1) & 3)) << 4) + byte;
+      const int da_hi = r_hi * 64 + ((dchunk ^ ((r_hi >> 1) & 3)) << 4) + byte;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const v4s alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(dyt + kx * (T3 * 64) + da_lo));
+        const v4s ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(dyt + kx * (T3 * 64) + da_hi));
+        const v4s blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(zt + bz_lo[kx] + ks * 4096));
+        const v4s bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(zt + bz_hi[kx] + ks * 4096));
+        bf16x8 fa, fb;
+        fa[0] = alo[0]; fa[1] = alo[1]; fa[2] = alo[2]; fa[3] = alo[3];
+        fa[4] = ahi[0]; fa[5] = ahi[1]; fa[6] = ahi[2]; fa[7] = ahi[3];
+        fb[0] = blo[0]; fb[1] = blo[1]; fb[2] = blo[2]; fb[3] = blo[3];
+        fb[4] = bhi[0]; fb[5] = bhi[1]; fb[6] = bhi[2]; fb[7] = bhi[3];
+        acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[kx], 0, 0, 0);
+      }
+    }
+  };
+
+  // A pixel group owns CONSECUTIVE tiles: kernel row ky of tile t+1 re-reads most of what row ky+1 read for tile t, and
+  // both workgroups sit on this XCD's L2.  Global loads run TWO tiles ahead in two register sets: one tile of work
+  // (~2 us) does not cover a miss to HBM, and the loop was latency-bound at ~6 us per tile with one set.
+  const int per = (ntile + G - 1) / G;
+  const int t_end = min(ntile, (g + 1) * per);
+  uint4 zvA[9], dvA[2], zvB[9], dvB[2];
+  int tile = g * per;
+  fetch(zvA, dvA, tile < t_end ? tile : ntile);
+  fetch(zvB, dvB, tile + 1 < t_end ? tile + 1 : ntile);
+  for (; tile < t_end; tile += 2) {
+    __syncthreads();                                     // the previous tile's MFMAs are done with the LDS tiles
+    stage(zvA, dvA, tile);
+    __syncthreads();
+    fetch(zvA, dvA, tile + 2 < t_end ? tile + 2 : ntile);
+    multiply();
+    if (tile + 1 < t_end) {
+      __syncthreads();
+      stage(zvB, dvB, tile + 1);
+      __syncthreads();
+      fetch(zvB, dvB, tile + 3 < t_end ? tile + 3 : ntile);
+      multiply();
+    }
+  }
+  // acc[kx][r]: co = (r&3) + 8*(r>>2) + 4*h, column (3 ky + kx)*128 + 32 wave + l31 of the 1152-wide row of partial g
+  float* dst = wpart + (long long)g * (C3_OUT * 9 * C3_IN);
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int n = (3 * ky + kx) * C3_IN + 32 * wave + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[co * (9 * C3_IN) + n] = acc[kx][r];
+    }
+  }
+}
+
+// pixel groups (= partials) of the kernel-row form: three workgroups each, two workgroups per CU
+static inline int wrw3k_groups(int ntile) { return ntile < 176 ? ntile : 176; }
+
 // Deterministic form: per-workgroup fp32 partials (32 x 1152 each) in the workspace + a fixed-order merge launch.
 static inline int wrw3_grid(int64_t S, int ntile) {
   // Two workgroups per CU on the large maps: the kernel stages each slab synchronously, so a second resident
@@ -738,7 +913,9 @@ static inline int wrw3_grid(int64_t S, int ntile) {
 
 extern "C" int64_t mcl_dense_conv3x3_wrw_workspace_floats(int64_t S) {
   if (S <= 0) return -1;
-  return (int64_t)wrw3_grid(S, (int)((S + T3 - 1) / T3)) * (C3_OUT * 9 * C3_IN);
+  const int ntile = (int)((S + T3 - 1) / T3);
+  const int slabs = wrw3_grid(S, ntile) > wrw3k_groups(ntile) ? wrw3_grid(S, ntile) : wrw3k_groups(ntile);
+  return (int64_t)slabs * (C3_OUT * 9 * C3_IN);
 }
 
 extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
@@ -751,6 +928,21 @@ extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const voi
       (reinterpret_cast<uintptr_t>(workspace) & 15u))
     return MCL_EUNSUPPORTED;
   const int ntile = (int)((S + T3 - 1) / T3);
+  hipStream_t st = mcl_stream(stream);
+  // kernel-row form on the 28 x 28 and smaller maps (kernel time 26.5 / 16.5 / 10 us vs 50 / 36 / 20 for the slab form);
+  // on the 56 x 56 maps its twelve LDS fragment reads per three MFMAs lose to the slab form's shared dy fragment
+  // (115 vs 85 us): MCL_WRW3_SLAB=1 / =0 force one form for A/B runs
+  static const char* e_form = getenv("MCL_WRW3_SLAB");
+  const bool slab = e_form ? e_form[0] == '1' : S >= 200000;
+  if (!slab) {
+    const int G = wrw3k_groups(ntile);
+    const int nblk = ((G + 7) / 8) * 8 * 3;
+    hipLaunchKernelGGL(conv3x3_wrw_ky_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (long long)lddy,
+                       (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, ntile, G, workspace);
+    mcl_launch_wrw_merge(workspace, G, (long long)C3_OUT * 9 * C3_IN, dW, accumulate_w, st);
+    MCL_CHECK_LAUNCH();
+    return MCL_OK;
+  }
   const size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256 + T3 * 64 + (T3 + 2 * W + 2) * 2 + 64;
   static bool attr_set = false;
   if (!attr_set) {
@@ -759,7 +951,6 @@ extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const voi
     attr_set = true;
   }
   const int grid = wrw3_grid(S, ntile);
-  hipStream_t st = mcl_stream(stream);
   hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)dy, (long long)lddy,
                      (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile, workspace);
   mcl_launch_wrw_merge(workspace, grid, (long long)C3_OUT * 9 * C3_IN, dW, accumulate_w, st);
