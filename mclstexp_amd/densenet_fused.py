@@ -1023,6 +1023,10 @@ class TransitionFn(torch.autograd.Function):
         return dx, (None if direct else dg), (None if direct else db), gw, None
 
 
+# dense block index -> callable invoked on the main stream right after that block's forward has been enqueued
+FORWARD_BLOCK_HOOKS: dict = {}
+
+
 def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
     """Train-mode forward of torchvision-layout DenseNet ``features`` (conv0 ... norm5), returning the
     (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly)."""
@@ -1054,6 +1058,9 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     next_stats = None
     while hasattr(features, f"denseblock{i}"):
         buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec, next_stats)
+        hook = FORWARD_BLOCK_HOOKS.get(i)
+        if hook is not None:
+            hook()                                            # e.g. an event other streams wait for (model.embed)
         next_stats = None
         n = buf.shape[0] * buf.shape[2] * buf.shape[3]
         if hasattr(features, f"transition{i}"):

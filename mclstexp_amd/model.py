@@ -222,6 +222,15 @@ class _ContrastiveBase(nn.Module):
     def _branch_stream(self, device) -> Optional["torch.cuda.Stream"]:
         if not (self.overlap_branches and device.type == "cuda"):
             return None
+        if (os.environ.get("MCL_SHARED_SIDE", "1") != "0" and self.fused_backbone
+                and isinstance(getattr(self, "image_encoder", None), backbones.ImageEncoder)
+                and self.backbone_dtype == torch.bfloat16):
+            # ONE side stream for everything off the critical chain.  A replayed graph runs on two hardware queues here:
+            # during the backward they are the main chain and the backbone's weight-gradient stream, and a third branch
+            # is multiplexed onto the MAIN one (a pure delay in the spot backward showed up 1:1 in the step time).  On
+            # the weight-gradient stream -- ahead of that work, see embed() -- the spot backward rides in its slack.
+            from . import densenet_fused
+            return densenet_fused._side_stream(device)
         s = _ContrastiveBase._branch_streams.get(device.index)
         if s is None:
             s = torch.cuda.Stream(device=device)
@@ -376,6 +385,26 @@ class mclSTExp_Attention(_ContrastiveBase):
     def embed(self, batch):
         ops.set_compute(self.compute)
         side = self._branch_stream(batch["expression"].device)
+        late = int(os.environ.get("MCL_SPOT_AFTER_BLOCK", "2"))
+        if (side is not None and late > 0 and self.fused_backbone and isinstance(self.image_encoder, backbones.ImageEncoder)
+                and self.backbone_dtype == torch.bfloat16):
+            # The spot branch starts when the DenseNet has finished dense block `late`: the first two blocks (56 x 56 and
+            # 28 x 28 maps) are throughput-bound, anything running beside them costs its full duration; the
+            # later blocks are latency-bound chains with idle CUs.
+            from . import densenet_fused
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            densenet_fused.FORWARD_BLOCK_HOOKS[late] = lambda: ev.record(main)
+            try:
+                image_features = self._encode_image(self.image_encoder, batch["image"])
+            finally:
+                densenet_fused.FORWARD_BLOCK_HOOKS.pop(late, None)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                spot_embeddings = self._embed_spots(batch)
+            image_embeddings = self.image_projection(image_features)
+            main.wait_stream(side)
+            return spot_embeddings, image_embeddings
         if side is not None:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
