@@ -71,7 +71,7 @@ def _adam(a):                   # (p, g, m, v, n, ...): read p, g, m, v; write p
 
 TABLE = {
     "mcl_conv1x1_wrw_det": {"kernels": "wrw_partial_kernel + wrw_merge_kernel", "bytes": _conv1x1_wrw_det},
-    "mcl_dense_conv3x3_wrw_det": {"kernels": "conv3x3_wrw_kernel + wrw_merge_kernel", "bytes": _conv3x3_wrw_det},
+    "mcl_dense_conv3x3_wrw_det": {"kernels": "conv3x3_wrw_kernel (56x56 maps) / conv3x3_wrw_ky_kernel + wrw_merge_kernel", "bytes": _conv3x3_wrw_det},
     "mcl_dense_bn1_wrw": {"kernels": "wrw_partial_kernel<Gram> + wrw_merge_kernel", "bytes": _bn1_wrw},
     "mcl_dense_bn1_dx": {"kernels": "bn1_bwd_kernel<1>", "bytes": _bn1_dx},
     "mcl_conv1x1_wrw_bf16": {"kernels": "conv1x1_wrw_kernel (atomics, A/B only)", "bytes": _conv1x1_wrw},

@@ -19,7 +19,7 @@ UNITS = {   # ABI unit -> [(kernel substring, launches of it per unit call)]
     "mcl_dense_conv1x1_fwd": [("conv1x1_fwd_kernel", 1)],
     "mcl_dense_conv3x3_fwd": [("conv3x3_fwd_kernel", 1)],
     "mcl_conv1x1_wrw_det": [("wrw_partial_kernel", 1)],
-    "mcl_dense_conv3x3_wrw_det": [("conv3x3_wrw_kernel", 1)],
+    "mcl_dense_conv3x3_wrw_det": [("conv3x3_wrw_k", 1)],      # slab form + kernel-row form (launch-weighted)
     "mcl_adam_table_step_dev": [("adam_table_kernel", 1)],
     "mcl_adam_step_dev": [("adam_kernel(", 1)],
 }

@@ -1,0 +1,29 @@
+# Profiles of the shipped configuration at HEAD -> gpurun_out/head_* (copied into profiles/r02_* afterwards)
+mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
+cd /tmp
+B="python3 $R/bench.py --no_cpu_baseline --profile_steps 0"
+# 1. PMC passes (separate, counters only)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/hp/fetch -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/hp/write -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+# 2. kernel traces: shipped configuration, and every kernel alone (no side streams)
+rocprofv3 --kernel-trace -d $R/gpurun_out/hp/kt -o kt -- $B --steps 12 --warmup 4 > /dev/null 2>&1
+MCL_SIDE_STREAM=0 MCL_OVERLAP_BRANCHES=0 rocprofv3 --kernel-trace -d $R/gpurun_out/hp/ks -o ks -- $B --steps 12 --warmup 4 > /dev/null 2>&1
+cd $R
+python tools/make_traffic_json.py gpurun_out/hp/fetch gpurun_out/hp/write gpurun_out/head_kernel_traffic.json gpurun_out/head_pmc_hbm_traffic.txt > /dev/null
+cp gpurun_out/head_kernel_traffic.json profiles/kernel_traffic.json
+python tools/rocpd_stats.py $(find gpurun_out/hp/kt -name "*.db" | head -1) gpurun_out/head_kernel_stats.csv --steady 8
+python tools/rocpd_stats.py $(find gpurun_out/hp/ks -name "*.db" | head -1) gpurun_out/head_kernel_stats_serial.csv --steady 8
+python tools/trace_gaps.py $(find gpurun_out/hp/kt -name "*.db" | head -1) --steady 6 > gpurun_out/head_gpu_idle_gaps.txt
+rm -rf gpurun_out/hp
+# 3. the bench line itself (with the traffic file just produced and the CPU baseline), and the no-overlap wall times
+python bench.py --steps 100 --warmup 20 > gpurun_out/head_bench.json 2> gpurun_out/head_bench.err
+cut -c1-400 gpurun_out/head_bench.json
+for v in "0 0" "1 0"; do set -- $v; MCL_SIDE_STREAM=$1 MCL_OVERLAP_BRANCHES=$2 python bench.py --steps 60 --warmup 10 --no_cpu_baseline --profile_steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('side=$1 overlap=$2', d['ms_per_step'])"; done > gpurun_out/head_overlap_modes.txt
+cat gpurun_out/head_overlap_modes.txt
+# 4. micro-benchmarks
+python tools/bench_infonce.py --unfused > gpurun_out/head_infonce.jsonl 2>/dev/null
+python tools/bench_dense_layer.py --json gpurun_out/head_dense.jsonl > /dev/null 2>&1
+python tools/bench_gemm_bf16.py > gpurun_out/head_gemm.jsonl 2>/dev/null
+python tools/bench_spot_path.py > gpurun_out/head_spot.json 2>/dev/null
+bash tools/run_other_configs.sh > /dev/null 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
