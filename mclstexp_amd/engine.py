@@ -79,6 +79,14 @@ class TrainStep:
             # one process, no collectives: forward, InfoNCE (closed-form forward + backward) and backward replay as ONE
             # graph -- no host round trip between the three phases (the eager InfoNCE launches left the GPU idle
             # while the second graph was being submitted)
+            # the optimizer is part of this graph: the position tables may be updated from inside the backward (side stream,
+            # under the latency-bound blocks of the backbone) -- armed for the capture only, see FusedAdam.attach_model
+            sink = getattr(m, "sparse_grads", None)
+            early = (self.opt_will_be_in_graph() and sink is not None and hasattr(self.opt, "_early_tables")
+                     and getattr(m, "embedding_grad", "dense") == "rowsparse" and "hook" not in sink
+                     and os.environ.get("MCL_EARLY_TABLES", "1") != "0")
+            if early:
+                sink["hook"] = self.opt._early_tables
             with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
                 self.es, self.ei = m.embed(self.static_in)
                 self.loss, d_es, d_ei = m.loss_and_grads(self.es, self.ei)
@@ -92,6 +100,8 @@ class TrainStep:
                 if self.opt_in_graph:
                     self.opt.step()
                     self.opt._step_count -= 1    # capture records launches, it does not run them: the replay counts
+            if early:
+                sink.pop("hook", None)           # eager backward calls (ragged batches) keep the plain semantics
             torch.cuda.synchronize()
             return
         # two graphs with eager work between them: the early position-table update (a hook inside backward that also
@@ -109,6 +119,9 @@ class TrainStep:
         if getattr(m, "embedding_grad", "dense") == "rowsparse":
             m.sparse_grads["static"] = True
         torch.cuda.synchronize()
+
+    def opt_will_be_in_graph(self) -> bool:
+        return hasattr(self.opt, "_begin_step") and os.environ.get("MCL_OPT_IN_GRAPH", "1") != "0"
 
     def _eager_ragged(self, batch) -> Tensor:
         """A batch whose shapes differ from the captured ones (ragged last batch: train.py:49 has no drop_last) runs

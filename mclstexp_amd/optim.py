@@ -53,12 +53,12 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 self._group_of[id(p)] = gi
-        # Optional (MCL_EARLY_TABLES=1), single process: update the position tables as soon as their gradient rows exist
-        # -- from inside PosEmbedAddFn.backward, i.e. on the spot-branch stream while the image backbone's backward is
-        # still running on the main stream.  Measured on configs[1] (A/B on one box): 15.00 vs 15.02 ms/step -- the
-        # 16 K streaming workgroups compete with the latency-bound backward chain for CU slots and give back what the
-        # overlap gains -- so it is off by default.  Data parallel always updates in step() (gathered rows of every rank).
-        if self._sink is not None and self.process_group is None and os.environ.get("MCL_EARLY_TABLES", "0") != "0":
+        # The position tables can be updated as soon as their gradient rows exist -- from inside PosEmbedAddFn.backward, on
+        # the side stream, under the latency-bound part of the image backbone's backward -- instead of in step().  That
+        # changes what a bare ``loss.backward()`` does, so it is engine.TrainStep that switches it on, only while it captures
+        # its single step graph (a backward that is always followed by step()); MCL_EARLY_TABLES=always forces it for every
+        # backward of an attached model.  Data parallel always updates in step() (gathered rows of every rank).
+        if self._sink is not None and self.process_group is None and os.environ.get("MCL_EARLY_TABLES", "0") == "always":
             self._sink["hook"] = self._early_tables
         # load_state_dict() into a live model rewrites the flat fp32 buffer behind the bf16 shadows' back (captured
         # HIP graphs read the shadows directly, so the lazy per-parameter check in shadow() cannot catch that case)
