@@ -282,11 +282,13 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
 
 
 # Deterministic fusion of the bottleneck weight gradient with the BatchNorm-backward reduction (csrc/wrw_fused.hip): one
-# pass over (dz, x) replaces conv1x1_wrw (fp32 atomics) + the reduce launch + its finalize; then the dx pass alone.
-# Measured (profiles/r02_*): the Gram fusion does the least total work but it puts the weight gradient ON the critical
-# chain of the backward; with the side stream idle-capable, the shorter chain (reduce + finalize + dx on the main stream,
-# atomics-free weight gradients beside it) wins: 14.87 vs 15.08 ms/step.  Default off; MCL_FUSED_BN1_WRW=1 selects it.
-USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "0") != "0"
+# pass over (dz, x) replaces conv1x1_wrw + the reduce launch + its finalize; then the dx pass alone.  It does the least
+# total work but puts the weight gradient ON the critical chain of the backward.  Where the side stream hides the weight
+# gradients (14 x 14 and 7 x 7 maps, mostly 28 x 28) the shorter chain wins; on the 56 x 56 maps both lanes are
+# throughput-bound, the side work costs its full duration anyway, and saving one pass over (dz, x) per layer wins:
+# fused from 200 000 pixels up 14.08 / 14.12 ms/step, from 50 000 up 14.15, never 14.28 / 14.36 (interleaved A/B).
+USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "1") != "0"
+FUSED_BN1_WRW_MIN_PIXELS = int(os.environ.get("MCL_FUSED_BN1_WRW_MIN_PIXELS", "200000"))
 
 
 def _bn1_wrw_ok(w_param: Tensor) -> bool:
@@ -639,7 +641,7 @@ class DenseBlockFn(torch.autograd.Function):
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 ev = torch.cuda.Event()
                 ev.record(main)
-                fused_wrw = _bn1_wrw_ok(w1)
+                fused_wrw = _bn1_wrw_ok(w1) and dz.shape[0] * dz.shape[2] * dz.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS
                 if fused_wrw:
                     # the bottleneck weight gradient rides on the BatchNorm-backward reduction (one pass over dz, x;
                     # no atomics): it is part of the main chain now, only the 3x3 weight gradient forks off
@@ -685,7 +687,7 @@ class DenseBlockFn(torch.autograd.Function):
                 # fused forward: nothing of norm1's output was kept.  Weight gradient with BN1+ReLU recomputed from the
                 # concat buffer; data gradient + BN1 backward without materialising da
                 bn1 = (g1, b1, stats.mean[:cin], stats.rstd[:cin])
-                if _bn1_wrw_ok(w1):
+                if _bn1_wrw_ok(w1) and dz.shape[0] * dz.shape[2] * dz.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS:
                     dw1 = ("direct", None)
                     dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                                 gbuf[:, :cin], w1, into_param_grads=d1)
