@@ -223,7 +223,7 @@ class _ContrastiveBase(nn.Module):
         if not (self.overlap_branches and device.type == "cuda"):
             return None
         if (os.environ.get("MCL_SHARED_SIDE", "1") != "0" and self.fused_backbone
-                and isinstance(getattr(self, "image_encoder", None), backbones.ImageEncoder)
+                and isinstance(getattr(self, "image_encoder", None), (backbones.ImageEncoder, backbones.ImageEncoder_VIT))
                 and self.backbone_dtype == torch.bfloat16):
             # ONE side stream for everything off the critical chain.  A replayed graph runs on two hardware queues here:
             # during the backward they are the main chain and the backbone's weight-gradient stream, and a third branch

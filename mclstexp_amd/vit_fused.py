@@ -16,6 +16,7 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
 import torch
 
 from . import _lib, ops
@@ -74,6 +75,31 @@ def _grad_target(p: Tensor):
         return p.grad, True, None
     g = torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
     return g, False, g
+
+
+# Weight and bias gradients only feed the optimizer: they run on the side stream (the step's second lane, shared with the
+# spot branch and the DenseNet weight gradients) while the data-gradient chain continues, whenever they accumulate
+# straight into the parameters' .grad (nothing is handed back to autograd from the other stream).
+SIDE_WGRAD = os.environ.get("MCL_VIT_SIDE_WGRAD", "1") != "0"
+
+
+def _param_grads(dy: Tensor, x: Tensor, lin, rows: int, grads: dict) -> None:
+    """grads[lin.weight], grads[lin.bias] for y = x W^T + b given dy; on the side stream when both are written in place."""
+    from . import densenet_fused as dn
+    direct = _grad_target(lin.weight)[1] and (lin.bias is None or _grad_target(lin.bias)[1])
+    if SIDE_WGRAD and dn.USE_SIDE_STREAM and direct:
+        main = torch.cuda.current_stream()
+        side = dn._side_stream(dy.device)
+        side.wait_stream(main)                # dy is final on the main stream
+        with torch.cuda.stream(side):
+            grads[lin.weight] = linear_wgrad(dy, x, lin.weight, rows)
+            if lin.bias is not None:
+                grads[lin.bias] = bias_grad(dy, lin.bias, rows)
+        dn._side_park(dy.device, dy, x)
+        return
+    grads[lin.weight] = linear_wgrad(dy, x, lin.weight, rows)
+    if lin.bias is not None:
+        grads[lin.bias] = bias_grad(dy, lin.bias, rows)
 
 
 def linear_wgrad(dy: Tensor, x: Tensor, w: Tensor, rows: int):
@@ -194,6 +220,7 @@ class ViTFn(torch.autograd.Function):
         patches, saved = t[0], t[1:]
         dev = dfeat.device
         L = _lib.lib()
+        from . import densenet_fused as _dn
         scale = dh ** -0.5
         dx = torch.zeros((B, T, D), device=dev, dtype=BF)
         dx[:, 1:] = (dfeat / float(npatch)).to(BF).unsqueeze(1)
@@ -205,18 +232,15 @@ class ViTFn(torch.autograd.Function):
             x, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h1 = saved[13 * li: 13 * li + 13]
             Dh = m.fc1.out_features
             # MLP
-            grads[m.fc2.weight] = linear_wgrad(dx, h1, m.fc2.weight, M)
-            grads[m.fc2.bias] = bias_grad(dx, m.fc2.bias, M)
+            _param_grads(dx, h1, m.fc2, M, grads)
             dpre = torch.empty((B, T, Dh), device=dev, dtype=BF)
             gemm(dx, _w16(m.fc2.weight), dpre, M, Dh, D, D, Dh, Dh, flags=B_KM | GELU_BWD, aux=pre, ldaux=Dh)
-            grads[m.fc1.weight] = linear_wgrad(dpre, u2, m.fc1.weight, M)
-            grads[m.fc1.bias] = bias_grad(dpre, m.fc1.bias, M)
+            _param_grads(dpre, u2, m.fc1, M, grads)
             du2 = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dpre, _w16(m.fc1.weight), du2, M, D, Dh, Dh, D, D, flags=B_KM)
             dx1, grads[blk.norm2.weight], grads[blk.norm2.bias] = ln_bwd(du2, x1, blk.norm2, mean2, rstd2, dx, M)
             # attention output projection
-            grads[a.proj.weight] = linear_wgrad(dx1, o, a.proj.weight, M)
-            grads[a.proj.bias] = bias_grad(dx1, a.proj.bias, M)
+            _param_grads(dx1, o, a.proj, M, grads)
             do = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dx1, _w16(a.proj.weight), do, M, D, D, D, D, D, flags=B_KM)
             # attention core, per (image, head)
@@ -235,11 +259,12 @@ class ViTFn(torch.autograd.Function):
                  sA=sP, sB=sQ, sC=sQ)                                                   # dQ = dS K
             gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=A_KM | B_KM, c_off=D, batch=nb, batch2=heads,
                  sA=sP, sB=sQ, sC=sQ)                                                   # dK = dS^T Q
-            grads[a.qkv.weight] = linear_wgrad(dqkv, u1, a.qkv.weight, M)
-            grads[a.qkv.bias] = bias_grad(dqkv, a.qkv.bias, M)
+            _param_grads(dqkv, u1, a.qkv, M, grads)
             du1 = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dqkv, _w16(a.qkv.weight), du1, M, D, 3 * D, 3 * D, D, D, flags=B_KM)
             dx, grads[blk.norm1.weight], grads[blk.norm1.bias] = ln_bwd(du1, x, blk.norm1, mean1, rstd1, dx1, M)
+            if li % 4 == 0:
+                _dn._side_join(dev)      # bounds what stays parked for the side stream (0.7 GB of operands per block)
         # embeddings: position table and class token (fp32 sums over the batch), patch projection
         dxf = dx.float()
         dpos = dxf.sum(dim=0, keepdim=True)
@@ -251,6 +276,7 @@ class ViTFn(torch.autograd.Function):
         gw = linear_wgrad(dxp, patches, pe.weight, M)
         grads[pe.weight] = None if gw is None else gw.view_as(pe.weight)
         grads[pe.bias] = bias_grad(dxp, pe.bias, M)
+        _dn._side_join(dev)
         return (None, None, *[grads.get(prm) for prm in _param_list(vit)])
 
 
