@@ -345,7 +345,7 @@ def main():
                        "final_loss_note": f"{args.n_batches} synthetic batches are cycled: the loss reflects "
                                           "memorisation of that set, it is not a convergence claim"},
             "roofline": roof,
-            "roofline_kernels": roof_rows[1:8],
+            "roofline_kernels": roof_rows[1:12],
         }
         if world == 1 and not args.no_cpu_baseline:
             log("gpu done: %.2f ms/step; timing the CPU oracle baseline" % out["ms_per_step"])
