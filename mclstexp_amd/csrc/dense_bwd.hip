@@ -465,7 +465,12 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   float* coef = workspace + (int64_t)nrt * 2 * C;
   hipStream_t st = mcl_stream(stream);
   // persistent over row tiles: two (128-row tiles) or three (64-row tiles) workgroups per CU, each keeps one column tile
-  int gx = ((tmv == 64 ? 768 : 512) + nct - 1) / nct;
+  // 512 workgroups (two per CU) although LDS and registers allow three: alone the kernels are faster with three (r01:
+  // 2302 -> 1835 us/step serial), but in the step they share the CUs with the weight-gradient kernels of the side stream,
+  // which cannot become resident beside three: 14.02 / 14.09 ms/step at 768, 13.92 / 13.96 at 512 (MCL_MAIN_GRID for A/B)
+  static const char* e_gx = getenv("MCL_MAIN_GRID");
+  const int gcap = e_gx ? atoi(e_gx) : 512;
+  int gx = ((tmv == 64 ? gcap : 512) + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
 #define MCL_BN1(MODE, TMV, COEF, GB, LDG, PART)                                                                         \
@@ -494,7 +499,9 @@ extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const
       (reinterpret_cast<uintptr_t>(gbuf) & 15u))
     return MCL_EUNSUPPORTED;
   const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
-  int gx = (768 + nct - 1) / nct;
+  static const char* e_gx = getenv("MCL_MAIN_GRID");
+  const int gcap = e_gx ? atoi(e_gx) : 512;
+  int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<1, 64>), dim3(gx, nct), dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
                      (const bf16_t*)W1, C, (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, coef,
@@ -525,7 +532,9 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
   float* coef = workspace + (int64_t)ntile * 2 * C3I;
   const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
   hipStream_t st = mcl_stream(stream);
-  hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < 768 ? ntile : 768), dim3(256), lds_bytes, st, (const bf16_t*)dy,
+  static const char* e_gx = getenv("MCL_MAIN_GRID");
+  const int gcap = e_gx ? atoi(e_gx) : 512;
+  hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
                      (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
                      (bf16_t*)g2, part, ntile);
   hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C3I), dim3(256), 0, st, (const float2*)part, ntile, C3I,
