@@ -741,6 +741,8 @@ extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z
 //   * the three ky workgroups of a pixel group run next to each other on one XCD (z is re-read from that L2) and write
 //     disjoint column ranges of ONE 32 x 1152 partial: a third of the partial traffic per pixel group.
 // Wave w owns input channels 32w..32w+31 of all three taps (48 accumulator registers).
+namespace {
+
 constexpr int W3K_ROWS = T3 + 2;                         // staged z rows per tile
 constexpr int W3K_LDS = W3K_ROWS * 256 + 3 * T3 * 64;    // z tile + three masked dy tiles = 57,856 B: two per CU
 
@@ -898,6 +900,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __
     }
   }
 }
+
+}  // namespace
 
 // pixel groups (= partials) of the kernel-row form: three workgroups each, two workgroups per CU
 static inline int wrw3k_groups(int ntile) { return ntile < 176 ? ntile : 176; }
