@@ -467,9 +467,12 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   // persistent over row tiles: two (128-row tiles) or three (64-row tiles) workgroups per CU, each keeps one column tile
   // 512 workgroups (two per CU) although LDS and registers allow three: alone the kernels are faster with three (r01:
   // 2302 -> 1835 us/step serial), but in the step they share the CUs with the weight-gradient kernels of the side stream,
-  // which cannot become resident beside three: 14.02 / 14.09 ms/step at 768, 13.92 / 13.96 at 512 (MCL_MAIN_GRID for A/B)
+  // which cannot become resident beside three: 14.02 / 14.09 ms/step at 768, 13.92 / 13.96 at 512 (MCL_MAIN_GRID for A/B).
+  // Only on the 28 x 28 and larger maps: below, the grids do not fill the chip anyway and three per CU stay (no difference
+  // in the step, 13.84-13.95 either way; MCL_MAIN_GRID_SMALL)
   static const char* e_gx = getenv("MCL_MAIN_GRID");
-  const int gcap = e_gx ? atoi(e_gx) : 512;
+  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
+  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
   int gx = ((tmv == 64 ? gcap : 512) + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
@@ -500,7 +503,8 @@ extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const
     return MCL_EUNSUPPORTED;
   const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
   static const char* e_gx = getenv("MCL_MAIN_GRID");
-  const int gcap = e_gx ? atoi(e_gx) : 512;
+  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
+  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<1, 64>), dim3(gx, nct), dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
@@ -533,7 +537,8 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
   const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
   hipStream_t st = mcl_stream(stream);
   static const char* e_gx = getenv("MCL_MAIN_GRID");
-  const int gcap = e_gx ? atoi(e_gx) : 512;
+  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
+  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
   hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
                      (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
                      (bf16_t*)g2, part, ntile);
