@@ -95,6 +95,20 @@ def test_gemm_splitk_matches_one_pass_and_is_deterministic(ops):
     assert_close_scaled(C3.cpu(), A3.cpu().double() @ B3.cpu().double(), 2e-6, what="batched split-K")
 
 
+def test_linear_bwd_weight_accumulates_into_param_grad(ops):
+    """Spot-path weight gradients add straight into an existing fp32 .grad (FusedAdam's flat bucket), also through the
+    split-K second pass; without a .grad they are returned."""
+    for M, N, K in ((128, 1000, 1000), (128, 40, 1536), (33, 171, 785)):
+        dy, x = _rand(M, N, seed=1).to(DEV), _rand(M, K, seed=2).to(DEV)
+        w = torch.nn.Parameter(torch.zeros(N, K, device=DEV))
+        assert ops.linear_bwd_weight(dy, x, w) is not None            # no .grad yet: returned to autograd
+        w.grad = _rand(N, K, seed=3).to(DEV)
+        g0 = w.grad.clone()
+        assert ops.linear_bwd_weight(dy, x, w) is None
+        ref = g0.cpu().double() + dy.cpu().double().t() @ x.cpu().double()
+        assert_close_scaled(w.grad.cpu(), ref, 2e-6, what="param.grad += dy^T x (%d, %d, %d)" % (M, N, K))
+
+
 def test_gemm_unaligned_views(ops):
     """Operands that are strided views (q/k/v slices of qkv) and 4-byte-aligned-only bases."""
     B, H, d = 19, 3, 64
