@@ -904,14 +904,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __
 }  // namespace
 
 // pixel groups (= partials) of the kernel-row form: three workgroups each, two workgroups per CU
-static inline int wrw3k_groups(int ntile) { return ntile < 176 ? ntile : 176; }
+static inline int wrw3k_groups(int ntile) {
+  static const char* e = getenv("MCL_W3K_GROUPS");             // 88 x 3 workgroups: 14.08 ms/step at 176, 13.99 at 88 (32-88 alike)
+  const int g = e ? atoi(e) : 88;
+  return ntile < g ? ntile : g;
+}
 
 // Deterministic form: per-workgroup fp32 partials (32 x 1152 each) in the workspace + a fixed-order merge launch.
 static inline int wrw3_grid(int64_t S, int ntile) {
   // Two workgroups per CU on the large maps: the kernel stages each slab synchronously, so a second resident
   // workgroup is what overlaps one's loads with the other's MFMAs (one per CU measured 133 vs ~75 us in block 1); every
   // workgroup costs a 147 KB partial that the merge re-reads, hence fewer on the small maps.
-  const int gmax = S >= 200000 ? 512 : (S >= 50000 ? 256 : 96);
+  static const char* e_g = getenv("MCL_W3_GRID");              // 56 x 56 maps: 384 in the step (512 alone), see plan() in wrw_fused.hip
+  const int gmax = S >= 200000 ? (e_g ? atoi(e_g) : 384) : (S >= 50000 ? 256 : 96);
   return ntile < gmax ? ntile : gmax;
 }
 

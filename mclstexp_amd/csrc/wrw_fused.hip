@@ -333,10 +333,14 @@ struct Split {
 inline Split plan(long long S, int N) {
   Split p;
   p.tn = (N + BT - 1) / BT;
-  // ~2 workgroups per CU.  A workgroup's time is a chain of (tiles x DMA latency ~3 us) + prologue + epilogue, so the
+  // A workgroup's time is a chain of (tiles x DMA latency ~3 us) + prologue + epilogue, so the
   // small maps (blocks 3-4: the whole operand set is 8-56 MB) want FEW tiles per workgroup even though every extra
   // workgroup costs a 64 KB partial that the merge re-reads: at least 4 tiles (2 on the 7 x 7 maps) per workgroup.
-  const long long target = 512;
+  // (192 workgroups, not two per CU: alone the kernel is a little faster at 512, but in the step it shares the chip with
+  //  the other lane's kernels and every workgroup costs a partial the merge re-reads: 13.83 ms/step at 512, 13.57-13.66
+  //  at 192-256 together with the smaller 3x3 weight-gradient grids; MCL_WRW_TARGET for A/B)
+  static const char* e_t = getenv("MCL_WRW_TARGET");
+  const long long target = e_t ? atoll(e_t) : 192;
   long long ks = (target + p.tn - 1) / p.tn;
   const long long min_rows = S < 10000 ? 2 * BK : 4 * BK;
   const long long max_ks = (S + min_rows - 1) / min_rows;
