@@ -938,11 +938,11 @@ extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const voi
     return MCL_EUNSUPPORTED;
   const int ntile = (int)((S + T3 - 1) / T3);
   hipStream_t st = mcl_stream(stream);
-  // kernel-row form on the 28 x 28 and smaller maps (kernel time 26.5 / 16.5 / 10 us vs 50 / 36 / 20 for the slab form);
-  // on the 56 x 56 maps its twelve LDS fragment reads per three MFMAs lose to the slab form's shared dy fragment
-  // (115 vs 85 us): MCL_WRW3_SLAB=1 / =0 force one form for A/B runs
+  // kernel-row form everywhere.  Timed alone it loses to the slab form on the 56 x 56 maps (115 vs 85 us: twelve LDS
+  // fragment reads per three MFMAs), but in the step, with 88 x 3 workgroups that leave room for the other lane and a
+  // sixth of the partial traffic, it wins: 13.56 / 13.60 vs 13.70 / 13.76 ms/step.  MCL_WRW3_SLAB=1 selects the slab form.
   static const char* e_form = getenv("MCL_WRW3_SLAB");
-  const bool slab = e_form ? e_form[0] == '1' : S >= 200000;
+  const bool slab = e_form && e_form[0] == '1';
   if (!slab) {
     const int G = wrw3k_groups(ntile);
     const int nblk = ((G + 7) / 8) * 8 * 3;

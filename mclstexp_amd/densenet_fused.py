@@ -286,9 +286,10 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
 # total work but puts the weight gradient ON the critical chain of the backward.  Where the side stream hides the weight
 # gradients (14 x 14 and 7 x 7 maps, mostly 28 x 28) the shorter chain wins; on the 56 x 56 maps both lanes are
 # throughput-bound, the side work costs its full duration anyway, and saving one pass over (dz, x) per layer wins:
-# fused from 200 000 pixels up 14.08 / 14.12 ms/step, from 50 000 up 14.15, never 14.28 / 14.36 (interleaved A/B).
+# fused from 200 000 pixels up 14.08 / 14.12 ms/step, from 50 000 up 14.15, never 14.28 / 14.36 (interleaved A/B); after the
+# side-lane grids were shrunk (csrc/wrw_fused.hip plan()): from 50 000 up 13.59 / 13.60, from 200 000 up 13.70 / 13.76.
 USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "1") != "0"
-FUSED_BN1_WRW_MIN_PIXELS = int(os.environ.get("MCL_FUSED_BN1_WRW_MIN_PIXELS", "200000"))
+FUSED_BN1_WRW_MIN_PIXELS = int(os.environ.get("MCL_FUSED_BN1_WRW_MIN_PIXELS", "50000"))
 
 
 def _bn1_wrw_ok(w_param: Tensor) -> bool:
