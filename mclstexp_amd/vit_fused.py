@@ -64,6 +64,7 @@ def _w16(w: Tensor) -> Tensor:
     return w.detach().to(BF).contiguous()
 
 
+JOIN_EVERY = int(os.environ.get("MCL_VIT_JOIN_EVERY", "4"))              # encoder blocks between joins of the side stream
 KSPLIT_TARGET = int(os.environ.get("MCL_VIT_KSPLIT_TARGET", "128"))     # workgroups a split-K weight gradient aims for (side lane: 60.5 ms/step at 256, 59.7 at 128)
 
 
@@ -266,7 +267,7 @@ class ViTFn(torch.autograd.Function):
             du1 = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dqkv, _w16(a.qkv.weight), du1, M, D, 3 * D, 3 * D, D, D, flags=B_KM)
             dx, grads[blk.norm1.weight], grads[blk.norm1.bias] = ln_bwd(du1, x, blk.norm1, mean1, rstd1, dx1, M)
-            if li % 4 == 0:
+            if li % JOIN_EVERY == 0:
                 _dn._side_join(dev)      # bounds what stays parked for the side stream (0.7 GB of operands per block)
         # embeddings: position table and class token (fp32 sums over the batch), patch projection
         dxf = dx.float()
