@@ -743,6 +743,13 @@ extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z
 // Wave w owns input channels 32w..32w+31 of all three taps (48 accumulator registers).
 namespace {
 
+// z-tile swizzle: a transposing read takes 4 consecutive pixel rows x 32 bytes per 16 lanes, so consecutive rows must
+// land in different 64-byte bank windows: chunk bits 2-3 ^= row & 3, bits 0-1 ^= (row >> 2) & 3 (a period-16 pattern:
+// read addresses still advance by 4096 B per 16-pixel k-step).  The slab kernels' chunk ^ (row & 15) only swaps the two
+// chunks of a pair between rows 2m and 2m+1: a 2-way conflict on every read (SQ_LDS_BANK_CONFLICT was 76 % of the
+// kernel's busy cycles, profiles/r02_sq_counters_step_kernels_before_swizzle_fix.txt; 0 after).
+__device__ __forceinline__ int w3k_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
 constexpr int W3K_ROWS = T3 + 2;                         // staged z rows per tile
 constexpr int W3K_LDS = W3K_ROWS * 256 + 3 * T3 * 64;    // z tile + three masked dy tiles = 57,856 B: two per CU
 
@@ -790,8 +797,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __
   for (int kx = 0; kx < 3; ++kx) {
     const int chunk = wave * 4 + ((half16 + jj * 4) >> 3);
     const int r0 = 8 * h + q + kx, r1 = r0 + 4;
-    bz_lo[kx] = r0 * 256 + ((chunk ^ (r0 & 15)) << 4) + byte;
-    bz_hi[kx] = r1 * 256 + ((chunk ^ (r1 & 15)) << 4) + byte;
+    bz_lo[kx] = r0 * 256 + ((chunk ^ w3k_swz(r0)) << 4) + byte;
+    bz_hi[kx] = r1 * 256 + ((chunk ^ w3k_swz(r1)) << 4) + byte;
   }
   const int dchunk = (half16 + jj * 4) >> 3;
 
@@ -823,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __
       if (j < W3K_ROWS) {
         const int p = qs + j;
         const bool ok = p >= 0 && p < Si;                // (rows outside the tensor: exact zeros, not relu(shift))
-        *reinterpret_cast<uint4*>(zt + j * 256 + ((cc ^ (j & 15)) << 4)) =
+        *reinterpret_cast<uint4*>(zt + j * 256 + ((cc ^ w3k_swz(j)) << 4)) =
             ok ? bn_relu_chunk(zv[i], sc, sh) : make_uint4(0u, 0u, 0u, 0u);
       }
     }
