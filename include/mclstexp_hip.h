@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 1
+#define MCL_ABI_VERSION 2
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -416,9 +416,11 @@ int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows, int32_t co
 /* Graph-replayable Adam: the step counter (one int64) and the derived constants (8 floats) live on the device.
  * mcl_adam_consts_update advances the counter and refreshes the constants (one thread, double arithmetic, rounded once
  * as the host-constant entry points do); the _dev kernels read them, so nothing step-dependent is baked into a launch
- * and the whole optimizer step can sit inside a captured HIP graph.                                             */
-int mcl_adam_consts_update(int64_t* step, float* consts, double lr, double beta1, double beta2, double eps,
-                           double weight_decay, mcl_stream_t stream);
+ * and the whole optimizer step can sit inside a captured HIP graph.  `hyper` = DEVICE pointer to 5 doubles
+ * {lr, beta1, beta2, eps, weight_decay}: the host refreshes them with an ordinary copy between replays, so an LR schedule
+ * (torch.optim.lr_scheduler / a manual param_groups edit) is honoured by a captured step (ABI 2; ABI 1 took them by value
+ * and froze them into the graph).                                                                                     */
+int mcl_adam_consts_update(int64_t* step, float* consts, const double* hyper, mcl_stream_t stream);
 int mcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* consts, mcl_stream_t stream);
 int mcl_adam_table_step_dev(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
                             const float* row_grad, int64_t ld_rg, const float* consts, mcl_stream_t stream);

@@ -118,9 +118,12 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
 // One thread: advances the device-resident step counter and derives this step's constants from it (double arithmetic,
 // rounded once, exactly as make_consts does on the host).  With the counter on the device the whole optimizer step can
 // be captured in a HIP graph and replayed: nothing step-dependent is baked into the launches.
-__global__ void adam_consts_kernel(long long* __restrict__ step, AdamC* __restrict__ out, double lr, double b1, double b2,
-                                   double eps, double wd) {
+// The hyper-parameters (lr, beta1, beta2, eps, weight_decay) are READ FROM DEVICE MEMORY too: a by-value kernel argument
+// is frozen into a captured graph, so an LR schedule or a manual param_groups edit would be ignored by every replay.
+__global__ void adam_consts_kernel(long long* __restrict__ step, AdamC* __restrict__ out,
+                                   const double* __restrict__ hyper) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
   const long long t = *step + 1;
   *step = t;
   const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
@@ -206,12 +209,12 @@ extern "C" int mcl_adam_table_step(float* p, float* m, float* v, int32_t n_rows,
 }
 
 // ---- graph-replayable form: the step counter and the derived constants live on the device
-extern "C" int mcl_adam_consts_update(int64_t* step, float* consts /* 8 floats */, double lr, double beta1, double beta2,
-                                      double eps, double weight_decay, mcl_stream_t stream) {
+extern "C" int mcl_adam_consts_update(int64_t* step, float* consts /* 8 floats */, const double* hyper /* 5 doubles */,
+                                      mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!step || !consts) return MCL_EINVAL;
+  if (!step || !consts || !hyper) return MCL_EINVAL;
   hipLaunchKernelGGL(adam_consts_kernel, dim3(1), dim3(64), 0, mcl_stream(stream), (long long*)step,
-                     reinterpret_cast<AdamC*>(consts), lr, beta1, beta2, eps, weight_decay);
+                     reinterpret_cast<AdamC*>(consts), hyper);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -43,3 +43,10 @@ void mcl_launch_wrw_merge(const float* wpart, int ks, long long MN, float* dW, i
 // same with an explicit slab stride (floats)
 void mcl_launch_wrw_merge_strided(const float* wpart, int ks, long long MN, long long stride, float* dW, int accumulate_w,
                                   hipStream_t st);
+
+// csrc/conv3x3_rows.hip: row-walking form of the growth 3x3 convolution for the large maps (enqueue only).
+bool mcl_conv3x3_rows_applicable(long long S, int H, int W);
+long long mcl_conv3x3_rows_workspace_floats(long long S);
+int mcl_launch_conv3x3_fwd_rows(const void* z, long long S, int H, int W, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, const void* W2, void* out, long long ldo,
+                                float* workspace, float eps, float* ymean, float* yvar, float* yrstd, hipStream_t st);

@@ -522,7 +522,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_fwd_kernel(const bf16_t* __res
 
 extern "C" int64_t mcl_dense_conv3x3_workspace_floats(int64_t S) {
   if (S <= 0) return -1;
-  return ((S + T3 - 1) / T3) * C3_OUT * 2;
+  const int64_t flat = ((S + T3 - 1) / T3) * C3_OUT * 2, rows = mcl_conv3x3_rows_workspace_floats(S);
+  return flat > rows ? flat : rows;
 }
 
 extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_t W, const float* gamma,
@@ -537,6 +538,13 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
   if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (ldo % 8) || ldo < C3_OUT || (reinterpret_cast<uintptr_t>(z) & 15u) ||
       (reinterpret_cast<uintptr_t>(W2) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
     return MCL_EUNSUPPORTED;
+  if (mcl_conv3x3_rows_applicable(S, H, W)) {       // the large maps: row-walking form (csrc/conv3x3_rows.hip)
+    const int rc = mcl_launch_conv3x3_fwd_rows(z, S, H, W, gamma, beta, mean, rstd, W2, out, ldo, workspace, eps, ymean,
+                                               yvar, yrstd, mcl_stream(stream));
+    if (rc != 0) return rc;
+    MCL_CHECK_LAUNCH();
+    return MCL_OK;
+  }
   const int ntile = (int)((S + T3 - 1) / T3);
   // slab + zero row; the epilogue reuses it for 4 x 128 x 32 fp32 partials (64 KiB) / the statistics scratch
   size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256;

@@ -115,7 +115,10 @@ class SizeExchange:
 
     def _group(self):
         if self._cpu_pg is None:
-            self._cpu_pg = self.pg if td.get_backend(self.pg) == "gloo" else td.new_group(backend="gloo")
+            # a gloo group over exactly the ranks of ``pg`` (which may be a subgroup of the world; like every
+            # new_group call this is collective over the WORLD: all processes must construct their SizeExchange)
+            self._cpu_pg = (self.pg if td.get_backend(self.pg) == "gloo"
+                            else td.new_group(ranks=td.get_process_group_ranks(self.pg), backend="gloo"))
         return self._cpu_pg
 
     def __call__(self, b_loc: int) -> List[int]:

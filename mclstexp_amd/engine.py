@@ -1,8 +1,8 @@
 """TrainStep: one optimisation step of train.py:33-41, optionally replayed from HIP graphs.
 
-Why graphs: the step is ~2500 kernel launches (DenseNet-121 has 120 conv + 121 BatchNorm layers, each with
-forward, data-gradient and weight-gradient kernels); in eager mode the Python/ATen launch path needs ~30 ms
-per step on the host -- as long as the GPU work itself.  Capturing removes the host from the critical path
+Why graphs: the step is ~1000 kernel launches (DenseNet-121 has 120 conv + 121 BatchNorm layers, each with
+fused forward, data-gradient and weight-gradient kernels); in eager mode the Python launch path needs longer per
+step on the host than the GPU work itself.  Capturing removes the host from the critical path
 (MI355X-first: "HIP streams and graphs instead of a tracing compiler").
 
 Structure (identical for 1 GPU and for data parallel, so RCCL collectives are never inside a capture):
@@ -30,8 +30,12 @@ Tensor = torch.Tensor
 
 class TrainStep:
     def __init__(self, model, optimizer, reducer=None, graphs: bool = True, warmup: int = 3,
-                 single_graph: Optional[bool] = None):
+                 single_graph: Optional[bool] = None, equal_shards: bool = False):
+        """``equal_shards``: the caller guarantees that every rank sees the same per-rank batch size on every step
+        (DistributedSampler with drop_last, synthetic data): the per-step host size exchange -- a blocking gloo
+        all-gather that keeps the ranks' host threads in lock-step -- is skipped."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
+        self.equal_shards = bool(equal_shards)
         self.graphs = graphs and torch.cuda.is_available()
         self.warmup = max(2, warmup)
         self.calls = 0
@@ -71,6 +75,8 @@ class TrainStep:
     def _capture(self, batch) -> None:
         m = self.model
         self.static_in = {k: v.clone(memory_format=torch.preserve_format) for k, v in batch.items()}
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()                # the captured step reads lr / betas / eps / wd from device memory
         torch.cuda.synchronize()
         # capture_error_mode "thread_local": under data parallelism the RCCL watchdog thread polls events while we
         # capture; in the default "global" mode any such call from another thread invalidates the capture
@@ -157,6 +163,10 @@ class TrainStep:
         True when all shards are equal."""
         if self.reducer is None:
             return True
+        if self.equal_shards:
+            self._all_regular = (self.static_in is not None
+                                 and batch["expression"].shape[0] == self.static_in["expression"].shape[0])
+            return True
         from . import dist as mdist
         if self._sizes_ex is None:
             self._sizes_ex = mdist.SizeExchange(self.reducer.pg)
@@ -184,6 +194,8 @@ class TrainStep:
             return self._eager_ragged(batch)
         for k, v in self.static_in.items():
             v.copy_(batch[k], non_blocking=True)
+        if self.opt_in_graph:
+            self.opt.sync_hyper()                # an LR schedule / param_groups edit reaches the replayed optimizer
         self.ga.replay()
         if self.single_graph:
             if self.opt_in_graph:

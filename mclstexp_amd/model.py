@@ -386,20 +386,32 @@ class mclSTExp_Attention(_ContrastiveBase):
         ops.set_compute(self.compute)
         side = self._branch_stream(batch["expression"].device)
         late = int(os.environ.get("MCL_SPOT_AFTER_BLOCK", "2"))
+        # only the train-mode fused forward (densenet_features_fused) fires the block hook: eval / no_grad calls take
+        # forward_eval_fused or the module and must use the plain fork below, or the side stream would wait on an event
+        # that is never recorded (= not wait at all)
         if (side is not None and late > 0 and self.fused_backbone and isinstance(self.image_encoder, backbones.ImageEncoder)
-                and self.backbone_dtype == torch.bfloat16):
+                and self.backbone_dtype == torch.bfloat16 and self.image_encoder.training and torch.is_grad_enabled()
+                and batch["image"].is_cuda):
             # The spot branch starts when the DenseNet has finished dense block `late`: the first two blocks (56 x 56 and
             # 28 x 28 maps) are throughput-bound, anything running beside them costs its full duration; the
             # later blocks are latency-bound chains with idle CUs.
             from . import densenet_fused
             main = torch.cuda.current_stream()
             ev = torch.cuda.Event()
-            densenet_fused.FORWARD_BLOCK_HOOKS[late] = lambda: ev.record(main)
+            fired = []
+
+            def _hook():
+                ev.record(main)
+                fired.append(True)
+            densenet_fused.FORWARD_BLOCK_HOOKS[late] = _hook
             try:
                 image_features = self._encode_image(self.image_encoder, batch["image"])
             finally:
                 densenet_fused.FORWARD_BLOCK_HOOKS.pop(late, None)
-            side.wait_event(ev)
+            if fired:
+                side.wait_event(ev)
+            else:                                   # MCL_SPOT_AFTER_BLOCK beyond the last block: order after everything
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 spot_embeddings = self._embed_spots(batch)
             image_embeddings = self.image_projection(image_features)

@@ -235,9 +235,31 @@ class FusedAdam(torch.optim.Optimizer):
         d = self._dev.get(gi)
         if d is None:
             d = {"step": torch.full((1,), self._step_count, dtype=torch.int64, device=device),
-                 "consts": torch.zeros(8, dtype=torch.float32, device=device)}
+                 "consts": torch.zeros(8, dtype=torch.float32, device=device),
+                 # {lr, beta1, beta2, eps, weight_decay} as the kernels read them (device) and as last uploaded (host)
+                 "hyper": torch.zeros(5, dtype=torch.float64, device=device), "hyper_host": None}
             self._dev[gi] = d
         return d
+
+    def sync_hyper(self) -> None:
+        """Upload the param groups' hyper-parameters to their device buffers when they changed (LR scheduler, manual
+        ``param_groups[i]['lr'] = ...``).  mcl_adam_consts_update reads them from device memory, so a step captured
+        in a HIP graph honours the change on its next replay; engine.TrainStep calls this before every replay.
+        Never called while a stream is capturing (a host-to-device copy cannot be captured from pageable memory):
+        ``_begin_step`` checks and raises instead."""
+        for gi, group in enumerate(self.param_groups):
+            dev = next((p.device for p in group["params"] if p.is_cuda), None)
+            if dev is None:
+                continue
+            d = self._dev_state(gi, dev)
+            b1, b2 = group["betas"]
+            cur = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            if d["hyper_host"] != cur:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("FusedAdam: hyper-parameters changed inside a graph capture; call "
+                                       "optimizer.sync_hyper() before capturing")
+                d["hyper"].copy_(torch.tensor(cur, dtype=torch.float64))
+                d["hyper_host"] = cur
 
     def _begin_step(self) -> None:
         """Advance the device step counters and refresh the constants -- once per optimisation step, by whoever comes
@@ -245,6 +267,7 @@ class FusedAdam(torch.optim.Optimizer):
         if self._began:
             return
         self._began = True
+        self.sync_hyper()
         L = _lib.lib()
         st = ops._stream()
         for gi, group in enumerate(self.param_groups):
@@ -252,9 +275,8 @@ class FusedAdam(torch.optim.Optimizer):
             if dev is None:
                 continue
             d = self._dev_state(gi, dev)
-            b1, b2 = group["betas"]
-            check(L.mcl_adam_consts_update(d["step"].data_ptr(), d["consts"].data_ptr(), group["lr"], b1, b2,
-                                           group["eps"], group["weight_decay"], st), "mcl_adam_consts_update")
+            check(L.mcl_adam_consts_update(d["step"].data_ptr(), d["consts"].data_ptr(), d["hyper"].data_ptr(), st),
+                  "mcl_adam_consts_update")
 
     def _early_tables(self) -> None:
         """Called by ops.PosEmbedAddFn.backward once sink['dout'|'ix'|'iy'] exist (single process)."""

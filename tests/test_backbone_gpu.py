@@ -334,7 +334,11 @@ def test_dense_conv1x1_fwd_fused(S, K, ldx):
 
 
 @pytest.mark.parametrize("B,H,W,ldo", [(4, 56, 56, 256), (8, 28, 28, 512), (16, 14, 14, 1024), (32, 7, 7, 1024), (3, 10, 6, 64),
-                                       (1, 5, 3, 32), (2, 64, 64, 160)])
+                                       (1, 5, 3, 32), (2, 64, 64, 160),
+                                       # row-walking form (csrc/conv3x3_rows.hip): ragged strips, one-row images, 3-5 strips,
+                                       # more units than wave slots (B*H*strips > 2048)
+                                       (3, 9, 17, 64), (2, 5, 33, 96), (1, 1, 40, 32), (2, 2, 150, 32), (1, 3, 97, 64),
+                                       (40, 56, 56, 32), (7, 31, 29, 64)])
 def test_dense_conv3x3_fwd_fused(B, H, W, ldo):
     """y = conv3x3(relu(bn2(z))) written into a channel slice of a wider NHWC buffer + batch statistics of y, in one
     kernel (csrc/dense_conv.hip) vs torch on the same bf16 data: every DenseNet stage geometry, image borders,

@@ -69,7 +69,12 @@ def main():
                              1 << 20), device=dev)
         st = dn._stream
         P = lambda t: t.data_ptr()
+        ym, yv, yr = (torch.zeros(32, device=dev) for _ in range(3))
+        ws3 = torch.empty(L.mcl_dense_conv3x3_workspace_floats(S), device=dev)
         calls = {
+            "conv3x3_fwd (+finalize)": (lambda: L.mcl_dense_conv3x3_fwd(P(z), S, hw, hw, P(gam), P(bet), P(mu), P(rs), P(W2),
+                                                                       P(xw) + 2 * (ld - 32), ld, P(ws3), 1e-5, P(ym), P(yv),
+                                                                       P(yr), st()), 2 * S * 160),
             "bn1_wrw (fused Gram + merge)": (lambda: L.mcl_dense_bn1_wrw(P(dz), P(W1), C, P(x), ld, S, P(gam), P(bet), P(mu), P(rs),
                                                                          P(ws), P(dW1), 1, P(dg), P(db), 1, P(coef), st()),
                                              2 * S * (128 + C)),
