@@ -111,7 +111,8 @@ int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const flo
  * may alias dx), g = dy*gamma.  dgamma/dbeta (cols) are OVERWRITTEN with the column sums over rows. */
 int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* dx_add, int64_t ldadd, float* dx,
-                      int64_t lddx, float* dgamma, float* dbeta, int32_t rows, int32_t cols, mcl_stream_t stream);
+                      int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate_params, int32_t rows, int32_t cols,
+                      mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- K4 attention softmax (model.py:53-54)
  * In place over n_rows rows of length cols (row stride ld):  p = softmax(scale * s).           */
@@ -122,7 +123,7 @@ int mcl_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int32_t n_rows, 
 
 /* ---------------------------------------------------------------- bias gradient
  * out[n] = sum_m x[m,n]  (nn.Linear bias backward).                                           */
-int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, mcl_stream_t stream);
+int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate, mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- K8 symmetric InfoNCE (model.py:242-247)
  * Works on a logits strip S (R x C, already divided by T): this rank's rows are global rows
@@ -249,16 +250,6 @@ int mcl_bn_act_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, int
                    float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, void* dx, int64_t lddx,
                    int32_t accumulate, mcl_stream_t stream);
 
-/* 1x1-convolution weight gradient (DenseNet bottleneck conv1 / transition conv) on channels-last bf16:
- *   dW[m][n] += sum_s dz[s][m] * a'[s][n],   a' = a, or relu(BatchNorm(a)) when gamma/beta/mean/rstd (all four,
- * per input channel) are given: the layer input is then read straight from the concat buffer and its BN+ReLU is
- * recomputed on the fly, so the normalised activation never has to be kept for the backward.  dz: (S, M) row
- * stride ldz; a: (S, N) row stride lda; dW: (M, N) fp32, ACCUMULATED with float atomics (pass the parameter's
- * .grad view).  M, N, ldz, lda multiples of 8; bases 16-byte aligned.  bf16 MFMA, fp32 accumulate.        */
-int mcl_conv1x1_wrw_bf16(const void* dz, int64_t ldz, const void* a, int64_t lda, const float* gamma,
-                         const float* beta, const float* mean, const float* rstd, float* dW, int64_t lddw, int64_t S,
-                         int32_t M, int32_t N, mcl_stream_t stream);
-
 /* DenseNet bottleneck 1x1 convolution with both BatchNorms folded in (torchvision _DenseLayer norm1/relu1/conv1 +
  * norm2's statistics):   z[s][n] = sum_k relu(x[s][k]*g[k]*rstd[k] + beta[k] - mean[k]*g[k]*rstd[k]) * W[n][k],
  * n < 128;  zmean/zvar (biased)/zrstd = batch statistics of the bf16-rounded z.  x: (S, K) bf16 row stride ldx
@@ -282,16 +273,11 @@ int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_t W, const 
                           const float* mean, const float* rstd, const void* W2, void* out, int64_t ldo,
                           float* workspace, float eps, float* ymean, float* yvar, float* yrstd, mcl_stream_t stream);
 
-/* Weight gradient of that 3x3 convolution: dW2[co][ky][kx][ci] += sum_p dy[p][co] * relu(bn2(z))[p + tap][ci], the
+/* Weight gradient of that 3x3 convolution: dW2[co][ky][kx][ci] (+)= sum_p dy[p][co] * relu(bn2(z))[p + tap][ci], the
  * normalised input recomputed from z on the fly; dW2: (32, 3, 3, 128) fp32 contiguous (the channels-last parameter's
- * .grad), ACCUMULATED with float atomics.  dy: (S, 32) bf16 row stride lddy; z: (S, 128) bf16 contiguous.   */
-int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
-                          const float* gamma, const float* beta, const float* mean, const float* rstd, float* dW,
-                          mcl_stream_t stream);
-
-/* Atomics-free form of mcl_dense_conv3x3_wrw: every workgroup stores its fp32 partial (32 x 1152) in the workspace and
- * a merge launch adds the partials in fixed order -> dW (accumulate_w != 0: +=).  Bit-reproducible.
- * workspace: mcl_dense_conv3x3_wrw_workspace_floats(S) floats.                                                  */
+ * .grad).  dy: (S, 32) bf16 row stride lddy; z: (S, 128) bf16 contiguous.  No atomics: every pixel group stores its fp32
+ * partial (32 x 1152) in the workspace and a merge launch adds the partials in fixed order -> dW (accumulate_w != 0: +=).
+ * Bit-reproducible.  workspace: mcl_dense_conv3x3_wrw_workspace_floats(S) floats.                                  */
 int64_t mcl_dense_conv3x3_wrw_workspace_floats(int64_t S);
 int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
                               const float* gamma, const float* beta, const float* mean, const float* rstd,
@@ -378,9 +364,9 @@ int64_t mcl_conv0_workspace_floats(int32_t N, int32_t H, int32_t W);
 int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, const void* Wt, void* y, float* workspace, float eps,
                   float* mean, float* var, float* rstd, mcl_stream_t stream);
 /* Weight gradient of conv0: dW (64,7,7,3) fp32 (the channels-last parameter's .grad) (+)= sum_p dy[p] (x) patch(x)[p].
- * dy: (N,H/2,W/2,64) bf16 NHWC contiguous.  H % 4 == 0, W % 8 == 0, W <= 256.  workspace != NULL
- * (mcl_conv0_wrw_workspace_floats floats): deterministic -- per-workgroup partials merged in fixed order,
- * accumulate_w != 0 adds into dW, else overwrites.  workspace == NULL: round-1 form, fp32 atomics (+= only).      */
+ * dy: (N,H/2,W/2,64) bf16 NHWC contiguous.  H % 4 == 0, W % 8 == 0, W <= 256.  workspace:
+ * mcl_conv0_wrw_workspace_floats floats -- per-workgroup partials merged in fixed order (deterministic);
+ * accumulate_w != 0 adds into dW, else overwrites.                                                              */
 int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W);
 int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* workspace, float* dW,
                   int32_t accumulate_w, mcl_stream_t stream);

@@ -59,10 +59,10 @@ PROTOTYPES = {
     "mcl_embed_rowgrad": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
     "mcl_embed_scatter_rows": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "mcl_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_p],
-    "mcl_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_p],
+    "mcl_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p],
     "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
-    "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_p],
+    "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
     "mcl_infonce_lse": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
     "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
@@ -89,11 +89,9 @@ PROTOTYPES = {
     "mcl_bn_stats": [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_bn_act_fwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "mcl_bn_act_bwd": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_p],
-    "mcl_conv1x1_wrw_bf16": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_p],
     "mcl_dense_conv1x1_workspace_floats": [c_l],
     "mcl_dense_conv1x1_fwd": [c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_dense_conv3x3_workspace_floats": [c_l],
-    "mcl_dense_conv3x3_wrw": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_dense_bn1_bwd_workspace_floats": [c_l, c_i],
     "mcl_dense_conv3x3_bwd_workspace_floats": [c_l],
     "mcl_avgpool2_nhwc_bf16": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -1,4 +1,7 @@
-"""Image backbones (kernel K10): delegated to PyTorch-ROCm (MIOpen / hipBLASLt).
+"""Image backbones (kernel K10): module trees + parameter names only.  EXECUTION: DenseNet-121 in bf16
+runs entirely on the hand-written kernels scheduled by densenet_fused.py (``ImageEncoder.forward_fused`` /
+``forward_eval_fused``), the ViT on vit_fused.py; the modules' own ``forward`` (plain torch.nn on PyTorch-ROCm) is what fp32
+activations, the ResNet selector values (a12) and the A/B flag ``fused_backbone=False`` use.
 
 torchvision and timm are absent from the image, so the architectures are restated here in plain
 ``torch.nn`` with torchvision-/timm-compatible parameter names, which keeps reference checkpoints

@@ -567,181 +567,14 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
 }
 
 // =====================================================================================================================
-// Weight gradient of the growth 3x3 convolution, with norm2+relu2 recomputed on the fly and accumulation straight
-// into the parameter's fp32 .grad:
+// Weight gradient of the growth 3x3 convolution, with norm2+relu2 recomputed on the fly, deterministic:
 //
-//     dW2[co][ky][kx][ci] += sum_p dy[p][co] * relu(bn2(z))[p + (ky-1)*W + (kx-1)][ci]        (taps inside the image)
+//     dW2[co][ky][kx][ci] (+)= sum_p dy[p][co] * relu(bn2(z))[p + (ky-1)*W + (kx-1)][ci]        (taps inside the image)
 //
-// A "TN" GEMM M = 32, N = 9*128, K = S pixels, both operands pixel-major -> both MFMA fragments come from
-// transposing LDS reads (ds_read_b64_tr_b16).  A workgroup (4 waves, two per CU) walks 128-pixel tiles: dy tile
-// (128 x 32) and the z slab [p0 - W - 1, p0 + 128 + W + 1) with BN+ReLU applied while staging (the same slab as the
-// forward kernel, so a2 never exists in HBM in the backward either); N is split over the waves (9 blocks of 32 =
-// 2.25 taps each, 144 accumulator registers); taps that leave the image select an all-zero LDS row per PIXEL (the
-// pixel is the reduction index here, so the mask rides on the row address each lane supplies to the transposing
-// read).  fp32 partials go to dW with hardware float atomics (no zero-fill / cast / accumulate passes).
-__global__ __launch_bounds__(256, 2) void conv3x3_wrw_kernel(const bf16_t* __restrict__ dy, long long lddy,
-                                                             const bf16_t* __restrict__ z, long long S, int H, int W,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta,
-                                                             const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ dW,
-                                                             int ntile, float* __restrict__ wpart) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  typedef short v4s __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int nrow = T3 + 2 * W + 2;
-  const int zero_off = nrow * 256;                       // 256 B of zeros
-  unsigned char* dyt = lds + zero_off + 256;             // dy tile [128][32] bf16, 64-byte rows (chunk ^ (row>>1)&3)
-  unsigned short* vm = reinterpret_cast<unsigned short*>(dyt + T3 * 64);   // [128 + 2W + 2] 9-bit tap validity per SLAB row
-
-  const int cc = tid & 15;
-  float sc[8], sh[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = cc * 8 + i;
-    sc[i] = gamma[c] * rstd[c];
-    sh[i] = fmaf(-mean[c], sc[i], beta[c]);
-  }
-  if (tid < 16) *reinterpret_cast<uint4*>(lds + zero_off + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int b = 0; b < 9; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
-
-  // transposing-read lane geometry (see csrc/conv1x1.hip frag()): lane i = lane & 15 supplies pixel row (i >> 2)
-  // [+4 for the second read] of the 8-pixel k-group 8*(lane >> 5), 4 channels at (i & 3)*4 of the 16-channel half
-  const int i15 = lane & 15, q = i15 >> 2, jj = i15 & 3;
-  const int half16 = 16 * ((lane >> 4) & 1);
-
-  // per (lane, column block b): slab byte offset of pixel row 8h+q (+4) for the block's tap and input-channel chunk.
-  // (row + toff) & 15 does not depend on the 16-pixel k-step, so a read address is base[b] + 4096*ks.
-  int base_lo[9], base_hi[9], tapb[9];
-#pragma unroll
-  for (int b = 0; b < 9; ++b) {
-    const int nb = 9 * wave + b, tap = nb >> 2, cb = nb & 3;
-    const int toff = (tap / 3) * W + (tap % 3);
-    const int chunk = cb * 4 + ((half16 + jj * 4) >> 3), byte = (jj & 1) * 8;
-    const int r0 = 8 * h + q + toff, r1 = r0 + 4;
-    base_lo[b] = r0 * 256 + ((chunk ^ (r0 & 15)) << 4) + byte;
-    base_hi[b] = r1 * 256 + ((chunk ^ (r1 & 15)) << 4) + byte;
-    tapb[b] = tap;
-  }
-  const int Si = (int)S;
-  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int p0 = tile * T3;
-    __syncthreads();   // previous tile fully consumed
-    // ---- stage: z slab with BN+ReLU, dy tile, validity masks
-    stage_slab<SLAB_NB>(lds, z, p0, S, W, nrow, tid, sc, sh);
-    {
-      const int r = tid >> 1, c2 = tid & 1;              // 128 pixels x 4 chunks: two chunks per thread
-      const int p = p0 + r;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int ch = c2 * 2 + u;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (p < Si) v = *reinterpret_cast<const uint4*>(dy + (long long)p * lddy + ch * 8);
-        *reinterpret_cast<uint4*>(dyt + r * 64 + ((ch ^ ((r >> 1) & 3)) << 4)) = v;
-      }
-    }
-    if (tid < T3) {   // tap validity of OUTPUT pixel p0 + tid (the reduction index)
-      const int p = p0 + tid;
-      unsigned m = 0;
-      if (p < Si) {
-        const int x = p % W, y = (p / W) % H;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) m |= 1u << (ky * 3 + kx);
-          }
-      }
-      vm[tid] = (unsigned short)m;
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int ks = 0; ks < 8; ++ks) {                     // 16 pixels per step
-      const int r_lo = ks * 16 + 8 * h + q, r_hi = r_lo + 4;   // tile pixel rows this lane supplies
-      // A operand: dy^T, channels l31 (32 wide), pixels = k
-      bf16x8 fa;
-      {
-        const int chunk = (half16 + jj * 4) >> 3, byte = ((jj & 1) * 8);
-        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (v4s __attribute__((address_space(3)))*)(dyt + r_lo * 64 + ((chunk ^ ((r_lo >> 1) & 3)) << 4) + byte));
-        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (v4s __attribute__((address_space(3)))*)(dyt + r_hi * 64 + ((chunk ^ ((r_hi >> 1) & 3)) << 4) + byte));
-        fa[0] = lo[0]; fa[1] = lo[1]; fa[2] = lo[2]; fa[3] = lo[3];
-        fa[4] = hi[0]; fa[5] = hi[1]; fa[6] = hi[2]; fa[7] = hi[3];
-      }
-      const unsigned m_lo = vm[r_lo], m_hi = vm[r_hi];
-#pragma unroll
-      for (int b = 0; b < 9; ++b) {
-        const int byte = (jj & 1) * 8;
-        const int a_lo = ((m_lo >> tapb[b]) & 1u) ? base_lo[b] + ks * 4096 : zero_off + byte;
-        const int a_hi = ((m_hi >> tapb[b]) & 1u) ? base_hi[b] + ks * 4096 : zero_off + byte;
-        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + a_lo));
-        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(lds + a_hi));
-        bf16x8 fb;
-        fb[0] = lo[0]; fb[1] = lo[1]; fb[2] = lo[2]; fb[3] = lo[3];
-        fb[4] = hi[0]; fb[5] = hi[1]; fb[6] = hi[2]; fb[7] = hi[3];
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[b], 0, 0, 0);
-      }
-    }
-  }
-  // acc[b][r] is element co = (r&3) + 8*(r>>2) + 4*h, n = 32*nb + l31 of the 1152-wide row.  Deterministic form
-  // (wpart != nullptr): this workgroup's fp32 partial goes to its own workspace slot with plain stores and a merge
-  // launch adds the slots in fixed order; round-1 form: hardware float atomics straight into dW.
-  float* dst = wpart ? wpart + (long long)blockIdx.x * (C3_OUT * 9 * C3_IN) : dW;
-#pragma unroll
-  for (int b = 0; b < 9; ++b) {
-    const int n = 32 * (9 * wave + b) + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (wpart) dst[co * (9 * C3_IN) + n] = acc[b][r];
-      else unsafeAtomicAdd(dst + co * (9 * C3_IN) + n, acc[b][r]);
-    }
-  }
-}
-
-extern "C" int mcl_dense_conv3x3_wrw(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
-                                     const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                     float* dW, mcl_stream_t stream) {
-  MCL_CLEAR_ERROR();
-  if (!dy || !z || !gamma || !beta || !mean || !rstd || !dW || S <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
-  if ((S % ((int64_t)H * W)) || S > 0x7fff0000LL || W > 150 || (lddy % 8) || lddy < C3_OUT || (reinterpret_cast<uintptr_t>(dy) & 15u) ||
-      (reinterpret_cast<uintptr_t>(z) & 15u))
-    return MCL_EUNSUPPORTED;
-  const int ntile = (int)((S + T3 - 1) / T3);
-  const size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256 + T3 * 64 + (T3 + 2 * W + 2) * 2 + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wrw_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
-  // The fp32 atomics of the epilogue (36,864 per workgroup) run at ~0.3 T lane-atomics/s: fewer, longer pixel
-  // ranges per workgroup trade compute parallelism against that (measured optimum per DenseNet stage size).
-  const int gmax = S >= 200000 ? 512 : (S >= 50000 ? 192 : 128);
-  const int grid = ntile < gmax ? ntile : gmax;
-  hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(grid), dim3(256), lds_bytes, mcl_stream(stream), (const bf16_t*)dy,
-                     (long long)lddy, (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile,
-                     (float*)nullptr);
-  MCL_CHECK_LAUNCH();
-  return MCL_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round-2 form of the 3x3 weight gradient ("one kernel row per workgroup"), deterministic.
+// A "TN" GEMM M = 32, N = 9*128, K = S pixels, both operands pixel-major -> both MFMA fragments come from transposing
+// LDS reads (ds_read_b64_tr_b16).  "One kernel row per workgroup":
 //
-// The slab kernel above stages 128 + 2W + 2 rows of z per 128-pixel tile (1.9x the tile at W = 56) synchronously,
-// selects a zero row per (pixel, tap) with ~8 VALU per MFMA, and leaves 147 KB of fp32 partials per workgroup for the
-// merge (75 MB at 512 workgroups): with staging AND masks compiled out it still needed 69 us in block 1 where the MFMAs
-// need 12.  Here a workgroup owns ONE kernel row ky (3 taps, 384 of the 1152 columns) of a strided set of pixel tiles:
+// A workgroup owns ONE kernel row ky (3 taps, 384 of the 1152 columns) of a strided set of 128-pixel tiles:
 //   * the z rows a tile needs for its three kx taps are the 130 consecutive pixels [p0 + (ky-1)W - 1, +130): no halo;
 //   * border handling moves to the OTHER operand: dy is staged three times (8 KB each), each copy zeroed where the
 //     pixel's (ky, kx) neighbour leaves the image -- the MFMA loop has no masks and no address selects at all;
@@ -925,21 +758,10 @@ static inline int wrw3k_groups(int ntile) {
   return ntile < g ? ntile : g;
 }
 
-// Deterministic form: per-workgroup fp32 partials (32 x 1152 each) in the workspace + a fixed-order merge launch.
-static inline int wrw3_grid(int64_t S, int ntile) {
-  // Two workgroups per CU on the large maps: the kernel stages each slab synchronously, so a second resident
-  // workgroup is what overlaps one's loads with the other's MFMAs (one per CU measured 133 vs ~75 us in block 1); every
-  // workgroup costs a 147 KB partial that the merge re-reads, hence fewer on the small maps.
-  static const char* e_g = getenv("MCL_W3_GRID");              // 56 x 56 maps: 384 in the step (512 alone), see plan() in wrw_fused.hip
-  const int gmax = S >= 200000 ? (e_g ? atoi(e_g) : 384) : (S >= 50000 ? 256 : 96);
-  return ntile < gmax ? ntile : gmax;
-}
-
 extern "C" int64_t mcl_dense_conv3x3_wrw_workspace_floats(int64_t S) {
   if (S <= 0) return -1;
   const int ntile = (int)((S + T3 - 1) / T3);
-  const int slabs = wrw3_grid(S, ntile) > wrw3k_groups(ntile) ? wrw3_grid(S, ntile) : wrw3k_groups(ntile);
-  return (int64_t)slabs * (C3_OUT * 9 * C3_IN);
+  return (int64_t)wrw3k_groups(ntile) * (C3_OUT * 9 * C3_IN);
 }
 
 extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
@@ -953,31 +775,13 @@ extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const voi
     return MCL_EUNSUPPORTED;
   const int ntile = (int)((S + T3 - 1) / T3);
   hipStream_t st = mcl_stream(stream);
-  // kernel-row form everywhere.  Timed alone it loses to the slab form on the 56 x 56 maps (115 vs 85 us: twelve LDS
-  // fragment reads per three MFMAs), but in the step, with 88 x 3 workgroups that leave room for the other lane and a
-  // sixth of the partial traffic, it wins: 13.56 / 13.60 vs 13.70 / 13.76 ms/step.  MCL_WRW3_SLAB=1 selects the slab form.
-  static const char* e_form = getenv("MCL_WRW3_SLAB");
-  const bool slab = e_form && e_form[0] == '1';
-  if (!slab) {
-    const int G = wrw3k_groups(ntile);
-    const int nblk = ((G + 7) / 8) * 8 * 3;
-    hipLaunchKernelGGL(conv3x3_wrw_ky_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (long long)lddy,
-                       (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, ntile, G, workspace);
-    mcl_launch_wrw_merge(workspace, G, (long long)C3_OUT * 9 * C3_IN, dW, accumulate_w, st);
-    MCL_CHECK_LAUNCH();
-    return MCL_OK;
-  }
-  const size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256 + T3 * 64 + (T3 + 2 * W + 2) * 2 + 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wrw_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr_set = true;
-  }
-  const int grid = wrw3_grid(S, ntile);
-  hipLaunchKernelGGL(conv3x3_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)dy, (long long)lddy,
-                     (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, dW, ntile, workspace);
-  mcl_launch_wrw_merge(workspace, grid, (long long)C3_OUT * 9 * C3_IN, dW, accumulate_w, st);
+  // per pixel group ONE fp32 partial (32 x 1152) in the workspace, written in disjoint column ranges by its three kernel-row
+  // workgroups; fixed-order merge launch (bit-reproducible)
+  const int G = wrw3k_groups(ntile);
+  const int nblk = ((G + 7) / 8) * 8 * 3;
+  hipLaunchKernelGGL(conv3x3_wrw_ky_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (long long)lddy,
+                     (const bf16_t*)z, (long long)S, H, W, gamma, beta, mean, rstd, ntile, G, workspace);
+  mcl_launch_wrw_merge(workspace, G, (long long)C3_OUT * 9 * C3_IN, dW, accumulate_w, st);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
@@ -1116,14 +920,14 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
   }
 }
 
-// Weight gradient of conv0:  dW[co][ky][kx][c] += sum_p dy[p][co] * x[n, 2 oy - 3 + ky, 2 ox - 3 + kx, c]   (fp32 atomics
-// into the channels-last parameter's .grad).  GEMM M = 64 (co), N = 7 x 24 (k, as in the forward), K = pixels.  Same
+// Weight gradient of conv0:  dW[co][ky][kx][c] (+)= sum_p dy[p][co] * x[n, 2 oy - 3 + ky, 2 ox - 3 + kx, c]  (the
+// channels-last parameter's .grad).  GEMM M = 64 (co), N = 7 x 24 (k, as in the forward), K = pixels.  Same
 // tiles and input slab as the forward; dy is staged TRANSPOSED ([co][pixel]) so that an A fragment (8 consecutive pixels
 // of one channel) is one ds_read_b128; a B fragment (8 consecutive pixels of one k column) is 8 strided 2-byte reads of
 // the slab (12 bytes apart).  Wave w owns co tile w & 1 and k tiles 3 (w >> 1) .. + 2; accumulators persist over the
 // workgroup's tiles.  Each output row of the tile is padded to a multiple of 16 pixels in the transposed dy tile (zero
 // columns: a 16-pixel k-step never straddles output rows, and OW = 56 -- 112-pixel her2st patches -- works).
-// wpart != nullptr: deterministic form, the workgroup's fp32 partial (64 x 7 x 21) goes to its workspace slot.
+// The workgroup's fp32 partial (64 x 7 x 21) goes to its workspace slot (fixed-order merge launch: deterministic).
 __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
                                                            const bf16_t* __restrict__ dy, float* __restrict__ dW,
                                                            int ntile, float* __restrict__ wpart) {
@@ -1211,12 +1015,11 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
     if (!kval[t]) continue;
     const int k = (kt0 + t) * 32 + l31;
     const int ky = k / C0_KP, j = k % C0_KP;
-    float* dst = wpart ? wpart + (long long)blockIdx.x * (C0_OUT * C0_K * 21) : dW;
+    float* dst = wpart + (long long)blockIdx.x * (C0_OUT * C0_K * 21);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (wpart) dst[(co * C0_K + ky) * 21 + j] = acc[t][r];
-      else unsafeAtomicAdd(dst + (co * C0_K + ky) * 21 + j, acc[t][r]);
+      dst[(co * C0_K + ky) * 21 + j] = acc[t][r];
     }
   }
 }
@@ -1261,8 +1064,8 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
   return MCL_OK;
 }
 
-// workspace == nullptr: round-1 form (fp32 atomics into dW).  Otherwise deterministic: per-workgroup partials in the
-// workspace (mcl_conv0_wrw_workspace_floats floats) + a fixed-order merge launch; accumulate_w != 0 adds into dW.
+// Deterministic: per-workgroup partials in the workspace (mcl_conv0_wrw_workspace_floats floats) + a fixed-order merge
+// launch; accumulate_w != 0 adds into dW.
 extern "C" int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W) {
   if (N <= 0 || H <= 0 || W <= 0) return -1;
   const int ntile = N * (H / 4);
@@ -1272,7 +1075,7 @@ extern "C" int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t 
 extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* workspace, float* dW,
                              int32_t accumulate_w, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!x || !dy || !dW || N <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
+  if (!x || !dy || !dW || !workspace || N <= 0 || H <= 0 || W <= 0) return MCL_EINVAL;
   if ((H % 4) || (W % 8) || W > 256 || (reinterpret_cast<uintptr_t>(x) & 15u) || (reinterpret_cast<uintptr_t>(dy) & 15u) ||
       (reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(dW) & 15u))
     return MCL_EUNSUPPORTED;
@@ -1287,16 +1090,10 @@ extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, con
     attr_set = true;
   }
   hipStream_t st = mcl_stream(stream);
-  if (!workspace) {
-    if (!accumulate_w) return MCL_EINVAL;
-    hipLaunchKernelGGL(conv0_wrw_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H,
-                       W, (const bf16_t*)dy, dW, ntile, (float*)nullptr);
-  } else {
-    const int grid = ntile < 256 ? ntile : 256;
-    hipLaunchKernelGGL(conv0_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H, W,
-                       (const bf16_t*)dy, dW, ntile, workspace);
-    mcl_launch_wrw_merge(workspace, grid, (long long)C0_OUT * C0_K * 21, dW, accumulate_w, st);
-  }
+  const int grid = ntile < 256 ? ntile : 256;
+  hipLaunchKernelGGL(conv0_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H, W,
+                     (const bf16_t*)dy, dW, ntile, workspace);
+  mcl_launch_wrw_merge(workspace, grid, (long long)C0_OUT * C0_K * 21, dW, accumulate_w, st);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dgb_kernel(const float* __r
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ rstd,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                int rows, int cols) {
+                                                                int rows, int cols, int accumulate) {
   __shared__ float sg[4][64], sb[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -87,13 +87,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dgb_kernel(const float* __r
   sb[grp][lane] = ab;
   __syncthreads();
   if (grp == 0 && c < cols) {
-    dgamma[c] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
-    dbeta[c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+    const float g = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    const float b = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+    dgamma[c] = accumulate ? dgamma[c] + g : g;          // += : straight into the parameters' .grad (no AccumulateGrad add)
+    dbeta[c] = accumulate ? dbeta[c] + b : b;
   }
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx,
-                                                     float* __restrict__ out, int rows, int cols) {
+                                                     float* __restrict__ out, int rows, int cols, int accumulate) {
   __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
@@ -102,7 +104,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     for (int r = grp; r < rows; r += 4) a += x[(long long)r * ldx + c];
   sm[grp][lane] = a;
   __syncthreads();
-  if (grp == 0 && c < cols) out[c] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+  if (grp == 0 && c < cols) {
+    const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    out[c] = accumulate ? out[c] + v : v;
+  }
 }
 
 __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ s, long long ld, int n_rows,
@@ -152,23 +157,25 @@ extern "C" int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
 
 extern "C" int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, const float* dx_add, int64_t ldadd,
-                                 float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t rows, int32_t cols,
-                                 mcl_stream_t stream) {
+                                 float* dx, int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate_params,
+                                 int32_t rows, int32_t cols, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipStream_t st = mcl_stream(stream);
   hipLaunchKernelGGL(layernorm_bwd_dgb_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd,
-                     dgamma, dbeta, rows, cols);
+                     dgamma, dbeta, rows, cols, accumulate_params);
   hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st, dy,
                      lddy, x, ldx, gamma, mean, rstd, dx_add, ldadd, dx, lddx, rows, cols);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
 
-extern "C" int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, mcl_stream_t stream) {
+extern "C" int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate,
+                          mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!x || !out || rows <= 0 || cols <= 0) return MCL_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, mcl_stream(stream), x, ldx, out, rows, cols);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, mcl_stream(stream), x, ldx, out, rows, cols,
+                     accumulate);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -14,7 +14,10 @@ kernels.  Here:
   * BN+ReLU forward is one read + one write (csrc/bnrelu.hip); BN+ReLU backward is a reduce pass and a
     dx pass that ACCUMULATES in place into the block's gradient buffer, replacing autograd's per-layer
     slice gradients and their add chain;
-  * convolutions stay on MIOpen (``aten.convolution`` / ``aten.convolution_backward``).
+  * in bf16 every convolution, its data gradient and its weight gradient run on the hand-written kernels of
+    csrc/dense_conv.hip, conv3x3_rows.hip, dense_bwd.hip and wrw_fused.hip (a bf16 tensor reaching a library path raises,
+    see ``_fallback``); with fp32 activations (``backbone_dtype=None``, the reference-numerics mode) the convolutions are
+    ``aten.convolution`` / ``aten.convolution_backward`` calls between the same BatchNorm kernels.
 
 Train-mode semantics of nn.BatchNorm2d are kept: batch statistics, running_mean / running_var (unbiased)
 / num_batches_tracked updates with momentum 0.1 (batched with torch._foreach ops at the end of forward).
@@ -41,7 +44,16 @@ _ws_cache = {}
 _fallbacks: dict = {}
 
 
-def _fallback(site: str) -> None:
+ALLOW_LIBRARY_FALLBACK = os.environ.get("MCL_ALLOW_LIBRARY_FALLBACK", "0") == "1"
+
+
+def _fallback(site: str, t: Optional[Tensor] = None) -> None:
+    """A bf16 tensor reaching a library path means a shape / layout the hand-written kernels do not cover: that is an error
+    (a drop-in that silently changes backend is a dual path), unless MCL_ALLOW_LIBRARY_FALLBACK=1.  fp32 activations
+    (``backbone_dtype=None``: the reference-numerics mode) run their convolutions on the library by design."""
+    if t is not None and t.dtype == torch.bfloat16 and not ALLOW_LIBRARY_FALLBACK:
+        raise RuntimeError(f"densenet_fused: '{site}' would leave the HIP kernels for a library call on the bf16 path "
+                           f"(tensor {tuple(t.shape)}); set MCL_ALLOW_LIBRARY_FALLBACK=1 to permit it")
     _fallbacks[site] = _fallbacks.get(site, 0) + 1
 
 
@@ -113,7 +125,14 @@ def bn_act_fwd(x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tenso
 
 
 def _direct_grad_ok(p: Tensor) -> bool:
+    """True when the backward kernels may add this parameter's gradient straight into ``p.grad``.  A parameter whose
+    .grad is None -- the state torch.optim.*.zero_grad() (set_to_none) leaves behind, /root/reference/train.py:37 -- gets a
+    zero-filled dense fp32 .grad here, so the reference's own ``Adam`` + ``zero_grad()`` + ``backward()`` loop stays on the
+    HIP weight-gradient kernels (they accumulate; nothing is handed back to autograd)."""
     g = getattr(p, "grad", None)
+    if (g is None and DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_cuda
+            and p.dtype == torch.float32):
+        p.grad = g = torch.zeros_like(p)              # preserve_format: same strides as the parameter
     return (g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape
             and g.stride() == p.stride() and not g.requires_grad)
 
@@ -215,30 +234,19 @@ class _BlockStats:
         self.rstd = torch.empty(c_total, device=device, dtype=torch.float32)
 
 
-# 1x1 convolutions on channels-last activations are plain GEMMs over the (S, C) row view: route them to
-# hipBLASLt (torch.mm) instead of MIOpen's implicit-GEMM solvers (whose split-K weight-gradient kernels
-# also need zero-fill / cast helper passes).  Toggle for A/B measurements.
-USE_MM_1X1 = False   # measured r01: hipBLASLt 40.1 ms/step vs MIOpen igemm 29.7 ms/step on the N=128 skinny GEMMs
-
-
 def _as2d(t: Tensor) -> Tensor:
     B, C, H, W = t.shape
     return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
 
 
 def _conv1x1_fwd(a: Tensor, w: Tensor) -> Tensor:
-    if not USE_MM_1X1:
-        _fallback("conv1x1_fwd:miopen")
-        return F.conv2d(a, w).contiguous(memory_format=CL)
-    B, C, H, W = a.shape
-    z = torch.mm(_as2d(a), w.reshape(w.shape[0], C).t())
-    return z.view(B, H, W, w.shape[0]).permute(0, 3, 1, 2)
+    """fp32 activations only (library convolution)."""
+    _fallback("conv1x1_fwd:miopen", a)
+    return F.conv2d(a, w).contiguous(memory_format=CL)
 
 
-USE_HIP_WRW_1X1 = os.environ.get("MCL_HIP_WRW", "1") != "0"
 # norm1 + relu1 + conv1 + norm2-statistics of a dense layer as ONE kernel (csrc/dense_conv.hip): the normalised
 # input `a` is never materialised (the weight-gradient kernel recomputes it from the concat buffer).
-USE_FUSED_1X1 = os.environ.get("MCL_FUSED_1X1", "1") != "0"
 
 
 def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, w16: Tensor, eps2: float,
@@ -258,7 +266,6 @@ def dense_conv1x1_fwd(x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Ten
 
 
 # conv1 backward-data + norm1/relu1 backward as two GEMM-recomputing launches (csrc/dense_bwd.hip)
-USE_FUSED_BN1_BWD = os.environ.get("MCL_FUSED_BN1_BWD", "1") != "0"
 
 
 def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
@@ -322,7 +329,6 @@ def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor,
 
 
 # conv2 (3x3) backward-data + norm2/relu2 backward (csrc/dense_bwd.hip): dy is read in place from the gradient buffer
-USE_FUSED_BN2_BWD = os.environ.get("MCL_FUSED_BN2_BWD", "1") != "0"
 
 
 def dense_conv3x3_bwd(dy: Tensor, w16: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor,
@@ -348,7 +354,6 @@ def dense_conv3x3_bwd(dy: Tensor, w16: Tensor, z: Tensor, g2: Tensor, b2: Tensor
 
 
 # norm2 + relu2 + conv2 (3x3) + the new feature map's statistics as ONE kernel writing into the concat buffer
-USE_FUSED_3X3 = os.environ.get("MCL_FUSED_3X3", "1") != "0"
 
 
 def dense_conv3x3_fwd(z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor, w16: Tensor, out: Tensor, eps: float,
@@ -365,58 +370,61 @@ def dense_conv3x3_fwd(z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor,
                                   nz(yrstd), _stream()), "mcl_dense_conv3x3_fwd")
 
 
+def _grad_target_khwc(w_param: Tensor) -> Tuple[Tensor, bool]:
+    """The weight-gradient kernels write (C_out, kh, kw, C_in)-contiguous fp32.  A channels-last parameter's .grad (what
+    train.py / bench.py hold: ``model.to(memory_format=channels_last)``) IS that layout and is accumulated in place; for a
+    default-contiguous (NCHW) parameter the kernel fills a temporary that ``_grad_finish_khwc`` adds into .grad."""
+    g = w_param.grad
+    if g.permute(0, 2, 3, 1).is_contiguous():
+        return g, True
+    co, ci, kh, kw = w_param.shape
+    return torch.empty((co, kh, kw, ci), device=g.device, dtype=torch.float32), False
+
+
+def _grad_finish_khwc(w_param: Tensor, tgt: Tensor, in_place: bool) -> None:
+    if not in_place:
+        w_param.grad.add_(tgt.permute(0, 3, 1, 2))
+
+
 def dense_conv3x3_wrw(dy: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor, w_param: Tensor) -> bool:
     """Adds the 3x3 weight gradient (a2 = relu(bn2(z)) recomputed in-kernel) straight into ``w_param.grad``.
-    Returns False (nothing done) when the parameter has no dense channels-last fp32 .grad to accumulate into."""
-    if not (USE_FUSED_3X3 and DIRECT_PARAM_GRADS and _direct_grad_ok(w_param)
-            and w_param.grad.permute(0, 2, 3, 1).is_contiguous() and tuple(w_param.shape) == (32, 128, 3, 3)
-            and dy.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and z.is_contiguous(memory_format=CL)):
+    Returns False (nothing done) when the parameter cannot take a dense fp32 .grad or the operands are not bf16."""
+    if not _wrw3_direct_ok(w_param, z, dy):
         return False
     B, C, H, W = z.shape
     pd, S, Co, lddy = _rows(dy)
     assert Co == 32 and S == B * H * W
     L = _lib.lib()
-    if USE_DET_WRW:
-        # the side stream has its own workspace (keyed by stream in _ws): no aliasing with the main chain's
-        ws = _ws(L.mcl_dense_conv3x3_wrw_workspace_floats(S), z.device)
-        check(L.mcl_dense_conv3x3_wrw_det(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(), m2.data_ptr(),
-                                          r2.data_ptr(), ws.data_ptr(), w_param.grad.data_ptr(), 1, _stream()),
-              "mcl_dense_conv3x3_wrw_det")
-        return True
-    check(L.mcl_dense_conv3x3_wrw(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(),
-                                  m2.data_ptr(), r2.data_ptr(), w_param.grad.data_ptr(), _stream()),
-          "mcl_dense_conv3x3_wrw")
+    tgt, in_place = _grad_target_khwc(w_param)
+    # the side stream has its own workspace (keyed by stream in _ws): no aliasing with the main chain's
+    ws = _ws(L.mcl_dense_conv3x3_wrw_workspace_floats(S), z.device)
+    check(L.mcl_dense_conv3x3_wrw_det(pd, lddy, z.data_ptr(), S, H, W, g2.data_ptr(), b2.data_ptr(), m2.data_ptr(),
+                                      r2.data_ptr(), ws.data_ptr(), tgt.data_ptr(), int(in_place), _stream()),
+          "mcl_dense_conv3x3_wrw_det")
+    _grad_finish_khwc(w_param, tgt, in_place)
     return True
 
 
 def _wrw3_direct_ok(w_param: Tensor, z: Tensor, dy: Tensor) -> bool:
-    """dense_conv3x3_wrw's precondition (it accumulates straight into w_param.grad)."""
-    return (USE_FUSED_3X3 and DIRECT_PARAM_GRADS and _direct_grad_ok(w_param)
-            and w_param.grad.permute(0, 2, 3, 1).is_contiguous() and tuple(w_param.shape) == (32, 128, 3, 3)
+    """dense_conv3x3_wrw's precondition (it accumulates into w_param.grad)."""
+    return (DIRECT_PARAM_GRADS and _direct_grad_ok(w_param) and tuple(w_param.shape) == (32, 128, 3, 3)
             and dy.dtype == torch.bfloat16 and z.dtype == torch.bfloat16 and z.is_contiguous(memory_format=CL))
 
 
-# "block": one fork per layer, one join per dense block; "layer": fork + join per layer (first version)
-SIDE_MODE = os.environ.get("MCL_SIDE_MODE", "block")
-
-
 def _fused_3x3_ok(z: Tensor, w16: Tensor) -> bool:
-    return (USE_FUSED_3X3 and z.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16
+    return (z.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16
             and tuple(w16.shape) == (32, 128, 3, 3) and w16.permute(0, 2, 3, 1).is_contiguous()
             and z.shape[1] == 128 and z.shape[3] <= 150 and z.is_contiguous(memory_format=CL))
 
 
 def _fused_1x1_ok(x: Tensor, w16: Tensor) -> bool:
-    return (USE_FUSED_1X1 and x.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.shape[0] == 128
+    return (x.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and w16.shape[0] == 128
             and w16.shape[1] % 8 == 0 and w16.shape[1] <= 1024 and w16.shape[2:] == (1, 1)
             and w16.permute(0, 2, 3, 1).is_contiguous())
 
 
-USE_DET_WRW = os.environ.get("MCL_DET_WRW", "1") != "0"      # atomics-free weight-gradient kernels (A/B: 0 = round-1 atomics)
-
-
 def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Tensor]:
-    """Weight gradient of a 1x1 convolution through csrc/conv1x1.hip.  Adds straight into ``w_param.grad``
+    """Weight gradient of a 1x1 convolution (csrc/wrw_fused.hip, atomics-free).  Adds straight into ``w_param.grad``
     when it is a dense fp32 tensor (returns None), else returns a fresh fp32 gradient.  ``bn`` = (gamma, beta,
     mean, rstd): ``a`` is then the layer INPUT (concat-buffer slice) and relu(bn(a)) is recomputed in-kernel."""
     pz, S, M, ldz = _rows(dz)
@@ -428,14 +436,10 @@ def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Ten
         tgt = torch.zeros((M, N, 1, 1), device=dz.device, dtype=torch.float32)
         ret = tgt
     g_, b_, m_, r_ = (t.data_ptr() for t in bn) if bn is not None else (None, None, None, None)
-    if USE_DET_WRW:
-        L = _lib.lib()
-        ws = _ws(L.mcl_wrw_workspace_floats(S, min(M, 128), N), dz.device)
-        check(L.mcl_conv1x1_wrw_det(pz, ldz, pa, lda, g_, b_, m_, r_, ws.data_ptr(), tgt.data_ptr(), 1, S, M, N,
-                                    _stream()), "mcl_conv1x1_wrw_det")
-        return ret
-    check(_lib.lib().mcl_conv1x1_wrw_bf16(pz, ldz, pa, lda, g_, b_, m_, r_, tgt.data_ptr(), N, S, M, N, _stream()),
-          "mcl_conv1x1_wrw_bf16")
+    L = _lib.lib()
+    ws = _ws(L.mcl_wrw_workspace_floats(S, min(M, 128), N), dz.device)
+    check(L.mcl_conv1x1_wrw_det(pz, ldz, pa, lda, g_, b_, m_, r_, ws.data_ptr(), tgt.data_ptr(), 1, S, M, N,
+                                _stream()), "mcl_conv1x1_wrw_det")
     return ret
 
 
@@ -446,22 +450,12 @@ def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Optional[Tensor] = N
         assert dz.dtype == torch.bfloat16 and w_param is not None
         # the data gradient needs only dz and w: a transposed convolution IS the backward-data kernel and, unlike
         # aten.convolution_backward, does not make a contiguous copy of the (channel-sliced) layer input first
-        _fallback("conv1x1_bwd_data:miopen")
+        _fallback("conv1x1_bwd_data:miopen", dz)
         da = F.conv_transpose2d(dz, w)
         return da.contiguous(memory_format=CL), ("direct", conv1x1_wrw(dz, a, w_param, bn=bn))
-    if not USE_MM_1X1:
-        _fallback("conv1x1_bwd:miopen")
-        if USE_HIP_WRW_1X1 and w_param is not None and dz.dtype == torch.bfloat16:
-            da = torch.ops.aten.convolution_backward(dz, a, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                     [True, False, False])[0]
-            return da.contiguous(memory_format=CL), ("direct", conv1x1_wrw(dz, a, w_param))
-        da, dw, _ = _conv_bwd(dz, a, w, 0)
-        return da.contiguous(memory_format=CL), dw
-    B, C, H, W = a.shape
-    dz2, a2 = _as2d(dz), _as2d(a)
-    da = torch.mm(dz2, w.reshape(w.shape[0], C)).view(B, H, W, C).permute(0, 3, 1, 2)
-    dw = torch.mm(dz2.t(), a2).view(w.shape[0], C, 1, 1)
-    return da, dw
+    _fallback("conv1x1_bwd:miopen", dz)                   # fp32 activations: library convolution backward
+    da, dw, _ = _conv_bwd(dz, a, w, 0)
+    return da.contiguous(memory_format=CL), dw
 
 
 def _same_order(a: Tensor, b: Tensor) -> bool:
@@ -493,7 +487,7 @@ _weight_provider = None
 
 def set_weight_provider(fn) -> None:
     global _weight_provider
-    _weight_provider = fn if os.environ.get("MCL_BF16_SHADOW", "1") != "0" else None
+    _weight_provider = fn
 
 
 def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
@@ -507,7 +501,7 @@ def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
 
 
 def _conv_bwd(dy, x, w, padding):
-    _fallback("conv_bwd:miopen")
+    _fallback("conv_bwd:miopen", dy)
     return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [padding, padding], [1, 1], False, [0, 0], 1,
                                                [True, True, False])
 
@@ -544,6 +538,13 @@ def _side_join(device) -> None:
     if parked:
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
         parked.clear()
+
+
+# Test instrumentation (tests/test_layerwise_gpu.py): a list that receives, per dense block, the tensors every fused layer
+# kernel of the block consumed and produced (forward: concat buffer, statistics, z; backward: incoming gradient buffer, dz
+# per layer, final gradient buffer), so that each kernel can be checked against an fp64 evaluation of exactly its inputs
+# at the benched shapes.  None (the default) = nothing is recorded.
+CAPTURE_BLOCKS: Optional[list] = None
 
 
 class DenseBlockFn(torch.autograd.Function):
@@ -595,7 +596,7 @@ class DenseBlockFn(torch.autograd.Function):
             else:
                 a2 = torch.empty_like(z, memory_format=CL)
                 bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-                _fallback("conv3x3_fwd:miopen")
+                _fallback("conv3x3_fwd:miopen", z)
                 y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
                 bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
                          copy_out=buf[:, cin:c1])
@@ -604,6 +605,11 @@ class DenseBlockFn(torch.autograd.Function):
         ctx.save_for_backward(buf, *saved, *wcast)
         ctx.params = params             # Parameter objects (for direct .grad accumulation)
         ctx.meta = (stats, growth, bn2_stats, L, C0)
+        ctx.cap = None
+        if CAPTURE_BLOCKS is not None:
+            ctx.cap = {"buf": buf, "C0": C0, "growth": growth, "params": params, "wcast": wcast,
+                       "mean": stats.mean, "rstd": stats.rstd, "var": stats.var, "z": saved[1::3], "bn2": bn2_stats}
+            CAPTURE_BLOCKS.append(ctx.cap)
         return buf
 
     @staticmethod
@@ -618,6 +624,10 @@ class DenseBlockFn(torch.autograd.Function):
         # in place into it (no clone) when it is already a dense channels-last tensor
         if not gbuf.is_contiguous(memory_format=CL):
             gbuf = gbuf.contiguous(memory_format=CL)
+        if ctx.cap is not None:
+            ctx.cap["gin"] = gbuf.clone(memory_format=CL)
+            ctx.cap["dz"] = [None] * L
+            ctx.cap["gbuf"] = gbuf
         grads = [None] * (6 * L)
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
@@ -628,11 +638,11 @@ class DenseBlockFn(torch.autograd.Function):
             d2 = DIRECT_PARAM_GRADS and _direct_grad_ok(g2) and _direct_grad_ok(b2)
             dy_view = gbuf[:, cin:cin + growth]
             dw2_done = False
-            fused2 = a2.numel() == 0 and USE_FUSED_BN2_BWD and _fused_3x3_ok(z, w2c)
-            fused1 = a.numel() == 0 and USE_FUSED_BN1_BWD
+            fused2 = a2.numel() == 0 and _fused_3x3_ok(z, w2c)
+            fused1 = a.numel() == 0
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
-            if side is not None and SIDE_MODE == "block" and _wrw3_direct_ok(w2, z, dy_view):
+            if side is not None and _wrw3_direct_ok(w2, z, dy_view):
                 # Main chain first, ONE fork per layer, ONE join per block.  Every cross-stream edge of the captured graph
                 # costs the waiting side ~16 us (tools/trace_gaps.py): the per-layer fork + join of the first version
                 # left the GPU idle for 2.4 ms/step.  Here the critical chain (conv3x3_bwd -> bn2_dz -> bn1_bwd) never
@@ -640,6 +650,8 @@ class DenseBlockFn(torch.autograd.Function):
                 # exists (event) and are joined only at the end of the block; dz stays referenced until then.
                 d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
+                if ctx.cap is not None:
+                    ctx.cap["dz"][l] = dz
                 ev = torch.cuda.Event()
                 ev.record(main)
                 fused_wrw = _bn1_wrw_ok(w1) and dz.shape[0] * dz.shape[2] * dz.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS
@@ -763,12 +775,11 @@ def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats, stats: Optional[_
 
 
 # --------------------------------------------------------------------------- stem convolution (csrc/dense_conv.hip)
-USE_HIP_CONV0 = os.environ.get("MCL_HIP_CONV0", "1") != "0"
 
 
 def _conv0_ok(x: Tensor, conv: nn.Conv2d) -> bool:
     B, C, H, W = x.shape
-    return (USE_HIP_CONV0 and x.is_cuda and x.dtype == torch.bfloat16 and C == 3 and H % 4 == 0 and W % 8 == 0
+    return (x.is_cuda and x.dtype == torch.bfloat16 and C == 3 and H % 4 == 0 and W % 8 == 0
             and W <= 256 and x.is_contiguous(memory_format=CL) and tuple(conv.weight.shape) == (64, 3, 7, 7)
             and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.bias is None and not x.requires_grad)
 
@@ -805,25 +816,25 @@ class Conv0Fn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=CL)
         w = ctx.w
         B, _, H, W = x.shape
-        if (DIRECT_PARAM_GRADS and _direct_grad_ok(w) and w.grad.permute(0, 2, 3, 1).is_contiguous()
-                and dy.dtype == torch.bfloat16):
+        if DIRECT_PARAM_GRADS and _direct_grad_ok(w) and dy.dtype == torch.bfloat16:
             L = _lib.lib()
-            ws = _ws(L.mcl_conv0_wrw_workspace_floats(B, H, W), x.device) if USE_DET_WRW else None
-            check(L.mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), None if ws is None else ws.data_ptr(),
-                                  w.grad.data_ptr(), 1, _stream()), "mcl_conv0_wrw")   # straight into the fp32 .grad
+            ws = _ws(L.mcl_conv0_wrw_workspace_floats(B, H, W), x.device)
+            tgt, in_place = _grad_target_khwc(w)
+            check(L.mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), ws.data_ptr(), tgt.data_ptr(), int(in_place),
+                                  _stream()), "mcl_conv0_wrw")                          # straight into the fp32 .grad
+            _grad_finish_khwc(w, tgt, in_place)
             return None, None, None
-        _fallback("conv0_wrw:miopen")
+        _fallback("conv0_wrw:miopen", dy)
         dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                  [False, True, False])[1]
         return None, _wgrad(ctx.w, dw), None
 
 
 # --------------------------------------------------------------------------- pooling (csrc/pool.hip)
-USE_HIP_POOLS = os.environ.get("MCL_HIP_POOLS", "1") != "0"
 
 
 def _pool_ok(x: Tensor, even: bool) -> bool:
-    return (USE_HIP_POOLS and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0
             and x.is_contiguous(memory_format=CL) and (not even or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)))
 
 
@@ -902,24 +913,23 @@ class StemTailFn(torch.autograd.Function):
         return g, dg, db, None, None
 
 
-USE_FUSED_STEM_TAIL = os.environ.get("MCL_FUSED_STEM_TAIL", "1") != "0"
 
 
 def _stem_tail_ok(x: Tensor) -> bool:
-    return USE_FUSED_STEM_TAIL and _pool_ok(x, False) and x.shape[1] <= 2048
+    return _pool_ok(x, False) and x.shape[1] <= 2048
 
 
 def max_pool_3s2(x: Tensor) -> Tensor:
     if _pool_ok(x, False):
         return MaxPool3s2Fn.apply(x)
-    _fallback("maxpool:aten")
+    _fallback("maxpool:aten", x)
     return F.max_pool2d(x, 3, 2, 1)
 
 
 def avg_pool_2(x: Tensor) -> Tensor:
     if _pool_ok(x, True):
         return AvgPool2Fn.apply(x)
-    _fallback("avgpool:aten")
+    _fallback("avgpool:aten", x)
     return F.avg_pool2d(x, 2, 2)
 
 
@@ -929,7 +939,6 @@ def avg_pool_2(x: Tensor) -> Tensor:
 # convolution, its weight gradient and its data gradient all run on a QUARTER of the pixels, on the same kernels as
 # the dense layers' bottleneck convolution (identity BN prologue: p >= 0 so relu(1*p + 0) == p); its epilogue yields
 # the batch statistics the next block's norm1 layers need, so that pass disappears too.
-USE_FUSED_TRANSITION = os.environ.get("MCL_FUSED_TRANSITION", "1") != "0"
 _ident_cache = {}
 
 
@@ -971,7 +980,7 @@ def pooled_conv1x1_fwd(p: Tensor, w16: Tensor, eps: float, stats: Optional[_Bloc
 def _transition_ok(buf: Tensor, w: Tensor) -> bool:
     B, C, H, W = buf.shape
     # odd maps (her2st: 112 px patches reach 7 x 7 at the last transition) pool with floor, like nn.AvgPool2d(2, 2)
-    return (USE_FUSED_TRANSITION and USE_FUSED_1X1 and buf.is_cuda and buf.dtype == torch.bfloat16 and H >= 2
+    return (buf.is_cuda and buf.dtype == torch.bfloat16 and H >= 2
             and W >= 2 and C % 8 == 0 and C <= 1024 and w.shape[0] % 128 == 0 and w.shape[1] == C
             and buf.is_contiguous(memory_format=CL))
 
@@ -1000,7 +1009,7 @@ class TransitionFn(torch.autograd.Function):
         Co = w16.shape[0]
         _rows(dy)                                             # channels-last (possibly channel-sliced) view
         main = torch.cuda.current_stream()
-        deferred = (USE_SIDE_STREAM and SIDE_MODE == "block" and DIRECT_PARAM_GRADS and _direct_grad_ok(w)
+        deferred = (USE_SIDE_STREAM and DIRECT_PARAM_GRADS and _direct_grad_ok(w)
                     and w.grad.is_contiguous())
         if deferred:
             ev = torch.cuda.Event()
@@ -1049,7 +1058,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
         mean0, var0, rstd0 = (torch.empty(64, device=x.device, dtype=torch.float32) for _ in range(3))
         x = Conv0Fn.apply(x, features.conv0.weight, (features.norm0.eps, (mean0, var0, rstd0)))
     else:
-        _fallback("conv0_fwd:miopen")
+        _fallback("conv0_fwd:miopen", x)
         x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                      padding=features.conv0.padding)
     x = x.contiguous(memory_format=CL)
@@ -1084,7 +1093,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
                                        (stats, next_stats, nxt[0].norm1.eps))
             else:
                 a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
-                _fallback("transition:miopen")
+                _fallback("transition:miopen", buf)
                 x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
                 x = avg_pool_2(x.contiguous(memory_format=CL))
         else:
@@ -1123,7 +1132,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
     if _conv0_ok(x, features.conv0):
         x = conv0_fwd(x, _weight(features.conv0.weight, act_dtype), features.norm0.eps, None)
     else:
-        _fallback("eval.conv0_fwd:miopen")
+        _fallback("eval.conv0_fwd:miopen", x)
         x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
                      padding=features.conv0.padding)
     x = x.contiguous(memory_format=CL)
@@ -1149,7 +1158,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 dense_conv3x3_fwd(z, ly.norm2.weight, ly.norm2.bias, ly.norm2.running_mean, rs[id(ly.norm2)], w2c,
                                   buf[:, cin:cin + growth], ly.norm1.eps, None, None, None)
             else:
-                _fallback("eval.dense_layer:miopen")
+                _fallback("eval.dense_layer:miopen", buf)
                 a = affine(buf[:, :cin], ly.norm1, True)
                 z = affine(_conv1x1_fwd(a, w1c), ly.norm2, True)
                 buf[:, cin:cin + growth].copy_(F.conv2d(z, w2c, padding=1))
@@ -1159,7 +1168,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 p = bn_act_avgpool_fwd(buf, tr.norm.weight, tr.norm.bias, tr.norm.running_mean, rs[id(tr.norm)])
                 x = pooled_conv1x1_fwd(p, _weight(tr.conv.weight, act_dtype), tr.norm.eps, None)
             else:
-                _fallback("eval.transition:miopen")
+                _fallback("eval.transition:miopen", buf)
                 a = affine(buf, tr.norm, True)
                 x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
         else:

@@ -1,44 +1,20 @@
-"""Algorithmic HBM bytes of the hot C-ABI launch units of the training step.
+"""Algorithmic HBM bytes and FLOPs of the hot C-ABI launch units of the training step.
 
-``TABLE[abi_name] = {"kernels": "<kernel names the call enqueues>", "bytes": f(args) -> bytes of ONE call}`` where
-``args`` is the argument tuple of the ctypes call (positions as in ``_lib.PROTOTYPES`` / include/mclstexp_hip.h).
-"Algorithmic" = every operand element read once and every result element written once, at the element sizes the
-kernel is specified for (bf16 activations, fp32 parameters / statistics); re-reads, partial sums and workspaces
-are NOT counted -- they are what ``roofline.traffic`` (PMC counters) exposes.
+``TABLE[abi_name] = {"kernels": ..., "bytes": f(args), "strict": f(args), "flops": f(args), "bound": ...}`` where ``args``
+is the argument tuple of the ctypes call (positions as in ``_lib.PROTOTYPES`` / include/mclstexp_hip.h).
 
+* ``bytes``  -- "algorithmic" as the launch unit is BUILT: every operand element read once and every result element
+  written once PER PASS (a unit made of two kernels that hand a tensor over through HBM counts it written and re-read).
+* ``strict`` -- single-pass bytes: every distinct operand / result element once, whatever the unit's internal passes.
+* ``flops``  -- 2 x MACs of the contraction the unit performs (0 for the streaming units).
+* ``bound``  -- which roofline the unit is priced against first: "mfma/lds" (the 3x3 family: MFMA- and LDS-paced), "hbm",
+  or None = decided per launch (bench.py labels a unit "latency" when its working set is < 256 MB -- it lives in the
+  Infinity Cache -- and its average launch is < 30 us).
+
+Re-reads, partial sums and workspaces are NOT counted -- they are what ``roofline.traffic`` (PMC counters) exposes.
 Used by bench.py (`roofline`), tools/pmc_summary.py and the DESIGN.md tables; nothing here touches the GPU.
 """
 from __future__ import annotations
-
-
-def _conv1x1_wrw(a):            # (dz, ldz, a, lda, gamma, beta, mean, rstd, dW, lddw, S, M, N, stream)
-    S, M, N = a[10], a[11], a[12]
-    return 2 * S * (M + N) + 4 * M * N
-
-
-def _conv3x3_wrw(a):            # (dy, lddy, z, S, H, W, gamma, beta, mean, rstd, dW, stream)
-    S = a[3]
-    return 2 * S * (32 + 128) + 4 * 32 * 1152
-
-
-def _bn1_bwd(a):                # (dz, w16, C, x, ldx, S, ...): reduce pass reads dz + x; dx pass reads dz + x + g, writes g
-    C, S = a[2], a[5]
-    return 2 * S * (128 + C) + 2 * S * (128 + 3 * C)
-
-
-def _conv3x3_bwd(a):            # (dy, lddy, S, H, W, ...): dy + z read, da2 written; then da2 + z read, dz written
-    S = a[2]
-    return 2 * S * (32 + 128 + 128) + 2 * S * (128 + 128 + 128)
-
-
-def _conv1x1_fwd(a):            # (x, ldx, S, K, ...)
-    S, K = a[2], a[3]
-    return 2 * S * (K + 128)
-
-
-def _conv3x3_fwd(a):            # (z, S, H, W, ...)
-    S = a[1]
-    return 2 * S * (128 + 32)
 
 
 def _conv1x1_wrw_det(a):        # (dz, ldz, a, lda, gamma, beta, mean, rstd, ws, dW, acc, S, M, N, stream)
@@ -46,14 +22,71 @@ def _conv1x1_wrw_det(a):        # (dz, ldz, a, lda, gamma, beta, mean, rstd, ws,
     return 2 * S * (M + N) + 4 * M * N
 
 
+def _conv1x1_wrw_det_flops(a):
+    return 2 * a[11] * a[12] * a[13]
+
+
 def _conv3x3_wrw_det(a):        # (dy, lddy, z, S, H, W, gamma, beta, mean, rstd, ws, dW, acc, stream)
     S = a[3]
     return 2 * S * (32 + 128) + 4 * 32 * 1152
 
 
+def _conv3x3_flops_S3(a):
+    return 2 * a[3] * 32 * 1152
+
+
+def _bn1_bwd(a):                # (dz, w16, C, x, ldx, S, ...): reduce pass reads dz + x; dx pass reads dz + x + g, writes g
+    C, S = a[2], a[5]
+    return 2 * S * (128 + C) + 2 * S * (128 + 3 * C)
+
+
+def _bn1_bwd_strict(a):         # dz, x, g read once, g written once
+    C, S = a[2], a[5]
+    return 2 * S * (128 + 3 * C)
+
+
+def _bn1_flops(a):              # g = dz W1 per pass
+    return 2 * a[5] * 128 * a[2]
+
+
+def _conv3x3_bwd(a):            # (dy, lddy, S, H, W, ...): dy + z read, da2 written; then da2 + z read, dz written
+    S = a[2]
+    return 2 * S * (32 + 128 + 128) + 2 * S * (128 + 128 + 128)
+
+
+def _conv3x3_bwd_strict(a):     # dy + z read, dz written
+    return 2 * a[2] * (32 + 128 + 128)
+
+
+def _conv3x3_flops_S2(a):
+    return 2 * a[2] * 32 * 1152
+
+
+def _conv1x1_fwd(a):            # (x, ldx, S, K, ...)
+    S, K = a[2], a[3]
+    return 2 * S * (K + 128)
+
+
+def _conv1x1_fwd_flops(a):
+    return 2 * a[2] * a[3] * 128
+
+
+def _conv3x3_fwd(a):            # (z, S, H, W, ...)
+    S = a[1]
+    return 2 * S * (128 + 32)
+
+
+def _conv3x3_flops_S1(a):
+    return 2 * a[1] * 32 * 1152
+
+
 def _bn1_wrw(a):                # (dz, W1, C, x, ldx, S, ...): dz + x read once, dW1 written
     C, S = a[2], a[5]
     return 2 * S * (128 + C) + 4 * 128 * C
+
+
+def _bn1_wrw_flops(a):          # two Gram matrices
+    return 2 * 2 * a[5] * 128 * a[2]
 
 
 def _bn1_dx(a):                 # (dz, W1, C, x, ldx, S, ...): dz + x + g read, g written
@@ -69,17 +102,27 @@ def _adam(a):                   # (p, g, m, v, n, ...): read p, g, m, v; write p
     return 28 * a[4]
 
 
+def _zero(a):
+    return 0
+
+
+def _e(kernels, b, strict=None, flops=_zero, bound=None):
+    return {"kernels": kernels, "bytes": b, "strict": strict or b, "flops": flops, "bound": bound}
+
+
 TABLE = {
-    "mcl_conv1x1_wrw_det": {"kernels": "wrw_partial_kernel + wrw_merge_kernel", "bytes": _conv1x1_wrw_det},
-    "mcl_dense_conv3x3_wrw_det": {"kernels": "conv3x3_wrw_kernel (56x56 maps) / conv3x3_wrw_ky_kernel + wrw_merge_kernel", "bytes": _conv3x3_wrw_det},
-    "mcl_dense_bn1_wrw": {"kernels": "wrw_partial_kernel<Gram> + wrw_merge_kernel", "bytes": _bn1_wrw},
-    "mcl_dense_bn1_dx": {"kernels": "bn1_bwd_kernel<1>", "bytes": _bn1_dx},
-    "mcl_conv1x1_wrw_bf16": {"kernels": "conv1x1_wrw_kernel (atomics, A/B only)", "bytes": _conv1x1_wrw},
-    "mcl_dense_conv3x3_wrw": {"kernels": "conv3x3_wrw_kernel (atomics, A/B only)", "bytes": _conv3x3_wrw},
-    "mcl_dense_bn1_bwd": {"kernels": "bn1_bwd_kernel<0> + bn1_bwd_finalize_kernel + bn1_bwd_kernel<1>", "bytes": _bn1_bwd},
-    "mcl_dense_conv3x3_bwd": {"kernels": "conv3x3_bwd_kernel + finalize + bn2_dz_kernel", "bytes": _conv3x3_bwd},
-    "mcl_dense_conv1x1_fwd": {"kernels": "conv1x1_fwd_kernel + tile_stats_finalize_kernel", "bytes": _conv1x1_fwd},
-    "mcl_dense_conv3x3_fwd": {"kernels": "conv3x3_fwd_kernel + tile_stats_finalize_kernel", "bytes": _conv3x3_fwd},
-    "mcl_adam_table_step_dev": {"kernels": "adam_table_kernel", "bytes": _adam_table},
-    "mcl_adam_step_dev": {"kernels": "adam_kernel", "bytes": _adam},
+    "mcl_conv1x1_wrw_det": _e("wrw_partial_kernel + wrw_merge_kernel", _conv1x1_wrw_det, flops=_conv1x1_wrw_det_flops),
+    "mcl_dense_conv3x3_wrw_det": _e("conv3x3_wrw_ky_kernel + wrw_merge_kernel", _conv3x3_wrw_det, flops=_conv3x3_flops_S3,
+                                    bound="mfma/lds"),
+    "mcl_dense_bn1_wrw": _e("wrw_partial_kernel<Gram> + wrw_merge_kernel", _bn1_wrw, flops=_bn1_wrw_flops),
+    "mcl_dense_bn1_dx": _e("bn1_bwd_kernel<1>", _bn1_dx, flops=_bn1_flops),
+    "mcl_dense_bn1_bwd": _e("bn1_bwd_kernel<0> + bn1_bwd_finalize_kernel + bn1_bwd_kernel<1>", _bn1_bwd, _bn1_bwd_strict,
+                            flops=lambda a: 2 * _bn1_flops(a)),
+    "mcl_dense_conv3x3_bwd": _e("conv3x3_bwd_kernel + finalize + bn2_dz_kernel", _conv3x3_bwd, _conv3x3_bwd_strict,
+                                flops=_conv3x3_flops_S2, bound="mfma/lds"),
+    "mcl_dense_conv1x1_fwd": _e("conv1x1_fwd_kernel + tile_stats_finalize_kernel", _conv1x1_fwd, flops=_conv1x1_fwd_flops),
+    "mcl_dense_conv3x3_fwd": _e("conv3x3_fwd_rows_kernel + sums_finalize_kernel (56x56, 28x28 maps) / conv3x3_fwd_kernel + "
+                                "tile_stats_finalize_kernel", _conv3x3_fwd, flops=_conv3x3_flops_S1, bound="mfma/lds"),
+    "mcl_adam_table_step_dev": _e("adam_table_kernel", _adam_table, bound="hbm"),
+    "mcl_adam_step_dev": _e("adam_kernel", _adam, bound="hbm"),
 }

@@ -303,6 +303,13 @@ class _ContrastiveBase(nn.Module):
     def _fused_mode(self):
         return {"exact": False, "fused": True, "fp8": "fp8"}[self.infonce]
 
+    def infonce_effective(self, global_batch: int) -> str:
+        """The InfoNCE kernels a step at this GLOBAL batch actually runs: ``infonce="fused"`` takes the exact fp32 kernels
+        below ``ops.FUSED_MIN_BATCH`` pairs (they are faster AND exact there; same rule under data parallelism)."""
+        if self.infonce == "fused" and global_batch < ops.FUSED_MIN_BATCH:
+            return f"exact (fused from {ops.FUSED_MIN_BATCH} pairs)"
+        return self.infonce
+
 
     # ---- split form of forward(), used by engine.TrainStep (HIP-graph capture around the collectives)
     def embed(self, batch):

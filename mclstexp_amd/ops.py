@@ -149,10 +149,16 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, param: Optional[Tensor] = None) -> 
     return dW
 
 
-def colsum(x: Tensor) -> Tensor:
+def colsum(x: Tensor, param: Optional[Tensor] = None) -> Optional[Tensor]:
+    """Column sums (nn.Linear bias gradient).  With ``param`` (the bias Parameter) owning a dense fp32 .grad the sums are
+    ADDED straight into it and None is returned to autograd (no temporary, no AccumulateGrad add launch)."""
     x = _rowmajor(x, "x")
+    if param is not None and param.shape == (x.shape[1],) and _direct_grad_ok(param):
+        check(_lib.lib().mcl_colsum(x.data_ptr(), x.stride(0), param.grad.data_ptr(), x.shape[0], x.shape[1], 1, _stream()),
+              "mcl_colsum")
+        return None
     out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
-    check(_lib.lib().mcl_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], _stream()),
+    check(_lib.lib().mcl_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], 0, _stream()),
           "mcl_colsum")
     return out
 
@@ -171,19 +177,28 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = LN_EPS) -
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
-                  dx_add: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                  dx_add: Optional[Tensor] = None, params: Optional[Tuple[Tensor, Tensor]] = None
+                  ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    """``params`` = (weight, bias) Parameters: when both own a dense fp32 .grad, dgamma / dbeta are added straight into them
+    and (dx, None, None) is returned."""
     dy, x = _rowmajor(dy, "dy"), _rowmajor(x, "x")
     rows, cols = x.shape
     dx = torch.empty((rows, cols), device=x.device, dtype=torch.float32)
-    dg = torch.empty((cols,), device=x.device, dtype=torch.float32)
-    db = torch.empty((cols,), device=x.device, dtype=torch.float32)
+    direct = (params is not None and params[0].shape == (cols,) and params[1].shape == (cols,)
+              and _direct_grad_ok(params[0]) and _direct_grad_ok(params[1]))
+    if direct:
+        dg, db = params[0].grad, params[1].grad
+    else:
+        dg = torch.empty((cols,), device=x.device, dtype=torch.float32)
+        db = torch.empty((cols,), device=x.device, dtype=torch.float32)
     if dx_add is not None:
         dx_add = _rowmajor(dx_add, "dx_add")
     check(_lib.lib().mcl_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
                                        mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
                                        dx_add.stride(0) if dx_add is not None else 0, dx.data_ptr(), cols,
-                                       dg.data_ptr(), db.data_ptr(), rows, cols, _stream()), "mcl_layernorm_bwd")
-    return dx, dg, db
+                                       dg.data_ptr(), db.data_ptr(), int(direct), rows, cols, _stream()),
+          "mcl_layernorm_bwd")
+    return (dx, None, None) if direct else (dx, dg, db)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -196,12 +211,13 @@ class LayerNormFn(torch.autograd.Function):
         y, mean, rstd = layernorm_fwd(x2, gamma, beta, eps)
         ctx.save_for_backward(x2, gamma, mean, rstd)
         ctx.shp = shp
+        ctx.lparams = (gamma, beta)
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, gamma, mean, rstd = ctx.saved_tensors
-        dx, dg, db = layernorm_bwd(dy.reshape(x2.shape), x2, gamma, mean, rstd)
+        dx, dg, db = layernorm_bwd(dy.reshape(x2.shape), x2, gamma, mean, rstd, params=ctx.lparams)
         return dx.view(ctx.shp), dg, db, None
 
 
@@ -263,6 +279,7 @@ class AttnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h)
         ctx.heads, ctx.dim_head = heads, dim_head
         ctx.wparams = (wqkv, wo, w1, w2)   # the Parameter objects themselves: their .grad may be written directly
+        ctx.bparams = (bo, b1, b2, g1, be1, g2, be2)
         return x2
 
     @staticmethod
@@ -271,21 +288,22 @@ class AttnBlockFn(torch.autograd.Function):
         dx2 = _rowmajor(dx2, "dx2")
         # ff: x2 = h W2^T + b2 + x1
         p_qkv, p_o, p_1, p_2 = ctx.wparams
+        q_bo, q_b1, q_b2, q_g1, q_be1, q_g2, q_be2 = ctx.bparams
         dw2 = linear_bwd_weight(dx2, h, p_2)
-        db2 = colsum(dx2)
+        db2 = colsum(dx2, q_b2)
         dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
         dw1 = linear_bwd_weight(dpre, u2, p_1)
-        db1 = colsum(dpre)
+        db1 = colsum(dpre, q_b1)
         du2 = linear_bwd_data(dpre, w1)
-        dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2)
+        dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2, params=(q_g2, q_be2))
         # attn: x1 = o Wo^T + bo + x
         dwo = linear_bwd_weight(dx1, o, p_o)
-        dbo = colsum(dx1)
+        dbo = colsum(dx1, q_bo)
         do = linear_bwd_data(dx1, wo)
         dqkv = attention_core_bwd(do, qkv, P, ctx.heads, ctx.dim_head)
         dwqkv = linear_bwd_weight(dqkv, u1, p_qkv)
         du1 = linear_bwd_data(dqkv, wqkv)
-        dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1)
+        dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, params=(q_g1, q_be1))
         return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None
 
 
@@ -301,17 +319,19 @@ class ProjectionHeadFn(torch.autograd.Function):
         e, mean, rstd = layernorm_fwd(z, g, be)
         ctx.save_for_backward(x, wp, wf, g, p, a, z, mean, rstd)
         ctx.wparams = (wp, wf)
+        ctx.bparams = (bp, bf, g, be)
         return e
 
     @staticmethod
     def backward(ctx, de):
         x, wp, wf, g, p, a, z, mean, rstd = ctx.saved_tensors
-        dz, dg, dbe = layernorm_bwd(_rowmajor(de, "de"), z, g, mean, rstd)
+        q_bp, q_bf, q_g, q_be = ctx.bparams
+        dz, dg, dbe = layernorm_bwd(_rowmajor(de, "de"), z, g, mean, rstd, params=(q_g, q_be))
         dwf = linear_bwd_weight(dz, a, ctx.wparams[1])
-        dbf = colsum(dz)
+        dbf = colsum(dz, q_bf)
         dp = linear_bwd_data(dz, wf, gelu_bwd_aux=p, resid=dz)
         dwp = linear_bwd_weight(dp, x, ctx.wparams[0])
-        dbp = colsum(dp)
+        dbp = colsum(dp, q_bp)
         dx = linear_bwd_data(dp, wp) if ctx.needs_input_grad[0] else None
         return dx, dwp, dbp, dwf, dbf, dg, dbe
 

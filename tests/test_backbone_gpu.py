@@ -273,35 +273,6 @@ def test_bf16_shadow_follows_load_state_dict_and_inplace_edits():
     dn.set_weight_provider(None)
 
 
-@pytest.mark.parametrize("S,M,N,lda", [(4096, 128, 256, 256), (1000, 128, 96, 96), (777, 128, 160, 416),
-                                        (50000, 128, 64, 64), (300, 256, 512, 512), (31, 128, 992, 1024)])
-def test_conv1x1_wrw_kernel(S, M, N, lda):
-    """dW = dz^T a on bf16 channels-last operands (LDS transpose-read MFMA kernel) vs fp64 of the same bf16 data;
-    ragged S, channel-sliced a (lda > N), N not a multiple of the 128 tile."""
-    from mclstexp_amd import _lib, densenet_fused as dn
-    g = torch.Generator().manual_seed(S + N)
-    dz = (torch.rand(S, M, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
-    wide = (torch.rand(S, lda, generator=g) - 0.3).to(torch.bfloat16).to(DEV)
-    a = wide[:, :N]
-    dW = torch.full((M, N), 0.25, device=DEV)          # accumulate semantics
-    _lib.check(_lib.lib().mcl_conv1x1_wrw_bf16(dz.data_ptr(), M, a.data_ptr(), lda, None, None, None, None,
-                                               dW.data_ptr(), N, S, M, N, dn._stream()))
-    ref = dz.double().t() @ a.double() + 0.25
-    assert_close_scaled(dW.cpu(), ref.cpu(), 2e-5, what="conv1x1 wrw")
-    # fused BN+ReLU prologue on a
-    gam = (torch.rand(N, generator=g) + 0.5).to(DEV)
-    bet = (torch.rand(N, generator=g) - 0.5).to(DEV)
-    mu = (torch.rand(N, generator=g) - 0.5).to(DEV)
-    rs = (torch.rand(N, generator=g) + 0.5).to(DEV)
-    dW2 = torch.zeros((M, N), device=DEV)
-    _lib.check(_lib.lib().mcl_conv1x1_wrw_bf16(dz.data_ptr(), M, a.data_ptr(), lda, gam.data_ptr(), bet.data_ptr(),
-                                               mu.data_ptr(), rs.data_ptr(), dW2.data_ptr(), N, S, M, N, dn._stream()))
-    sc = gam * rs
-    sh = torch.addcmul(bet, mu, sc, value=-1.0)      # fmaf(-mean, sc, beta) as in the kernel
-    ap = torch.relu(torch.addcmul(sh, a.float(), sc)).to(torch.bfloat16)
-    assert_close_scaled(dW2.cpu(), (dz.double().t() @ ap.double()).cpu(), 2e-5, what="conv1x1 wrw + prologue")
-
-
 @pytest.mark.parametrize("S,K,ldx", [(401408 // 8, 64, 256), (100352 // 4, 224, 512), (25088, 992, 1024), (6272, 512, 1024),
                                      (300, 96, 96), (70000, 160, 512), (140000, 128, 256)])
 def test_dense_conv1x1_fwd_fused(S, K, ldx):
@@ -389,9 +360,6 @@ def test_dense_conv3x3_wrw_fused(B, H, W, lddy):
     rs = (torch.rand(128, generator=g) + 0.5).to(DEV)
     wide = (torch.rand(S, lddy, generator=g) - 0.5).to(torch.bfloat16).to(DEV)
     dy = wide[:, lddy - 32:]
-    dW = torch.full((32, 3, 3, 128), 0.125, device=DEV)
-    _lib.check(_lib.lib().mcl_dense_conv3x3_wrw(dy.data_ptr(), lddy, z.data_ptr(), S, H, W, gam.data_ptr(), bet.data_ptr(),
-                                                mu.data_ptr(), rs.data_ptr(), dW.data_ptr(), dn._stream()))
     sc = gam * rs
     sh = torch.addcmul(bet, mu, sc, value=-1.0)
     a2 = torch.relu(torch.addcmul(sh, z.float(), sc)).to(torch.bfloat16).double().permute(0, 3, 1, 2).requires_grad_(False)
@@ -399,8 +367,7 @@ def test_dense_conv3x3_wrw_fused(B, H, W, lddy):
     y = F.conv2d(a2, w, padding=1)
     y.backward(dy.double().reshape(B, H, W, 32).permute(0, 3, 1, 2))
     ref = w.grad.permute(0, 2, 3, 1) + 0.125
-    assert_close_scaled(dW.cpu(), ref.cpu(), 1e-4, what="fused conv3x3 weight gradient")   # fp32 atomics over <= 512 partials
-    # atomics-free form: per-workgroup partials + fixed-order merge; same values, bit-reproducible
+    # per-pixel-group partials + fixed-order merge: accumulate and overwrite semantics, bit-reproducible
     L = _lib.lib()
     ws = torch.empty(L.mcl_dense_conv3x3_wrw_workspace_floats(S), device=DEV)
     outs = []
@@ -513,7 +480,8 @@ def test_dense_bn1_wrw_dx_fused(S, C, ld):
 
 
 @pytest.mark.parametrize("S,M,N,lda", [(4096, 128, 256, 256), (1000, 128, 96, 96), (777, 128, 160, 416), (25088, 256, 512, 512),
-                                       (6272, 512, 1024, 1024), (100352, 128, 256, 256)])
+                                       (6272, 512, 1024, 1024), (100352, 128, 256, 256), (50000, 128, 64, 64),
+                                       (300, 256, 512, 512), (31, 128, 992, 1024)])
 def test_conv1x1_wrw_det_kernel(S, M, N, lda):
     """Atomics-free plain weight gradient dW = dz^T a (transition convolutions, M up to 512) vs fp64 of the same bf16
     data; accumulate and overwrite semantics; bit-reproducible."""
@@ -770,7 +738,7 @@ def test_conv0_wrw_kernel(B, H, W):
     F.conv2d(x.double(), w64, stride=2, padding=3).backward(dy.double())
     ws = torch.empty(L.mcl_conv0_wrw_workspace_floats(B, H, W), device=DEV)
     outs = []
-    for acc, wsp in ((1, ws.data_ptr()), (0, ws.data_ptr()), (1, ws.data_ptr()), (1, None)):
+    for acc, wsp in ((1, ws.data_ptr()), (0, ws.data_ptr()), (1, ws.data_ptr())):
         dW = torch.full((64, 3, 7, 7), 0.25, device=DEV).contiguous(memory_format=torch.channels_last)
         check(L.mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), wsp, dW.data_ptr(), acc, dn._stream()), "mcl_conv0_wrw")
         assert_close_scaled((dW - (0.25 if acc else 0.0)).cpu(), w64.grad.cpu(), 2e-5, floor=1e-4, what=f"dW conv0 acc={acc}")

@@ -20,5 +20,6 @@ def t(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 tf = t(lambda: dn.conv0_fwd(x, w, 1e-5, st))
-tw = t(lambda: check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), None, dW.data_ptr(), 1, dn._stream()), "wrw"))
+ws = torch.empty(_lib.lib().mcl_conv0_wrw_workspace_floats(B, H, W), device="cuda")
+tw = t(lambda: check(_lib.lib().mcl_conv0_wrw(x.data_ptr(), B, H, W, dy.data_ptr(), ws.data_ptr(), dW.data_ptr(), 1, dn._stream()), "wrw"))
 print(f"conv0 fwd+stats {tf:.1f} us ({(x.numel()*2 + B*64*H*W//4*2)/tf/1e6:.2f} TB/s)   wrw {tw:.1f} us")

@@ -83,14 +83,10 @@ def main():
             "r01 bn1_bwd (reduce+fin+dx)": (lambda: L.mcl_dense_bn1_bwd(P(dz), P(W1), C, P(x), ld, S, P(gam), P(bet), P(mu), P(rs),
                                                                         P(ws), P(dg), P(db), 1, P(gbuf), ld, st()),
                                             2 * S * (128 + C) + 2 * S * (128 + 3 * C)),
-            "r01 conv1x1_wrw (atomics)": (lambda: L.mcl_conv1x1_wrw_bf16(P(dz), 128, P(x), ld, P(gam), P(bet), P(mu), P(rs), P(dW1),
-                                                                         C, S, 128, C, st()), 2 * S * (128 + C)),
             "conv1x1_wrw_det (prologue, side)": (lambda: L.mcl_conv1x1_wrw_det(P(dz), 128, P(x), ld, P(gam), P(bet), P(mu), P(rs), P(ws),
                                                                                P(dW1), 1, S, 128, C, st()), 2 * S * (128 + C)),
             "conv3x3_wrw_det": (lambda: L.mcl_dense_conv3x3_wrw_det(P(dy), ld, P(z), S, hw, hw, P(gam), P(bet), P(mu), P(rs), P(ws),
                                                                     P(dW2), 1, st()), 2 * S * 160),
-            "r01 conv3x3_wrw (atomics)": (lambda: L.mcl_dense_conv3x3_wrw(P(dy), ld, P(z), S, hw, hw, P(gam), P(bet), P(mu), P(rs),
-                                                                          P(dW2), st()), 2 * S * 160),
             "conv3x3_bwd (+fin+bn2_dz)": (lambda: L.mcl_dense_conv3x3_bwd(P(dy), ld, S, hw, hw, P(W2), P(z), P(gam), P(bet), P(mu),
                                                                           P(rs), P(ws), P(dg), P(db), 1, P(scratch), P(dzo), st()),
                                           2 * S * (32 + 128 + 128) + 2 * S * 384),
