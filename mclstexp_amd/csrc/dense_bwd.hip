@@ -403,6 +403,285 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_kernel(const bf16_t* __res
   }
 }
 
+// =====================================================================================================================
+// Row-walking form of the kernel above for the large maps (image width 17..150: the 56 x 56 and 28 x 28 dense blocks), the
+// backward-data counterpart of csrc/conv3x3_rows.hip.  The flat-tile kernel loads a tile, synchronises, multiplies, runs a
+// 128-instruction-per-lane epilogue through LDS (lane = channel: z and g2 go through an LDS transpose as 2-byte
+// elements) and stores -- one tile in flight per workgroup (96 us per 56 x 56 layer inside the step).
+//
+// Here the work is cut into THIN, independent waves: a wave owns (image, row chunk, 32-column strip, 32-channel quarter of
+// the 128 input channels).  Its 18 weight fragments (9 taps x 2 halves of the 32 output channels) stay in registers; dy is
+// only 64 B per pixel, so the wave keeps a private 4-row ring of its strip (34 pixels incl. explicit zero halo columns) in
+// LDS and every output row is 18 MFMAs on 18 LDS fragment reads -- no masks (rows outside the image are skipped
+// wave-uniformly), no workgroup barrier at all.  MFMA roles are swapped (A = weights, B = pixels) so that a lane owns ONE
+// pixel and 16 channels: z arrives and g2 leaves as two 16-byte buffer accesses per lane (a v_permlane32_swap converts
+// between the memory order and the accumulator order), the ReLU mask and the BatchNorm sums are per-lane arithmetic on
+// per-lane running sums, reduced across lanes once per unit by DPP.  Loads run two rows ahead (dy) / one row ahead (z) in
+// two alternating register sets; rows past the unit's range read through a zero-size buffer descriptor.
+constexpr int BR_NWAVE = 8;                       // waves per workgroup (two per SIMD)
+constexpr int BR_SLOT = 34 * 64;                  // one dy row of the strip: 34 pixels x 32 channels bf16
+constexpr int BR_RING = 4 * BR_SLOT;              // rows jo-1, jo, jo+1 in use + the one being written
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned br_pack2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// sum over the 32 lanes of each half-wave by DPP; the total lands in lanes 16..31 / 48..63
+__device__ __forceinline__ float br_half_wave_sum(float x) {
+#define MCL_DPP_ADD(ctrl, rmask) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xF, false))
+  MCL_DPP_ADD(0xB1, 0xF);     // quad_perm [1,0,3,2]
+  MCL_DPP_ADD(0x4E, 0xF);     // quad_perm [2,3,0,1]
+  MCL_DPP_ADD(0x141, 0xF);    // row_half_mirror
+  MCL_DPP_ADD(0x140, 0xF);    // row_mirror
+  MCL_DPP_ADD(0x142, 0xA);    // row_bcast15 into rows 1 and 3
+#undef MCL_DPP_ADD
+  return x;
+}
+
+// memory order <-> accumulator order of a lane's 16 channels (8 dwords): an involution (see conv3x3_rows.hip emit_row)
+__device__ __forceinline__ void br_swap8(unsigned (&w)[8]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const u32x2 r = __builtin_amdgcn_permlane32_swap(w[4 * g + d], w[4 * g + 2 + d], false, false);
+      w[4 * g + d] = r[0];
+      w[4 * g + 2 + d] = r[1];
+    }
+}
+
+// the 18 MFMAs of one output row: taps of kernel row ky read dy row jo + 1 - ky (ring slot (jo + 1 - ky) & 3); fragment of
+// tap (ky, kx), half ks: pixel i = l31 + 2 - kx of the slot, 16-byte chunk (2 ks + h) ^ ((i >> 2) & 3)
+template <bool K0, bool K2>
+__device__ __forceinline__ void br_row_mfma(const unsigned char* __restrict__ ring, int jo, int lane_opaque,
+                                            const bf16x8 (&breg)[18], f32x16& acc) {
+  const int l31 = lane_opaque & 31, h = lane_opaque >> 5;
+  // fragment list of the row: (ky, kx, ks) over the valid kernel rows, two k-steps (one tap) per step; the fragments of
+  // step s+1 are requested before the MFMAs of step s issue (LDS latency would otherwise sit between every MFMA pair), and
+  // even / odd k-steps go to two accumulators so that consecutive MFMAs do not wait on each other's result
+  constexpr int KY0 = K0 ? 0 : 1, KY1 = K2 ? 3 : 2, NT = (KY1 - KY0) * 3;
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+  bf16x8 b[2][2];
+  auto fetch = [&](int t, int buf) {
+    const int ky = KY0 + t / 3, kx = t % 3;
+    const int i = l31 + 2 - kx;
+    const unsigned char* px = ring + ((jo + 1 - ky) & 3) * BR_SLOT + i * 64;
+    const int sw = (i >> 2) & 3;
+    b[buf][0] = *reinterpret_cast<const bf16x8*>(px + (((0 + h) ^ sw) << 4));
+    b[buf][1] = *reinterpret_cast<const bf16x8*>(px + (((2 + h) ^ sw) << 4));
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int cur = t & 1, tap = (KY0 + t / 3) * 3 + t % 3;
+    if (t + 1 < NT) fetch(t + 1, cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[tap * 2], b[cur][0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[tap * 2 + 1], b[cur][1], acc2, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+}
+
+__global__ __launch_bounds__(64 * BR_NWAVE, 2) void conv3x3_bwd_rows_kernel(
+    const bf16_t* __restrict__ dy, long long lddy, int nimg, int H, int W, const bf16_t* __restrict__ W2,
+    const bf16_t* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ rstd, bf16_t* __restrict__ g2, float2* __restrict__ partial,
+    int nsu, int rc, int nchunk, int nstrip) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int gw = blockIdx.x * BR_NWAVE + wave;
+  const int q = gw & 3;                                   // input-channel quarter: constant per wave (grid * 8 % 4 == 0)
+  unsigned char* ring = lds + wave * BR_RING;
+
+  // weight fragments: A[i = ci local][k = co]: lane (l31, h), fragment (tap, ks): W2[co = 16 ks + 8 h + j][tap][32 q + l31]
+  bf16x8 breg[18];
+#pragma unroll
+  for (int f = 0; f < 18; ++f) {
+    const int tap = f >> 1, co0 = 16 * (f & 1) + 8 * h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) breg[f][j] = (short)W2[((long long)(co0 + j) * 9 + tap) * 128 + 32 * q + l31];
+  }
+  // BatchNorm (scale, shift) per channel -> LDS; a lane re-reads the pairs of its 16 channels (accumulator order: r -> ci =
+  // 32 q + (r & 3) + 8 (r >> 2) + 4 h, i.e. four runs of 4 consecutive channels) in every row epilogue: 32 VGPRs saved
+  float2* coefs = reinterpret_cast<float2*>(lds + BR_NWAVE * BR_RING);
+  if (tid < 128) {
+    const float scv = gamma[tid] * rstd[tid];
+    coefs[tid] = make_float2(scv, fmaf(-mean[tid], scv, beta[tid]));
+  }
+  __syncthreads();
+  const unsigned dyrow_bytes = (unsigned)(((long long)(W - 1) * lddy + 32) * 2);
+  const unsigned zrow_bytes = (unsigned)W * 256u;
+  const unsigned lddy2 = (unsigned)(lddy * 2);
+  const int su_stride = (gridDim.x * BR_NWAVE) >> 2;
+
+  for (int su = gw >> 2; su < nsu; su += su_stride) {
+    const int strip = su % nstrip, t = su / nstrip;
+    const int chunk = t % nchunk, b = t / nchunk;
+    const int x0 = strip * 32;
+    const int j0 = chunk * rc, j1 = min(H, j0 + rc);
+    const int jd1 = min(H, j1 + 1);                              // dy rows [max(j0 - 1, 0), jd1) are needed
+    const long long img = (long long)b * H;
+    auto opaque_lane = [&]() { int ln = lane; asm volatile("" : "+v"(ln)); return ln; };
+
+    // dy row jr of the strip -> 3 chunks per lane: pixel i = (ln >> 2) + 16 tt, 16-byte chunk ln & 3.  Rows outside
+    // [0, jd1) read through a zero-size descriptor (zeros, no memory access); x = -1 reads pixel 0 and is zeroed at the write.
+    auto load_dy = [&](int jr, u32x4 (&d)[3]) {
+      const int ln = opaque_lane();
+      const bool inr = jr >= 0 && jr < jd1;
+      const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(dy) + (img + min(max(jr, 0), H - 1)) * W * lddy, 0, inr ? dyrow_bytes : 0u, 0x00020000);
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const int x = x0 - 1 + (ln >> 2) + 16 * tt;
+        d[tt] = __builtin_amdgcn_raw_buffer_load_b128(row, (unsigned)max(x, 0) * lddy2 + (unsigned)(ln & 3) * 16u, 0, 0);
+      }
+    };
+    auto write_dy = [&](int jr, const u32x4 (&d)[3]) {
+      const int ln = opaque_lane();
+      unsigned char* slot = ring + (jr & 3) * BR_SLOT;
+#pragma unroll
+      for (int tt = 0; tt < 3; ++tt) {
+        const int i = (ln >> 2) + 16 * tt, x = x0 - 1 + i;
+        const bool ok = x >= 0 && x < W;
+        if (i < 34)
+          *reinterpret_cast<uint4*>(slot + i * 64 + ((((ln & 3) ^ ((i >> 2) & 3))) << 4)) =
+              ok ? make_uint4(d[tt][0], d[tt][1], d[tt][2], d[tt][3]) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    };
+    // z row jo of this lane's pixel, quarter q, memory order: 16 bytes at 16 h and at 32 + 16 h of the 64-byte quarter row
+    auto load_z = [&](int jo, u32x4 (&zr)[2]) {
+      const int ln = opaque_lane();
+      const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(z) + (img + min(jo, H - 1)) * W * 128, 0, jo < j1 ? zrow_bytes : 0u, 0x00020000);
+      const unsigned off = (unsigned)(x0 + (ln & 31)) * 256u + (unsigned)q * 64u + 16u * (unsigned)(ln >> 5);
+      zr[0] = __builtin_amdgcn_raw_buffer_load_b128(row, off, 0, 0);
+      zr[1] = __builtin_amdgcn_raw_buffer_load_b128(row, off + 32u, 0, 0);
+    };
+
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.0f;
+
+    // ---- prologue: rows j0-1, j0, j0+1 into the ring; row j0+2 and z row j0 in flight
+    u32x4 dA[3], dB[3], zA[2], zB[2];
+    load_dy(j0 - 1, dA);
+    load_dy(j0, dB);
+    write_dy(j0 - 1, dA);
+    load_dy(j0 + 1, dA);
+    write_dy(j0, dB);
+    write_dy(j0 + 1, dA);
+    load_dy(j0 + 2, dB);
+    load_z(j0, zB);
+
+    int jo = j0;
+    bool more = true;
+    // X = sets loaded during the previous iteration (dy row jo + 2, z row jo); Y = the free sets (dy row jo + 3, z row jo + 1)
+#define MCL_BR_STEP(DX, ZX, DY, ZY)                                                                             \
+    {                                                                                                           \
+      load_dy(jo + 3, DY);                                                                                      \
+      load_z(jo + 1, ZY);                                                                                       \
+      f32x16 acc;                                                                                               \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.0f;                                             \
+      const bool k0 = jo + 1 < H, k2 = jo >= 1;                                                                 \
+      const int lo = opaque_lane();                                                                             \
+      if (k0 && k2) br_row_mfma<true, true>(ring, jo, lo, breg, acc);                                           \
+      else if (k0) br_row_mfma<true, false>(ring, jo, lo, breg, acc);                                           \
+      else if (k2) br_row_mfma<false, true>(ring, jo, lo, breg, acc);                                           \
+      else br_row_mfma<false, false>(ring, jo, lo, breg, acc);                                                  \
+      /* epilogue: mask, round, sums, store */                                                                  \
+      {                                                                                                         \
+        const int ln = opaque_lane();                                                                           \
+        const int px = x0 + (ln & 31);                                                                          \
+        const float vm = px < W ? 1.0f : 0.0f;                                                                  \
+        unsigned zw[8] = {ZX[0][0], ZX[0][1], ZX[0][2], ZX[0][3], ZX[1][0], ZX[1][1], ZX[1][2], ZX[1][3]};      \
+        br_swap8(zw);                                                                                           \
+        unsigned gw8[8];                                                                                        \
+        const float4* cf = reinterpret_cast<const float4*>(coefs + 32 * q + 4 * (ln >> 5));                    \
+        _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                         \
+          const float4 c4 = cf[4 * (d >> 1) + (d & 1)];      /* (sc, sh) of channels 8 (d >> 1) + 4 h + 2 (d & 1) + {0, 1} */ \
+          const float z0 = __uint_as_float(zw[d] << 16), z1 = __uint_as_float(zw[d] & 0xFFFF0000u);             \
+          const float g0 = fmaf(z0, c4.x, c4.y) > 0.0f ? acc[2 * d] * vm : 0.0f;                                \
+          const float g1 = fmaf(z1, c4.z, c4.w) > 0.0f ? acc[2 * d + 1] * vm : 0.0f;                            \
+          gw8[d] = br_pack2(g0, g1);                                                                            \
+          const float r0 = __uint_as_float(gw8[d] << 16), r1 = __uint_as_float(gw8[d] & 0xFFFF0000u);           \
+          s1[2 * d] += r0;                                                                                      \
+          s2[2 * d] = fmaf(r0, z0, s2[2 * d]);                                                                  \
+          s1[2 * d + 1] += r1;                                                                                  \
+          s2[2 * d + 1] = fmaf(r1, z1, s2[2 * d + 1]);                                                          \
+        }                                                                                                       \
+        br_swap8(gw8);                                                                                          \
+        const __amdgpu_buffer_rsrc_t orow = __builtin_amdgcn_make_buffer_rsrc(g2 + (img + jo) * W * 128, 0,     \
+                                                                              zrow_bytes, 0x00020000);          \
+        const unsigned off = (unsigned)px * 256u + (unsigned)q * 64u + 16u * (unsigned)(ln >> 5);               \
+        const u32x4 o0 = {gw8[0], gw8[1], gw8[2], gw8[3]}, o1 = {gw8[4], gw8[5], gw8[6], gw8[7]};               \
+        __builtin_amdgcn_raw_buffer_store_b128(o0, orow, off, 0, 0);                                            \
+        __builtin_amdgcn_raw_buffer_store_b128(o1, orow, off + 32u, 0, 0);                                      \
+      }                                                                                                         \
+      write_dy(jo + 2, DX);                                                                                     \
+      ++jo;                                                                                                     \
+      more = jo < j1;                                                                                           \
+    }
+    while (true) {
+      MCL_BR_STEP(dB, zB, dA, zA)
+      if (!more) break;
+      MCL_BR_STEP(dA, zA, dB, zB)
+      if (!more) break;
+    }
+#undef MCL_BR_STEP
+
+    // ---- unit sums: sum_p g and sum_p g*zhat = rstd (sum g*z - mean sum g) per channel, lanes 31 / 63 write
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s1[r] = br_half_wave_sum(s1[r]);
+      s2[r] = br_half_wave_sum(s2[r]);
+    }
+    if (l31 == 31) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * q + (r & 3) + 8 * (r >> 2) + 4 * h;
+        partial[(long long)c * nsu + su] = make_float2(s1[r], rstd[c] * fmaf(-mean[c], s1[r], s2[r]));
+      }
+    }
+  }
+}
+
+struct BwdRowsPlan {
+  int nimg, nstrip, rc, nchunk, nsu, grid;
+};
+
+inline BwdRowsPlan bwd_rows_plan(long long S, int H, int W) {
+  BwdRowsPlan p;
+  p.nimg = (int)(S / ((long long)H * W));
+  p.nstrip = (W + 31) / 32;
+  // four channel-quarter waves per spatial unit; units sized to fill the 2048 wave slots about once
+  long long rc = ((long long)H * p.nimg * p.nstrip * 4) / 2048;
+  if (rc < 2) rc = 2;
+  if (rc > H) rc = H;
+  p.rc = (int)rc;
+  p.nchunk = (H + p.rc - 1) / p.rc;
+  p.nsu = p.nimg * p.nchunk * p.nstrip;
+  p.grid = (4 * p.nsu + BR_NWAVE - 1) / BR_NWAVE;
+  if (p.grid > 256) p.grid = 256;
+  return p;
+}
+
+inline bool bwd_rows_applicable(long long S, int H, int W) {
+  static const char* e = getenv("MCL_C3_ROWS");
+  if (e && atoi(e) == 0) return false;
+  static const char* e_minw = getenv("MCL_C3_ROWS_MINW");
+  const int minw = e_minw ? atoi(e_minw) : 17;
+  return W >= minw && W <= 150 && S % ((long long)H * W) == 0;
+}
+
 // dz = gamma*rstd*(g2 - c1 - zhat*c2), elementwise over (S, 128) bf16
 __global__ __launch_bounds__(256) void bn2_dz_kernel(const bf16_t* __restrict__ g2, const bf16_t* __restrict__ z,
                                                      long long n_chunks, const float* __restrict__ gamma,
@@ -516,7 +795,9 @@ extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const
 
 extern "C" int64_t mcl_dense_conv3x3_bwd_workspace_floats(int64_t S) {
   if (S <= 0) return -1;
-  return ((S + T3B - 1) / T3B) * 2 * (int64_t)C3I + 2 * (int64_t)C3I;
+  // flat form: one partial per 128-pixel tile; row-walking form: one per spatial unit (<= image rows x strips / 2 <= S / 32)
+  const int64_t flat = (S + T3B - 1) / T3B, rows = S / 32 + 8;
+  return (flat > rows ? flat : rows) * 2 * (int64_t)C3I + 2 * (int64_t)C3I;
 }
 
 extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2,
@@ -531,19 +812,36 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
       (reinterpret_cast<uintptr_t>(dy) & 15u) || (reinterpret_cast<uintptr_t>(z) & 15u) ||
       (reinterpret_cast<uintptr_t>(g2) & 15u) || (reinterpret_cast<uintptr_t>(dz) & 15u))
     return MCL_EUNSUPPORTED;
-  const int ntile = (int)((S + T3B - 1) / T3B);
-  float2* part = reinterpret_cast<float2*>(workspace);
-  float* coef = workspace + (int64_t)ntile * 2 * C3I;
-  const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
   hipStream_t st = mcl_stream(stream);
-  static const char* e_gx = getenv("MCL_MAIN_GRID");
-  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
-  hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
-                     (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
-                     (bf16_t*)g2, part, ntile);
-  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C3I), dim3(256), 0, st, (const float2*)part, ntile, C3I,
-                     (long long)S, dgamma, dbeta, coef, accumulate_params);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  float* coef;
+  if (bwd_rows_applicable(S, H, W)) {                 // the large maps: thin row-walking waves
+    const BwdRowsPlan p = bwd_rows_plan(S, H, W);
+    coef = workspace + (int64_t)p.nsu * 2 * C3I;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bwd_rows_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_bwd_rows_kernel, dim3(p.grid), dim3(64 * BR_NWAVE), (size_t)BR_NWAVE * BR_RING + 1024, st,
+                       (const bf16_t*)dy, (long long)lddy, p.nimg, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta,
+                       mean, rstd, (bf16_t*)g2, part, p.nsu, p.rc, p.nchunk, p.nstrip);
+    hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C3I), dim3(256), 0, st, (const float2*)part, p.nsu, C3I,
+                       (long long)S, dgamma, dbeta, coef, accumulate_params);
+  } else {
+    const int ntile = (int)((S + T3B - 1) / T3B);
+    coef = workspace + (int64_t)ntile * 2 * C3I;
+    const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
+    static const char* e_gx = getenv("MCL_MAIN_GRID");
+    static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
+    const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
+    hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
+                       (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
+                       (bf16_t*)g2, part, ntile);
+    hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C3I), dim3(256), 0, st, (const float2*)part, ntile, C3I,
+                       (long long)S, dgamma, dbeta, coef, accumulate_params);
+  }
   const long long n_chunks = S * (C3I / 8);
   long long blocks = (n_chunks + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -517,7 +517,11 @@ def test_conv1x1_wrw_det_kernel(S, M, N, lda):
     assert_close_scaled(dW2.cpu(), (dz.double().t() @ ap.double()).cpu(), 2e-5, what="wrw det + prologue")
 
 
-@pytest.mark.parametrize("B,H,W,lddy", [(4, 56, 56, 256), (8, 28, 28, 32), (16, 14, 14, 1024), (32, 7, 7, 64), (3, 10, 6, 32)])
+@pytest.mark.parametrize("B,H,W,lddy", [(4, 56, 56, 256), (8, 28, 28, 32), (16, 14, 14, 1024), (32, 7, 7, 64), (3, 10, 6, 32),
+                                        # row-walking form (thin waves, csrc/dense_bwd.hip): ragged strips, one-row images,
+                                        # 3-5 strips, more units than wave slots
+                                        (3, 9, 17, 64), (2, 5, 33, 96), (1, 1, 40, 32), (2, 2, 150, 32), (1, 3, 97, 64),
+                                        (40, 56, 56, 32), (7, 31, 29, 64)])
 def test_dense_conv3x3_bwd_fused(B, H, W, lddy):
     """conv2 backward-data + relu2/norm2 backward -> dz, dgamma2, dbeta2 (csrc/dense_bwd.hip) vs fp64 torch autograd
     on the same bf16 data; dy read as a channel slice of a wider buffer; image borders; ragged last tile."""
