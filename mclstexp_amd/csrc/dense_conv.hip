@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256) void tile_stats_finalize_kernel(const float2* 
   rstd[c] = (float)(1.0 / sqrt(v + (double)eps));
 }
 
-inline int pick_wm(long long S) { return S >= 131072 ? 4 : (S >= 32768 ? 2 : 1); }
+// 128-row tiles (WM = 2: 72 KB of LDS, two workgroups per CU) also on the 56 x 56 maps: the 256-row tile (104 KB, ONE
+// workgroup per CU, nothing overlaps its load / multiply / store phases) is faster alone but 0.1 ms/step slower in the step
+// (13.07 / 13.09 vs 12.94 / 13.01 ms, interleaved A/B)
+inline int pick_wm(long long S) { return S >= 32768 ? 2 : 1; }
 
 }  // namespace
 
@@ -302,8 +305,7 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   static const char* e_half = getenv("MCL_C1F_HALF");
   const bool half_waves = !(e_half && atoi(e_half) == 0);
   // (the same doubling for the 128- / 256-row tiles, which already run two waves per SIMD, measured no gain)
-  if (wm == 4) MCL_LAUNCH(4, 64);
-  else if (wm == 2) MCL_LAUNCH(2, 64);
+  if (wm == 2) MCL_LAUNCH(2, 64);
   else if (half_waves) MCL_LAUNCH(2, 32);
   else MCL_LAUNCH(1, 64);
 #undef MCL_LAUNCH

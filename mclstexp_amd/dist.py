@@ -362,12 +362,42 @@ def gather_rows(dout: Tensor, ix: Tensor, iy: Tensor, pg, sizes: Optional[Sequen
     return g_dout, g_idx[:, 0].contiguous(), g_idx[:, 1].contiguous()
 
 
-class GradReducer:
-    """Sum parameter gradients over ranks: one all-reduce per flat FusedAdam bucket (the gradients
-    already live contiguously there), plus stragglers that are not in a flat bucket."""
+class _WireHandle:
+    """Work handle of a gradient all-reduce that travelled in a narrower wire format: ``wait()`` waits for the collective
+    and writes the summed values back into the fp32 gradient slice."""
 
-    def __init__(self, pg):
+    def __init__(self, work, dst: Tensor, wire: Tensor):
+        self.work, self.dst, self.wire = work, dst, wire
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.dst.copy_(self.wire)
+
+
+class GradReducer:
+    """Sum parameter gradients over ranks: the flat FusedAdam bucket (the gradients already live contiguously there) in
+    ``buckets`` contiguous chunks, each its own collective, plus stragglers that are not in a flat bucket.
+
+    ``buckets`` (MCL_GRAD_BUCKETS, default 1): several collectives in flight let RCCL pipeline the ring over xGMI; the
+    result is independent of the chunking (every element is still summed once over the same ranks).
+    ``wire`` (MCL_GRAD_WIRE, default "fp32"): "bf16" sends the gradient as bf16 -- half the bytes of the one large
+    message of the step (63 MB fp32 with DenseNet-121: ring time over 7 x 153 GB/s xGMI links 0.7 -> 0.35 ms) at bf16
+    rounding of the summands and of the sum (the usual DDP compression hook trade)."""
+
+    def __init__(self, pg, buckets: Optional[int] = None, wire: Optional[str] = None):
         self.pg = pg
+        self.buckets = max(1, int(os.environ.get("MCL_GRAD_BUCKETS", "1")) if buckets is None else int(buckets))
+        self.wire = (os.environ.get("MCL_GRAD_WIRE", "fp32") if wire is None else wire).lower()
+        if self.wire not in ("fp32", "bf16"):
+            raise ValueError("GradReducer wire format must be 'fp32' or 'bf16'")
+
+    def _chunks(self, g: Tensor) -> List[Tensor]:
+        n = g.numel()
+        if self.buckets == 1 or n < 4 * self.buckets:
+            return [g]
+        step = ((n + self.buckets - 1) // self.buckets + 3) // 4 * 4          # 16-byte aligned chunk starts
+        return [g[o:min(n, o + step)] for o in range(0, n, step)]
 
     def reduce(self, optimizer, async_flat: bool = False):
         """Sums gradients over ranks.  ``async_flat``: the (large) flat-bucket all-reduce is only ENQUEUED and its
@@ -383,10 +413,18 @@ class GradReducer:
         handles = []
         if hasattr(optimizer, "flat_grads"):
             for g in optimizer.flat_grads():
-                if async_flat and not _host_staged(g, self.pg):
-                    handles.append(td.all_reduce(g, op=td.ReduceOp.SUM, group=self.pg, async_op=True))
-                else:
-                    _all_reduce_sum(g, self.pg)
+                for c in self._chunks(g):
+                    if self.wire == "bf16":
+                        w = c.to(torch.bfloat16)
+                        if async_flat and not _host_staged(w, self.pg):
+                            handles.append(_WireHandle(td.all_reduce(w, op=td.ReduceOp.SUM, group=self.pg, async_op=True), c, w))
+                        else:
+                            _all_reduce_sum(w, self.pg)
+                            c.copy_(w)
+                    elif async_flat and not _host_staged(c, self.pg):
+                        handles.append(td.all_reduce(c, op=td.ReduceOp.SUM, group=self.pg, async_op=True))
+                    else:
+                        _all_reduce_sum(c, self.pg)
             flat_ids = optimizer.flat_param_ids()
         for group in optimizer.param_groups:
             for p in group["params"]:

@@ -266,6 +266,45 @@ def test_grad_reducer_sums_flat_bucket_and_stragglers():
         assert torch.equal(b, torch.full((2,), 30.0))
 
 
+def _bucket_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    g = torch.Generator().manual_seed(100 + rank)
+    base = torch.randn(100003, generator=g)
+
+    class Opt(_FakeFlatOpt):
+        def __init__(self, flat):
+            self.flat = flat
+            self.param_groups = [{"params": []}]
+
+        def flat_param_ids(self):
+            return set()
+
+    outs = {}
+    for name, kw in (("mono", dict(buckets=1)), ("b4", dict(buckets=4)), ("b7", dict(buckets=7)),
+                     ("bf16", dict(buckets=3, wire="bf16"))):
+        opt = Opt(base.clone())
+        handles = mdist.GradReducer(td.group.WORLD, **kw).reduce(opt, async_flat=True)
+        for h in handles:
+            h.wait()
+        outs[name] = opt.flat.clone()
+    return outs, base
+
+
+def test_grad_reducer_buckets_equal_monolithic_and_bf16_wire():
+    """Bucketed all-reduce == monolithic bit for bit (world 2: each element is one commutative fp32 addition whatever the
+    chunking); bf16 wire format = the sum of the bf16-rounded summands, rounded to bf16."""
+    res = _spawn(_bucket_case, 2)
+    (o0, b0), (o1, b1) = res
+    exact = b0 + b1
+    for o in (o0, o1):
+        assert torch.equal(o["mono"], exact)
+        assert torch.equal(o["b4"], o["mono"]) and torch.equal(o["b7"], o["mono"])
+        ref16 = (b0.to(torch.bfloat16) + b1.to(torch.bfloat16)).float()
+        assert torch.equal(o["bf16"], ref16)
+        assert (o["bf16"] - exact).abs().max() <= 2.0 ** -7 * exact.abs().max()
+    assert torch.equal(o0["mono"], o1["mono"]) and torch.equal(o0["bf16"], o1["bf16"])          # replicas identical
+
+
 def test_init_from_env_single_process(monkeypatch):
     from mclstexp_amd import dist as mdist
     monkeypatch.setenv("WORLD_SIZE", "1")

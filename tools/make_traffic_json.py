@@ -15,11 +15,13 @@ import sys
 
 UNITS = {   # ABI unit -> [(kernel substring, launches of it per unit call)]
     "mcl_dense_bn1_bwd": [("bn1_bwd_kernel<0", 1), ("bn1_bwd_finalize_kernel", 1), ("bn1_bwd_kernel<1", 1)],
-    "mcl_dense_conv3x3_bwd": [("conv3x3_bwd_kernel", 1), ("bn2_dz_kernel", 1)],
+    "mcl_dense_conv3x3_bwd": [("conv3x3_bwd_", 1), ("bn2_dz_kernel", 1)],          # flat + row-walking forms (launch-weighted)
     "mcl_dense_conv1x1_fwd": [("conv1x1_fwd_kernel", 1)],
-    "mcl_dense_conv3x3_fwd": [("conv3x3_fwd_kernel", 1)],
-    "mcl_conv1x1_wrw_det": [("wrw_partial_kernel", 1)],
-    "mcl_dense_conv3x3_wrw_det": [("conv3x3_wrw_k", 1)],      # slab form + kernel-row form (launch-weighted)
+    "mcl_dense_conv3x3_fwd": [("conv3x3_fwd_", 1)],                               # flat + row-walking forms
+    "mcl_conv1x1_wrw_det": [("wrw_partial_kernel<2", 1), ("wrw_partial_kernel<0", 1)],
+    "mcl_dense_bn1_wrw": [("wrw_partial_kernel<1", 1)],
+    "mcl_dense_bn1_dx": [("bn1_bwd_kernel<1", 1)],
+    "mcl_dense_conv3x3_wrw_det": [("conv3x3_wrw_k", 1)],
     "mcl_adam_table_step_dev": [("adam_table_kernel", 1)],
     "mcl_adam_step_dev": [("adam_kernel(", 1)],
 }
