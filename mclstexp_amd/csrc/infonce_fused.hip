@@ -155,12 +155,8 @@ __device__ __forceinline__ bf16x8 ld_b(const unsigned char* lds, const int (&a2)
   const int kk = j >> 3, pb = j & 7;
   const unsigned char* p0 = lds + cb * 16384 + kk * 8192 + (pb >> 2) * 256;
   const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p0 + a2[2 * (pb & 3)]));
-#ifdef MCL_EXP_HALF_LDS_B   // timing experiment only (wrong results): half the phase-B LDS traffic
-  const v4s hi = lo;
-#else
   const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (v4s __attribute__((address_space(3)))*)(p0 + 4096 + a2[2 * (pb & 3) + 1]));
-#endif
   bf16x8 bv;
   bv[0] = lo[0]; bv[1] = lo[1]; bv[2] = lo[2]; bv[3] = lo[3];
   bv[4] = hi[0]; bv[5] = hi[1]; bv[6] = hi[2]; bv[7] = hi[3];
@@ -213,27 +209,14 @@ struct EGradPair {
       }
     }
     if (s >= 1 && s <= 32) {    // exponentials of element s-1
-#if defined(MCL_EXP_NOEXP)      // timing experiments only (wrong results)
-      ea1 = xa1 * 0.5f;
-      ea2 = xa2 * 0.5f;
-#elif defined(MCL_EXP_NOE)
-      ea1 = xa1;
-      ea2 = xa2;
-#else
       ea1 = __builtin_amdgcn_exp2f(xa1);
       ea2 = __builtin_amdgcn_exp2f(xa2);
-#endif
     }
     if (s < 32) {               // exponent arguments of element s
       const int i = s & 15;
       const float t = s < 16 ? TE0[i] : TE1[i];
-#ifdef MCL_EXP_NOE
-      xa1 = t;
-      xa2 = s < 16 ? cl0[i] : cl1[i];
-#else
       xa1 = fmaf(t, c.kscale, c.nrl2);
       xa2 = fmaf(t, c.kscale, s < 16 ? cl0[i] : cl1[i]);
-#endif
     }
     // IR-level anchor: without it the (pure) element computations sink below the per-step sched_barriers to the
     // end of the stage and nothing overlaps the MFMAs
@@ -289,16 +272,7 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
   for (int s = 0; s < 4; ++s) f[s] = ld_a(lds, a1, CB0 + (s & 1), s >> 1);
 #pragma unroll
   for (int s = 0; s < 32; ++s) {
-#ifdef MCL_EXP_NO_LDS_A
-    if (s + 4 < 32) f[s + 4] = f[s];
-#elif defined(MCL_EXP_HALF_LDS_A)   // timing experiment only (wrong results): half the phase-A LDS traffic
-    if (s + 4 < 32) {
-      if (s & 1) f[s + 4] = f[s + 3];
-      else f[s + 4] = ld_a(lds, a1, CB0 + ((s + 4) & 1), (s + 4) >> 1);
-    }
-#else
     if (s + 4 < 32) f[s + 4] = ld_a(lds, a1, CB0 + ((s + 4) & 1), (s + 4) >> 1);
-#endif
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if ((s & 1) == 0) TA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], bfrag[s >> 1], s < 2 ? zero : TA0, 0, 0, 0);
     else TA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], bfrag[s >> 1], s < 2 ? zero : TA1, 0, 0, 0);
@@ -306,7 +280,6 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
       if (BWD) {
         eg.step(s, ECB, c, TE0, TE1, e_col0, e_dcol, wE0, wE1);
       } else {
-#ifndef MCL_EXP_NOSTAT
         const int i = s & 15;
         if (s < 16) {
           s0.step(c, TE0, ECB, i, e_col0, run_m);
@@ -315,17 +288,12 @@ __device__ __forceinline__ void stage_aa(const unsigned char* lds, const int (&a
           s1.step(c, TE1, ECB + 1, i, e_col0, run_m);
           if (i == 15) s1.finish(run_m, run_l);
         }
-#else
-        if (s == 31) run_l += TE0[3] + TE1[5];   // keep the logits alive
-#endif
       }
     }
     if (BWD && PF0 >= 0 && s == 16) eg.load_cl(eg.cl0, lds, cls_off, PF0, c.h);
     if (BWD && PF1 >= 0 && s == 17) eg.load_cl(eg.cl1, lds, cls_off, PF1, c.h);
     if (NDMA > 0) {   // the next tile's DMA: this wave's NDMA pieces, one per even step
-#ifndef MCL_EXP_NODMA
       if ((s & 1) == 0 && (s >> 1) < NDMA) dma_piece<FASTDMA>(d, s >> 1, col0n, dst_tile);
-#endif
       if (BWD && s == 1) dma_stat(d, col0n, dst_stat);
     }
     MCL_PIN();
@@ -471,11 +439,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
     it_b = nIt;
   }
 
-#ifdef MCL_EXP_NOBARRIER   // timing experiment only (racy)
-#define MCL_EXP_BARRIER()
-#else
-#define MCL_EXP_BARRIER() __syncthreads()
-#endif
   bf16x8 w0[2], w1[2], w2[2], w3[2];
 #define MCL_TILE_ITER(FIXV, FD)                                                                                    \
   {                                                                                                               \
@@ -509,7 +472,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void strip_kernel(const bf16_t* __
                                                  w1, run_m, run_l, c, dl, col0n, dst_tile, dst_stat);              \
     }                                                                                                             \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
-    MCL_EXP_BARRIER();                                                                                            \
+    __syncthreads();                                                                                            \
     buf ^= 1;                                                                                                     \
     cls_off ^= STAT_STRIDE;                                                                                       \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                               \
