@@ -122,7 +122,7 @@ __device__ __forceinline__ void row_mfma(const unsigned char* __restrict__ wf, c
     const bool tr = it >= 12;           // dword k of the 9 chunks in steps 12 + 3k .. 14 + 3k: one coefficient quad live at a time
     const int k = tr ? (it - 12) / 3 : 0, t0 = tr ? 3 * ((it - 12) % 3) : 0;
     float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tr) c = coef4[k];
+    if (tr) c = coef4[16 * k];
     const int nx = it + D, nb = nx % NB, nkx = nx >> 3, nkk = nx & 7;
     __builtin_amdgcn_sched_barrier(0);
     if (V0) aN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[cur], p[cur], aN, 0, 0, 0);
@@ -189,6 +189,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     gram_cb += F_cb^T F_cb   (diagonal = sum over pixels of y^2, exact: bf16 x bf16 products in fp32)
 //     sum_cb  += F_cb^T 1      (every column = sum over pixels of y)
 // -- 16 accumulator registers, 4 short MFMAs and 6 LDS instructions per row, no VALU reduction.
+constexpr int SROW = 64;                        // scratch bytes per pixel row (32 channels bf16)
 struct RowStats {
   f32x4 gram[2], sum[2];
 };
@@ -219,21 +220,26 @@ __device__ __forceinline__ void emit_row(const f32x16& a, __amdgpu_buffer_rsrc_t
   __builtin_amdgcn_raw_buffer_store_b128(lo4, orow, ooff, 0, 0);
   __builtin_amdgcn_raw_buffer_store_b128(hi4, orow, ooff + 32u, 0, 0);
   if (STATS) {
-    // scratch[pixel][channel] bf16, 64-byte rows; pixels beyond the image width contribute zeros
+    // scratch[pixel][channel] bf16, 64-byte rows, 16-byte chunk c of pixel row r stored at chunk c ^ ((r >> 1) & 3) (the stores of
+    // 8 consecutive lanes then tile all 32 banks); pixels beyond the image width contribute zeros
     const bool valid = px < W;
-    unsigned char* wp = scratch + (ln & 31) * 64 + (ln >> 5) * 16;
-    *reinterpret_cast<uint4*>(wp) = valid ? make_uint4(pk[0], pk[1], pk[2], pk[3]) : make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(wp + 32) = valid ? make_uint4(pk[4], pk[5], pk[6], pk[7]) : make_uint4(0u, 0u, 0u, 0u);
+    unsigned char* wp = scratch + (ln & 31) * SROW;
+    const int wsw = ((ln & 31) >> 1) & 3, hh = ln >> 5;
+    *reinterpret_cast<uint4*>(wp + ((hh ^ wsw) << 4)) = valid ? make_uint4(pk[0], pk[1], pk[2], pk[3]) : make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(wp + (((2 + hh) ^ wsw) << 4)) = valid ? make_uint4(pk[4], pk[5], pk[6], pk[7]) : make_uint4(0u, 0u, 0u, 0u);
     // fragment of channel block cb for the 16x16x32 MFMA: lane (i = l & 15, g = l >> 4) gets pixels 8g .. 8g+7 of channel
     // 16 cb + i.  ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of row (i >> 2), 8-byte piece
     // (i & 3) of a 4 x 16 block and receives column i of it.
     const int i = ln & 15, g = ln >> 4;
-    const unsigned char* rp = scratch + (8 * g + (i >> 2)) * 64 + (i & 3) * 8;
+    const int r0 = 8 * g + (i >> 2);                      // pixel row of the first read; the second reads row r0 + 4
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(rp + cb * 32));
-      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(rp + cb * 32 + 4 * 64));
+      const int ch = 2 * cb + ((i & 3) >> 1);             // 16-byte chunk of this lane's 8-byte piece
+      const unsigned char* p0 = scratch + r0 * SROW + ((ch ^ ((r0 >> 1) & 3)) << 4) + (i & 1) * 8;
+      const unsigned char* p1 = scratch + (r0 + 4) * SROW + ((ch ^ (((r0 + 4) >> 1) & 3)) << 4) + (i & 1) * 8;
+      const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)p0);
+      const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)p1);
       const bf16x8 f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       st.gram[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, st.gram[cb], 0, 0, 0);
       st.sum[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, ones, st.sum[cb], 0, 0, 0);
@@ -262,14 +268,15 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void conv3x3_fwd_rows_kernel(
   float* coef = reinterpret_cast<float*>(lds + WF_BYTES + NWAVE * SLAB_BYTES);
   if (tid < CI) {
     const float scv = gamma[tid] * rstd[tid];
-    coef[(tid >> 1) * 4 + (tid & 1)] = scv;
-    coef[(tid >> 1) * 4 + 2 + (tid & 1)] = fmaf(-mean[tid], scv, beta[tid]);
+    const int quad = ((tid >> 1) & 3) * 16 + (tid >> 3);        // [k = pair within the chunk][cc = chunk column]: lanes read 16 B apart
+    coef[quad * 4 + (tid & 1)] = scv;
+    coef[quad * 4 + 2 + (tid & 1)] = fmaf(-mean[tid], scv, beta[tid]);
   }
   __syncthreads();                                   // the only workgroup-wide barrier
 
   const unsigned char* wf = lds + l31 * WROW + h * 16;
   unsigned char* slab = lds + WF_BYTES + wave * SLAB_BYTES;
-  unsigned char* scratch = lds + WF_BYTES + NWAVE * SLAB_BYTES + CI * 8 + wave * 2048;     // statistics transpose buffer
+  unsigned char* scratch = lds + WF_BYTES + NWAVE * SLAB_BYTES + CI * 8 + wave * (32 * SROW);     // statistics transpose buffer
   const int pbase[3] = {lane, 0, 0};               // row_mfma derives its fragment offsets from the lane id per call
   const unsigned row_bytes = (unsigned)W * 256u;                         // one image row of z
   const unsigned orow_bytes = (unsigned)(((long long)(W - 1) * ldo + CO) * 2);
@@ -311,11 +318,11 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void conv3x3_fwd_rows_kernel(
 #pragma unroll
       for (int tt = 1; tt < 9; ++tt) v[tt] = __builtin_amdgcn_raw_buffer_load_b128(zrow, off1 + (tt - 1) * 1024u, 0, 0);
     };
-    const float4* coef4 = reinterpret_cast<const float4*>(coef) + (lane & 15) * 4;
+    const float4* coef4 = reinterpret_cast<const float4*>(coef) + (lane & 15);        // quad k at coef4[16 k]
     auto transform_row = [&](u32x4 (&v)[9]) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float4 c = coef4[k];
+        const float4 c = coef4[16 * k];
 #pragma unroll
         for (int tt = 0; tt < 9; ++tt) v[tt][k] = bn_relu_pair(v[tt][k], c.x, c.y, c.z, c.w);
       }
@@ -471,7 +478,7 @@ int mcl_launch_conv3x3_fwd_rows(const void* z, long long S, int H, int W, const 
                                 const float* mean, const float* rstd, const void* W2, void* out, long long ldo,
                                 float* workspace, float eps, float* ymean, float* yvar, float* yrstd, hipStream_t st) {
   const RowsPlan p = rows_plan(S, H, W);
-  const size_t lds_bytes = WF_BYTES + NWAVE * SLAB_BYTES + CI * 8 + NWAVE * 2048;
+  const size_t lds_bytes = WF_BYTES + NWAVE * SLAB_BYTES + CI * 8 + NWAVE * 32 * SROW;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_fwd_rows_kernel),

@@ -6,6 +6,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VA
   rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/ssq/$tag -- $B > /dev/null 2>&1
 done
 cd $R
-python tools/pmc_summary.py gpurun_out/ssq conv3x3_bwd_kernel bn1_bwd_kernel conv1x1_fwd_kernel conv3x3_fwd_kernel conv3x3_wrw_ky wrw_partial_kernel bn2_dz_kernel adam_table_kernel gemm_kernel > gpurun_out/step_sq_counters.txt
+python tools/pmc_summary.py gpurun_out/ssq conv3x3_bwd_rows_kernel conv3x3_bwd_kernel bn1_bwd_kernel conv1x1_fwd_kernel conv3x3_fwd_rows_kernel conv3x3_fwd_kernel conv3x3_wrw_ky wrw_partial_kernel bn2_dz_kernel adam_table_kernel gemm_kernel > gpurun_out/step_sq_counters.txt
 rm -rf gpurun_out/ssq
 head -60 gpurun_out/step_sq_counters.txt
