@@ -454,11 +454,11 @@ __device__ __forceinline__ void br_swap8(unsigned (&w)[8]) {
 }
 
 // the 18 MFMAs of one output row: taps of kernel row ky read dy row jo + 1 - ky (ring slot (jo + 1 - ky) & 3); fragment of
-// tap (ky, kx), half ks: pixel i = l31 + 2 - kx of the slot, 16-byte chunk (2 ks + h) ^ ((i >> 2) & 3)
+// tap (ky, kx), half ks: pixel i = l31 + 2 - kx of the slot, 16-byte chunk (2 ks + h) ^ ((i >> 2) & 3) -- the six byte offsets
+// foff[kx][ks] inside a slot are lane constants
 template <bool K0, bool K2>
-__device__ __forceinline__ void br_row_mfma(const unsigned char* __restrict__ ring, int jo, int lane_opaque,
+__device__ __forceinline__ void br_row_mfma(const unsigned char* __restrict__ ring, int jo, const int (&foff)[3][2],
                                             const bf16x8 (&breg)[18], f32x16& acc) {
-  const int l31 = lane_opaque & 31, h = lane_opaque >> 5;
   // fragment list of the row: (ky, kx, ks) over the valid kernel rows, two k-steps (one tap) per step; the fragments of
   // step s+1 are requested before the MFMAs of step s issue (LDS latency would otherwise sit between every MFMA pair), and
   // even / odd k-steps go to two accumulators so that consecutive MFMAs do not wait on each other's result
@@ -469,11 +469,9 @@ __device__ __forceinline__ void br_row_mfma(const unsigned char* __restrict__ ri
   bf16x8 b[2][2];
   auto fetch = [&](int t, int buf) {
     const int ky = KY0 + t / 3, kx = t % 3;
-    const int i = l31 + 2 - kx;
-    const unsigned char* px = ring + ((jo + 1 - ky) & 3) * BR_SLOT + i * 64;
-    const int sw = (i >> 2) & 3;
-    b[buf][0] = *reinterpret_cast<const bf16x8*>(px + (((0 + h) ^ sw) << 4));
-    b[buf][1] = *reinterpret_cast<const bf16x8*>(px + (((2 + h) ^ sw) << 4));
+    const unsigned char* slot = ring + ((jo + 1 - ky) & 3) * BR_SLOT;
+    b[buf][0] = *reinterpret_cast<const bf16x8*>(slot + foff[kx][0]);
+    b[buf][1] = *reinterpret_cast<const bf16x8*>(slot + foff[kx][1]);
   };
   fetch(0, 0);
 #pragma unroll
@@ -570,6 +568,13 @@ __global__ __launch_bounds__(64 * BR_NWAVE, 2) void conv3x3_bwd_rows_kernel(
     float s1[16], s2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.0f;
+    int foff[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int i = l31 + 2 - kx, sw = (i >> 2) & 3;
+      foff[kx][0] = i * 64 + ((h ^ sw) << 4);
+      foff[kx][1] = i * 64 + (((2 + h) ^ sw) << 4);
+    }
 
     // ---- prologue: rows j0-1, j0, j0+1 into the ring; row j0+2 and z row j0 in flight
     u32x4 dA[3], dB[3], zA[2], zB[2];
@@ -592,16 +597,14 @@ __global__ __launch_bounds__(64 * BR_NWAVE, 2) void conv3x3_bwd_rows_kernel(
       f32x16 acc;                                                                                               \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[r] = 0.0f;                                             \
       const bool k0 = jo + 1 < H, k2 = jo >= 1;                                                                 \
-      const int lo = opaque_lane();                                                                             \
-      if (k0 && k2) br_row_mfma<true, true>(ring, jo, lo, breg, acc);                                           \
-      else if (k0) br_row_mfma<true, false>(ring, jo, lo, breg, acc);                                           \
-      else if (k2) br_row_mfma<false, true>(ring, jo, lo, breg, acc);                                           \
-      else br_row_mfma<false, false>(ring, jo, lo, breg, acc);                                                  \
+      if (k0 && k2) br_row_mfma<true, true>(ring, jo, foff, breg, acc);                                         \
+      else if (k0) br_row_mfma<true, false>(ring, jo, foff, breg, acc);                                         \
+      else if (k2) br_row_mfma<false, true>(ring, jo, foff, breg, acc);                                         \
+      else br_row_mfma<false, false>(ring, jo, foff, breg, acc);                                                \
       /* epilogue: mask, round, sums, store */                                                                  \
       {                                                                                                         \
         const int ln = opaque_lane();                                                                           \
         const int px = x0 + (ln & 31);                                                                          \
-        const float vm = px < W ? 1.0f : 0.0f;                                                                  \
         unsigned zw[8] = {ZX[0][0], ZX[0][1], ZX[0][2], ZX[0][3], ZX[1][0], ZX[1][1], ZX[1][2], ZX[1][3]};      \
         br_swap8(zw);                                                                                           \
         unsigned gw8[8];                                                                                        \
@@ -609,8 +612,8 @@ __global__ __launch_bounds__(64 * BR_NWAVE, 2) void conv3x3_bwd_rows_kernel(
         _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                         \
           const float4 c4 = cf[4 * (d >> 1) + (d & 1)];      /* (sc, sh) of channels 8 (d >> 1) + 4 h + 2 (d & 1) + {0, 1} */ \
           const float z0 = __uint_as_float(zw[d] << 16), z1 = __uint_as_float(zw[d] & 0xFFFF0000u);             \
-          const float g0 = fmaf(z0, c4.x, c4.y) > 0.0f ? acc[2 * d] * vm : 0.0f;                                \
-          const float g1 = fmaf(z1, c4.z, c4.w) > 0.0f ? acc[2 * d + 1] * vm : 0.0f;                            \
+          const float g0 = fmaf(z0, c4.x, c4.y) > 0.0f ? acc[2 * d] : 0.0f;                                     \
+          const float g1 = fmaf(z1, c4.z, c4.w) > 0.0f ? acc[2 * d + 1] : 0.0f;                                 \
           gw8[d] = br_pack2(g0, g1);                                                                            \
           const float r0 = __uint_as_float(gw8[d] << 16), r1 = __uint_as_float(gw8[d] & 0xFFFF0000u);           \
           s1[2 * d] += r0;                                                                                      \
@@ -638,11 +641,14 @@ __global__ __launch_bounds__(64 * BR_NWAVE, 2) void conv3x3_bwd_rows_kernel(
     }
 #undef MCL_BR_STEP
 
-    // ---- unit sums: sum_p g and sum_p g*zhat = rstd (sum g*z - mean sum g) per channel, lanes 31 / 63 write
+    // ---- unit sums: sum_p g and sum_p g*zhat = rstd (sum g*z - mean sum g) per channel, lanes 31 / 63 write.  Lanes whose
+    // pixel lies beyond the image width hold sums of values that were never stored (their z reads returned zeros, their g2
+    // stores were dropped by the descriptor's range check): they contribute nothing.
+    const float vmask = x0 + l31 < W ? 1.0f : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s1[r] = br_half_wave_sum(s1[r]);
-      s2[r] = br_half_wave_sum(s2[r]);
+      s1[r] = br_half_wave_sum(s1[r] * vmask);
+      s2[r] = br_half_wave_sum(s2[r] * vmask);
     }
     if (l31 == 31) {
 #pragma unroll
