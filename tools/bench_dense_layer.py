@@ -71,7 +71,13 @@ def main():
         P = lambda t: t.data_ptr()
         ym, yv, yr = (torch.zeros(32, device=dev) for _ in range(3))
         ws3 = torch.empty(L.mcl_dense_conv3x3_workspace_floats(S), device=dev)
+        zo = torch.empty_like(z)
+        zm, zv, zr = (torch.zeros(128, device=dev) for _ in range(3))
+        ws1 = torch.empty(L.mcl_dense_conv1x1_workspace_floats(S), device=dev)
         calls = {
+            "conv1x1_fwd (+finalize)": (lambda: L.mcl_dense_conv1x1_fwd(P(x), ld, S, C, P(gam), P(bet), P(mu), P(rs), P(W1), P(zo),
+                                                                       128, P(ws1), 1e-5, P(zm), P(zv), P(zr), st()),
+                                        2 * S * (C + 128)),
             "conv3x3_fwd (+finalize)": (lambda: L.mcl_dense_conv3x3_fwd(P(z), S, hw, hw, P(gam), P(bet), P(mu), P(rs), P(W2),
                                                                        P(xw) + 2 * (ld - 32), ld, P(ws3), 1e-5, P(ym), P(yv),
                                                                        P(yr), st()), 2 * S * 160),

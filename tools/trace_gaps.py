@@ -19,6 +19,7 @@ idle = 0
 gaps = collections.defaultdict(lambda: [0, 0.0])
 last = rows[0][0]
 hist = collections.Counter()
+pairs = collections.defaultdict(lambda: [0, 0.0])
 for n, s, e in rows:
     if s > busy_end:
         g = (s - busy_end) / 1e3
@@ -26,6 +27,9 @@ for n, s, e in rows:
         key = re.sub(r"\(anonymous namespace\)::|^void\s+", "", last).split("(")[0][:50]
         gaps[key][0] += 1
         gaps[key][1] += g
+        nxt = re.sub(r"\(anonymous namespace\)::|^void\s+", "", n).split("(")[0][:40]
+        pairs[(key[:40], nxt)][0] += 1
+        pairs[(key[:40], nxt)][1] += g
         hist[min(int(g), 20)] += 1
     if e > busy_end:
         busy_end, last = e, n
@@ -34,3 +38,6 @@ print(f"{K} steps: wall {(t1 - t0) / 1e3 / K:.1f} us/step, kernel-sum {sum(e - s
 print("gap length histogram (us: count/step):", {k: round(v / K, 1) for k, v in sorted(hist.items())})
 for k, (n, t) in sorted(gaps.items(), key=lambda x: -x[1][1])[:14]:
     print(f"  after {k:52s} {n / K:6.1f} gaps/step {t / K:8.1f} us/step  avg {t / n:5.2f} us")
+print("gaps by (kernel that ended last, kernel that started next):")
+for (a, b), (n, t) in sorted(pairs.items(), key=lambda x: -x[1][1])[:12]:
+    print(f"  {a:42s} -> {b:42s} {n / K:6.1f} gaps/step {t / K:8.1f} us/step  avg {t / n:5.2f} us")
