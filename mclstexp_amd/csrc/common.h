@@ -50,3 +50,11 @@ long long mcl_conv3x3_rows_workspace_floats(long long S);
 int mcl_launch_conv3x3_fwd_rows(const void* z, long long S, int H, int W, const float* gamma, const float* beta,
                                 const float* mean, const float* rstd, const void* W2, void* out, long long ldo,
                                 float* workspace, float eps, float* ymean, float* yvar, float* yrstd, hipStream_t st);
+
+// csrc/conv3x3_wrw_rows.hip: row-walking form of the growth 3x3 weight gradient for the large maps (enqueue only;
+// workspace = one fp32 partial per workgroup; launches the fixed-order merge itself).
+bool mcl_conv3x3_wrw_rows_applicable(long long S, int H, int W);
+long long mcl_conv3x3_wrw_rows_workspace_floats(long long S, int H, int W);
+int mcl_launch_conv3x3_wrw_rows(const void* dy, long long lddy, const void* z, long long S, int H, int W, const float* gamma,
+                                const float* beta, const float* mean, const float* rstd, float* workspace, float* dW,
+                                int accumulate_w, hipStream_t st);

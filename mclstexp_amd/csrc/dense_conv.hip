@@ -763,7 +763,9 @@ static inline int wrw3k_groups(int ntile) {
 extern "C" int64_t mcl_dense_conv3x3_wrw_workspace_floats(int64_t S) {
   if (S <= 0) return -1;
   const int ntile = (int)((S + T3 - 1) / T3);
-  return (int64_t)wrw3k_groups(ntile) * (C3_OUT * 9 * C3_IN);
+  // (the row-walking form needs one partial per workgroup: <= 256; the map shape is not known here)
+  const int64_t g = wrw3k_groups(ntile);
+  return (g > 256 ? g : 256) * (int64_t)(C3_OUT * 9 * C3_IN);
 }
 
 extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const void* z, int64_t S, int32_t H, int32_t W,
@@ -777,6 +779,12 @@ extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const voi
     return MCL_EUNSUPPORTED;
   const int ntile = (int)((S + T3 - 1) / T3);
   hipStream_t st = mcl_stream(stream);
+  if (mcl_conv3x3_wrw_rows_applicable(S, H, W)) {
+    const int rc = mcl_launch_conv3x3_wrw_rows(dy, lddy, z, S, H, W, gamma, beta, mean, rstd, workspace, dW, accumulate_w, st);
+    if (rc != MCL_OK) return rc;
+    MCL_CHECK_LAUNCH();
+    return MCL_OK;
+  }
   // per pixel group ONE fp32 partial (32 x 1152) in the workspace, written in disjoint column ranges by its three kernel-row
   // workgroups; fixed-order merge launch (bit-reproducible)
   const int G = wrw3k_groups(ntile);

@@ -345,10 +345,14 @@ def test_dense_conv3x3_fwd_fused(B, H, W, ldo):
 
 
 @pytest.mark.parametrize("B,H,W,lddy", [(4, 56, 56, 256), (8, 28, 28, 32), (16, 14, 14, 1024), (32, 7, 7, 64), (3, 10, 6, 32),
-                                        (40, 56, 56, 32), (65, 56, 56, 32)])     # 65 x 56^2: 1593 pixel tiles, 19 per pixel group
+                                        (40, 56, 56, 32), (65, 56, 56, 32),      # 65 x 56^2: 1593 pixel tiles, 19 per pixel group
+                                        # row-walking form (csrc/conv3x3_wrw_rows.hip, image width 17..64): ragged widths, one-
+                                        # and two-row images, both k-step counts, more units than row streams (600 > 512)
+                                        (3, 9, 17, 64), (2, 5, 33, 96), (1, 1, 40, 32), (2, 2, 64, 32), (1, 3, 50, 64),
+                                        (7, 31, 29, 64), (600, 2, 20, 32)])
 def test_dense_conv3x3_wrw_fused(B, H, W, lddy):
-    """dW2 += dy^T (x) relu(bn2(z)) over the nine taps (csrc/dense_conv.hip) vs torch's conv2d weight gradient on
-    the same bf16 data; accumulate semantics; dy read as a channel slice of a wider buffer."""
+    """dW2 += dy^T (x) relu(bn2(z)) over the nine taps (csrc/dense_conv.hip, csrc/conv3x3_wrw_rows.hip) vs torch's conv2d
+    weight gradient on the same bf16 data; accumulate semantics; dy read as a channel slice of a wider buffer."""
     import torch.nn.functional as F
     from mclstexp_amd import _lib, densenet_fused as dn
     S = B * H * W
