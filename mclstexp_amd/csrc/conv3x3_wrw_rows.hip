@@ -233,7 +233,12 @@ inline WrwRowsPlan wrw_rows_plan(long long S, int H, int W) {
   WrwRowsPlan p;
   p.nimg = (int)(S / ((long long)H * W));
   p.nks = W <= 32 ? 2 : 4;
-  // two row streams per workgroup, one workgroup per CU; chunks sized so that the streams are filled about once
+  // two row streams per workgroup, one workgroup per CU (147 KB of LDS); chunks sized for 512 streams.  The launch is capped
+  // at 160 workgroups: the kernel lives on the side stream, where a full-chip grid of CU-filling workgroups keeps the
+  // critical chain's kernels off the CUs (bench.py: 12.93-12.97 ms/step at 256 workgroups, 12.78-12.84 at 128-160, 12.84-12.90
+  // with the kernel-row form although this kernel alone is twice as fast; MCL_WRW_ROWS_GRID for A/B runs)
+  static const char* e_g = getenv("MCL_WRW_ROWS_GRID");
+  const int gcap = e_g ? atoi(e_g) : 160;
   long long rc = ((long long)H * p.nimg + 511) / 512;
   if (rc < 1) rc = 1;
   if (rc > H) rc = H;
@@ -241,6 +246,7 @@ inline WrwRowsPlan wrw_rows_plan(long long S, int H, int W) {
   p.nchunk = (H + p.rc - 1) / p.rc;
   const int nunit = p.nimg * p.nchunk;
   p.grid = (nunit + 1) / 2;
+  if (p.grid > gcap) p.grid = gcap;
   if (p.grid > 256) p.grid = 256;
   return p;
 }
