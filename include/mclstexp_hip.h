@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 2
+#define MCL_ABI_VERSION 3
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -311,6 +311,20 @@ int mcl_dense_bn1_wrw(const void* dz, const void* W1, int32_t C, const void* x, 
 int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
                      const float* gamma, const float* beta, const float* mean, const float* rstd, const float* coef,
                      void* gbuf, int64_t ldg, mcl_stream_t stream);
+/* Single-pass form of mcl_dense_bn1_bwd for the latency-bound small maps.  dx = gamma*rstd*(g - mean g - xhat*mean(g*xhat)) is
+ * linear in the two means: ONE kernel adds gamma*rstd*g into gbuf and reduces the sums (no separate reduce pass over dz and
+ * x); its finalize adds dgamma / dbeta and the layer's mean terms gamma*rstd*(mean g, mean g*xhat) to ``kacc`` (2*C_total
+ * floats, [c][2], zeroed by the caller when the dense block's backward starts).  Channel statistics (mean, rstd) are those
+ * of the block's concat buffer, identical for every layer, so the totals of all layers reading a channel are applied once,
+ * by mcl_dense_bn1_fix, when that channel's gradient is complete:  gbuf[s][c] -= K1[c] + K2[c]*xhat[s][c]  for c in
+ * [c0, c0 + nc) (c0, nc multiples of 8).  workspace: mcl_dense_bn1_bwd_workspace_floats(S, C).
+ * Replaces the same torch sequence as mcl_dense_bn1_bwd (/root/reference/model.py:75-76 via torchvision _DenseLayer).   */
+int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                          const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
+                          float* dgamma, float* dbeta, int32_t accumulate_params, float* kacc, void* gbuf, int64_t ldg,
+                          mcl_stream_t stream);
+int mcl_dense_bn1_fix(const void* x, int64_t ldx, void* gbuf, int64_t ldg, int64_t S, int32_t c0, int32_t nc,
+                      const float* mean, const float* rstd, const float* kacc, mcl_stream_t stream);
 /* Deterministic 1x1 weight gradient dW[M][N] (+)= dz[S][M]^T a'[S][N]: a' = a (gamma..rstd NULL: transition
  * convolutions) or relu(BatchNorm(a)) recomputed in registers (all four given) -- the atomics-free form of
  * mcl_conv1x1_wrw_bf16.  workspace: mcl_wrw_workspace_floats(S, min(M,128), N).                                 */

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib: Optional[C.CDLL] = None
 
@@ -104,6 +104,8 @@ PROTOTYPES = {
     "mcl_wrw_workspace_floats": [c_l, c_i, c_i],
     "mcl_dense_bn1_wrw": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p],
     "mcl_dense_bn1_dx": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "mcl_dense_bn1_dx_sums": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p],
+    "mcl_dense_bn1_fix": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p],
     "mcl_conv1x1_wrw_det": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p],
     "mcl_dense_conv3x3_fwd": [c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p, c_p],
     "mcl_accum_into_f32": [c_p, c_p, c_l, c_i, c_p],

@@ -38,6 +38,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 
 // MODE 0: reduce (partials of sum g, sum g*xhat)      MODE 1: dx accumulate
+// MODE 2: ONE pass -- gbuf += gamma*rstd*g (the data-dependent term of dx) AND the partials of the two sums; the two mean
+// terms of dx, which are per-channel constants times (1, xhat), are added later for all layers at once (bn1_fix_kernel)
 // A workgroup keeps ONE column tile (its W1 block and per-channel constants are loaded once) and walks row tiles.
 // All global loads of a row tile (dz, x and -- dx launch -- the gradient-buffer chunks) are issued together at the
 // top, so the x / gradient latency hides under the dz staging and the MFMAs; LDS holds W1 (32 KB) + one 32 KB tile
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
       const bool ok = rg < S;
       dzr[i] = ok ? *reinterpret_cast<const uint4*>(dz + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
       xr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(x + rg * ldx + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
-      if (MODE == 1)
+      if (MODE >= 1)
         gr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(gbuf + rg * ldg + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();   // the previous row tile is done with the shared tile
@@ -168,19 +170,19 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
           const int row = wm * (TMv / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float xv = bf2f(xt[row * TN + cl]);
           const float gi = fmaf(xv, sc[j], sh[j]) > 0.0f ? acc[i][j][r] : 0.0f;
-          if (MODE == 0) {
+          if (MODE != 1) {
             if (row < nvalid) {
               s1[j] += gi;
               s2[j] = fmaf(gi, xv, s2[j]);
             }
-          } else {
-            // the x value of this element is dead: its slot takes the bf16 delta for the read-modify-write below
-            xt[row * TN + cl] = f2bf(fmaf(sc[j], gi, fmaf(ka, xv, kb)));
           }
+          // the x value of this element is dead: its slot takes the bf16 delta for the read-modify-write below
+          if (MODE == 1) xt[row * TN + cl] = f2bf(fmaf(sc[j], gi, fmaf(ka, xv, kb)));
+          if (MODE == 2) xt[row * TN + cl] = f2bf(sc[j] * gi);
         }
-      if (MODE == 0) s2[j] = rs[j] * fmaf(-mu[j], s1[j], s2[j]);
+      if (MODE != 1) s2[j] = rs[j] * fmaf(-mu[j], s1[j], s2[j]);
     }
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         s1[j] += __shfl_xor(s1[j], 32, 64);
@@ -195,8 +197,9 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
       if (tid < 128 && n0 + tid < K)
         partial[(long long)(n0 + tid) * nrt + rt] = make_float2(red[tid * 2] + red[(128 + tid) * 2],
                                                                 red[tid * 2 + 1] + red[(128 + tid) * 2 + 1]);
-    } else {
-      __syncthreads();
+    }
+    if (MODE >= 1) {
+      if (MODE == 1) __syncthreads();
       if (cok) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -226,7 +229,10 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
 __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __restrict__ partial, int nrt, int C,
                                                                long long S, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ coef,
-                                                               int accumulate_params) {
+                                                               int accumulate_params,
+                                                               float* __restrict__ kacc = nullptr /* [C][2], += */,
+                                                               const float* __restrict__ gamma = nullptr,
+                                                               const float* __restrict__ rstd = nullptr) {
   __shared__ double red[2][4];
   const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float2* p = partial + (long long)c * nrt;
@@ -256,8 +262,51 @@ __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __r
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
   }
+  if (kacc != nullptr) {
+    // single-pass form: the layer's mean terms gamma*rstd*(mean g, mean g*xhat) join the block's running totals
+    const double scv = (double)gamma[c] * (double)rstd[c];
+    kacc[2 * c] += (float)(scv * a / (double)S);
+    kacc[2 * c + 1] += (float)(scv * b / (double)S);
+    return;
+  }
   coef[2 * c] = (float)(a / (double)S);
   coef[2 * c + 1] = (float)(b / (double)S);
+}
+
+// The deferred mean terms of the BatchNorm-1 backward of ALL layers that read channels [c0, c0 + nc) of a dense block's
+// concat buffer, applied once, when the gradient of those channels is complete:
+//     gbuf[s][c] -= K1[c] + K2[c]*xhat[s][c],   xhat = (x - mean)*rstd        (K = running totals of bn1_bwd_finalize_kernel)
+// Elementwise over S x nc bf16, 16-byte chunks, both tensors strided (channel slices of the block's buffers).
+__global__ __launch_bounds__(256) void bn1_fix_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ gbuf,
+                                                      long long ldg, long long S, int c0, int nc,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ kacc) {
+  const int cpr = nc >> 3;                                   // chunks per row
+  const long long n = S * cpr;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long row = i / cpr;
+    const int c = c0 + (int)(i - row * cpr) * 8;
+    const uint4 xv = *reinterpret_cast<const uint4*>(x + row * ldx + c);
+    uint4 gv = *reinterpret_cast<const uint4*>(gbuf + row * ldg + c);
+    const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+    unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float o[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ch = c + 2 * u + e;
+        const float k1 = kacc[2 * ch], k2 = kacc[2 * ch + 1];
+        const float ka = k2 * rstd[ch], kb = fmaf(-ka, mean[ch], k1);
+        const float xf = e ? __uint_as_float(xw[u] & 0xFFFF0000u) : __uint_as_float(xw[u] << 16);
+        const float gf = e ? __uint_as_float(gw[u] & 0xFFFF0000u) : __uint_as_float(gw[u] << 16);
+        o[e] = gf - fmaf(ka, xf, kb);
+      }
+      const f32x2 pv = {o[0], o[1]};
+      gw[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));
+    }
+    *reinterpret_cast<uint4*>(gbuf + row * ldg + c) = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+  }
 }
 
 // =====================================================================================================================
@@ -771,6 +820,56 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   if (tmv == 64) MCL_BN1(1, 64, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
   else MCL_BN1(1, 128, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
 #undef MCL_BN1
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+// Single-pass form for the latency-bound small maps: ONE kernel accumulates gamma*rstd*g into the gradient buffer and
+// reduces the two sums; the finalize adds dgamma / dbeta and the layer's mean terms to the block's running totals
+// ``kacc`` ([C_total][2] fp32, zeroed by the caller at the start of the block's backward); mcl_dense_bn1_fix applies the
+// totals to a channel range once its gradient is complete.  Saves the separate reduce pass over (dz, x) of
+// mcl_dense_bn1_bwd: dx = gamma*rstd*(g - mean g - xhat*mean(g*xhat)) is linear in those two means.
+extern "C" int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                                     const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                     float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, float* kacc,
+                                     void* gbuf, int64_t ldg, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || !kacc || !gbuf || S <= 0 ||
+      C <= 0)
+    return MCL_EINVAL;
+  if ((C % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
+      (reinterpret_cast<uintptr_t>(W1) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(gbuf) & 15u))
+    return MCL_EUNSUPPORTED;
+  const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
+  float2* part = reinterpret_cast<float2*>(workspace);
+  hipStream_t st = mcl_stream(stream);
+  static const char* e_gx = getenv("MCL_MAIN_GRID");
+  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
+  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
+  int gx = (gcap + nct - 1) / nct;
+  if (gx > nrt) gx = nrt;
+  hipLaunchKernelGGL((bn1_bwd_kernel<2, 64>), dim3(gx, nct), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,
+                     (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)nullptr,
+                     (bf16_t*)gbuf, (long long)ldg, part, nrt);
+  hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float2*)part, nrt, C, (long long)S, dgamma,
+                     dbeta, (float*)nullptr, accumulate_params, kacc, gamma, rstd);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_dense_bn1_fix(const void* x, int64_t ldx, void* gbuf, int64_t ldg, int64_t S, int32_t c0, int32_t nc,
+                                 const float* mean, const float* rstd, const float* kacc, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!x || !gbuf || !mean || !rstd || !kacc || S <= 0 || c0 < 0 || nc <= 0) return MCL_EINVAL;
+  if ((c0 % 8) || (nc % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(gbuf) & 15u))
+    return MCL_EUNSUPPORTED;
+  const long long n = S * (nc >> 3);
+  long long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(bn1_fix_kernel, dim3((int)nb), dim3(256), 0, mcl_stream(stream), (const bf16_t*)x, (long long)ldx,
+                     (bf16_t*)gbuf, (long long)ldg, (long long)S, c0, nc, mean, rstd, kacc);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

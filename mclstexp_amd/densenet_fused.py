@@ -288,6 +288,41 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
     return (None, None) if into_param_grads else (dg, db)
 
 
+def dense_bn1_dx_sums(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
+                      kacc: Tensor, into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """Single-pass form of ``dense_bn1_bwd`` (csrc/dense_bwd.hip, mcl_dense_bn1_dx_sums): gbuf += gamma*rstd*g and the norm1
+    parameter gradients in ONE pass over (dz, x); the layer's two mean terms go to the block's running totals ``kacc``
+    ((C_total, 2) fp32) and reach the gradient buffer through ``dense_bn1_fix``."""
+    px, S, C, ldx = _rows(x)
+    pg, S2, C2, ldg = _rows(gbuf)
+    assert (S2, C2) == (S, C) and dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128 and kacc.numel() >= 2 * C
+    L = _lib.lib()
+    ws = _ws(L.mcl_dense_bn1_bwd_workspace_floats(S, C), x.device)
+    if into_param_grads:
+        dg, db = g1.grad, b1.grad
+    else:
+        dg = torch.empty(C, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(L.mcl_dense_bn1_dx_sums(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                  int(into_param_grads), kacc.data_ptr(), pg, ldg, _stream()), "mcl_dense_bn1_dx_sums")
+    return (None, None) if into_param_grads else (dg, db)
+
+
+def dense_bn1_fix(buf: Tensor, gbuf: Tensor, c0: int, nc: int, mean: Tensor, rstd: Tensor, kacc: Tensor) -> None:
+    """gbuf[:, c0:c0+nc] -= K1 + K2*xhat: the mean terms of every layer that read these channels of the concat buffer
+    ``buf``, applied once their gradient is complete (mcl_dense_bn1_fix).  mean / rstd / kacc are the block's full arrays."""
+    px, S, _, ldx = _rows(buf)
+    pg, S2, _, ldg = _rows(gbuf)
+    assert S == S2
+    check(_lib.lib().mcl_dense_bn1_fix(px, ldx, pg, ldg, S, c0, nc, mean.data_ptr(), rstd.data_ptr(), kacc.data_ptr(),
+                                       _stream()), "mcl_dense_bn1_fix")
+
+
+# Single-pass BatchNorm-1 backward (mean terms deferred, one pass over (dz, x) less per layer) on the maps where the
+# bottleneck weight gradient does not ride on the reduction anyway (below FUSED_BN1_WRW_MIN_PIXELS)
+USE_BN1_SINGLE_PASS = os.environ.get("MCL_BN1_SINGLE_PASS", "1") != "0"
+
 # Deterministic fusion of the bottleneck weight gradient with the BatchNorm-backward reduction (csrc/wrw_fused.hip): one
 # pass over (dz, x) replaces conv1x1_wrw + the reduce launch + its finalize; then the dx pass alone.  It does the least
 # total work but puts the weight gradient ON the critical chain of the backward.  Where the side stream hides the weight
@@ -629,6 +664,7 @@ class DenseBlockFn(torch.autograd.Function):
             ctx.cap["dz"] = [None] * L
             ctx.cap["gbuf"] = gbuf
         grads = [None] * (6 * L)
+        kacc = None             # running totals of the deferred BatchNorm-1 mean terms (single-pass form), [C_total][2]
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
             a, z, a2 = saved[3 * l: 3 * l + 3]
@@ -649,6 +685,9 @@ class DenseBlockFn(torch.autograd.Function):
                 # waits: the two atomics-bound weight-gradient kernels of the layer start on the side stream once dz
                 # exists (event) and are joined only at the end of the block; dz stays referenced until then.
                 d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
+                if kacc is not None:
+                    # this layer's 32 output channels have their complete gradient now: the later layers' mean terms
+                    dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 if ctx.cap is not None:
                     ctx.cap["dz"][l] = dz
@@ -661,6 +700,11 @@ class DenseBlockFn(torch.autograd.Function):
                     dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                                 gbuf[:, :cin], w1, into_param_grads=d1)
                     gw1 = None
+                elif USE_BN1_SINGLE_PASS:
+                    if kacc is None:
+                        kacc = torch.zeros((buf.shape[1], 2), device=buf.device, dtype=torch.float32)
+                    dg1, db1 = dense_bn1_dx_sums(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                                 gbuf[:, :cin], kacc, into_param_grads=d1)
                 else:
                     dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                              gbuf[:, :cin], into_param_grads=d1)
@@ -674,6 +718,8 @@ class DenseBlockFn(torch.autograd.Function):
                 continue
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
+            if kacc is not None:                                # (a layer off the fast path inside a single-pass block)
+                dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
             if fused2:
                 # fused forward: a2 = relu(bn2(z)) was never stored.  Both kernels read dy in place from the gradient
                 # buffer (row stride C_total): no contiguous copy, no MIOpen call
@@ -732,6 +778,8 @@ class DenseBlockFn(torch.autograd.Function):
         # the main chain wait whenever the side stream runs behind; the small maps can afford to keep their tensors alive
         # (tens of MB) until a later block joins: 14.58 -> 14.28 ms/step on configs[1].  The network's first block is the
         # last one of the backward: it always joins, so nothing is left running when the backward returns.
+        if kacc is not None:
+            dense_bn1_fix(buf, gbuf, 0, C0, stats.mean, stats.rstd, kacc)     # the block input's channels: every layer read them
         if buf.shape[0] * buf.shape[2] * buf.shape[3] >= JOIN_MIN_PIXELS or ctx.first_block:
             _side_join(buf.device)
         return (gbuf[:, :C0], None, *grads)

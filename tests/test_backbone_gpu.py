@@ -425,6 +425,55 @@ def test_dense_bn1_bwd_fused(S, C, ld):
     assert torch.equal(gw[:, C:], gw[:, C:]) and float((xw[:, :C] - x).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("S,C,ld", [(25088, 960, 1024), (6272, 512, 1024), (300, 64, 96), (129, 128, 512), (401408 // 16, 64, 256)])
+def test_dense_bn1_single_pass(S, C, ld):
+    """Single-pass BatchNorm-1 backward with deferred mean terms (mcl_dense_bn1_dx_sums + mcl_dense_bn1_fix): TWO layers of a
+    dense block -- layer B reads channels [0, C + 32), layer A reads [0, C) -- run in backward order with the running totals
+    ``kacc``; the totals are applied to [C, C + 32) after B and to [0, C) after A, exactly as DenseBlockFn.backward does.  The
+    final gradient buffer must equal  g0 + dx_B + dx_A  of fp64 autograd through train-mode BatchNorm on the same bf16 data
+    (same bound as the two-pass kernel plus the extra bf16 roundings of the deferred terms), and dgamma / dbeta of both
+    layers their autograd values."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(S + C + 1)
+    C2 = C + 32
+    xw = ((torch.rand(S, ld, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)
+    gw = ((torch.rand(S, ld, generator=g) - 0.5) * 0.1).to(torch.bfloat16).to(DEV)
+    g0 = gw.clone()
+    xd = xw[:, :C2].double()
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    muf, rsf = mu.float().contiguous(), (1.0 / torch.sqrt(var + 1e-5)).float().contiguous()
+    kacc = torch.zeros((C2, 2), device=DEV)
+    ref = g0[:, :C2].double().clone()
+    layers = []
+    for Cl in (C2, C):                                                   # backward order: the later layer first
+        dz = ((torch.rand(S, 128, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)
+        W1 = ((torch.rand(128, Cl, generator=g) - 0.5) / 8).to(torch.bfloat16).to(DEV)
+        gam = (torch.rand(Cl, generator=g) + 0.5).to(DEV)
+        bet = (torch.rand(Cl, generator=g) - 0.5).to(DEV)
+        dg, db = torch.full((Cl,), 0.5, device=DEV), torch.full((Cl,), -0.25, device=DEV)
+        ws = torch.empty(L.mcl_dense_bn1_bwd_workspace_floats(S, Cl), device=DEV)
+        _lib.check(L.mcl_dense_bn1_dx_sums(dz.data_ptr(), W1.data_ptr(), Cl, xw.data_ptr(), ld, S, gam.data_ptr(), bet.data_ptr(),
+                                           muf.data_ptr(), rsf.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(), 1,
+                                           kacc.data_ptr(), gw.data_ptr(), ld, dn._stream()))
+        if Cl == C2:       # the 32 channels only layer B read are complete now
+            _lib.check(L.mcl_dense_bn1_fix(xw.data_ptr(), ld, gw.data_ptr(), ld, S, C, 32, muf.data_ptr(), rsf.data_ptr(),
+                                           kacc.data_ptr(), dn._stream()))
+        xr = xw[:, :Cl].double().clone().requires_grad_(True)
+        gr, br = gam.double().clone().requires_grad_(True), bet.double().clone().requires_grad_(True)
+        a = torch.relu((xr - xr.mean(0)) / torch.sqrt(xr.var(0, unbiased=False) + 1e-5) * gr + br)
+        (a @ W1.double().t()).backward(dz.double())
+        ref[:, :Cl] += xr.grad
+        layers.append((dg, db, gr.grad, br.grad))
+    _lib.check(L.mcl_dense_bn1_fix(xw.data_ptr(), ld, gw.data_ptr(), ld, S, 0, C, muf.data_ptr(), rsf.data_ptr(),
+                                   kacc.data_ptr(), dn._stream()))
+    assert_close_scaled(gw[:, :C2].float().cpu(), ref.cpu(), 1.2e-2, what="gbuf += dx_B + dx_A (single pass, deferred mean terms)")
+    for dg, db, rg, rb in layers:
+        assert_close_scaled((dg - 0.5).cpu(), rg.cpu(), 2e-4, what="dgamma")
+        assert_close_scaled((db + 0.25).cpu(), rb.cpu(), 2e-4, what="dbeta")
+    assert torch.equal(gw[:, C2:], g0[:, C2:])                           # nothing outside the slices was touched
+
+
 @pytest.mark.parametrize("S,C,ld", [(401408 // 16, 64, 256), (100352 // 4, 224, 512), (25088, 992, 1024), (6272, 512, 1024),
                                     (300, 96, 96), (129, 160, 512), (70001, 136, 256)])
 def test_dense_bn1_wrw_dx_fused(S, C, ld):
