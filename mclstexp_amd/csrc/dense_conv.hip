@@ -54,7 +54,11 @@ __device__ __forceinline__ uint4 bn_relu_chunk(uint4 v, const float (&sc)[8], co
 // WM wave-rows of RW (64 or 32) rows each, two wave-columns of 64 channels: BM = WM*RW rows, 128*WM threads.  <2, 32> is
 // the small-map form of <1, 64>: the same 64-row tile and LDS footprint but four waves instead of two per workgroup
 // (two waves per SIMD instead of one at two workgroups per CU).
-template <int WM, int RW = 64>
+// DEPTH = K-stages requested ahead in registers.  1 on the large maps (several workgroups per CU cover each other's
+// latency); on the 14 x 14 / 7 x 7 maps a CU holds one workgroup or none, the 64-channel stage multiplies in ~0.1 us and every
+// stage exposed a whole memory round trip (1.3 us per stage measured: 21 us for K = 992 at S = 6272) -- four stages in flight
+// there.
+template <int WM, int RW = 64, int DEPTH = 1>
 __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, long long S,
                                                                int K, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
@@ -84,21 +88,31 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
 
   // staging roles: A chunk column ca = tid & 7, rows (tid >> 3) + (NT/8)*i; B chunk column the same, rows (tid>>3) + (NT/8)*i
   const int cc = tid & 7, rr = tid >> 3;
-  uint4 ra[NA], rb[NB];
-  auto load_stage = [&](int k0) {
-    const int kc = k0 + cc * 8;
+  // Buffer loads, never predicated: rows past S lie beyond the x descriptor and return zeros; past the last stage both
+  // descriptors have size zero (zeros, no memory access).  (A branch or an exec mask around the loads makes the compiler
+  // drain ALL outstanding loads -- s_waitcnt vmcnt(0) -- before it touches a register set again, which serialises the
+  // stages in flight.)  Chunks past K inside a row read the neighbouring channels / the next weight row: store_stage zeroes
+  // them.
+  u32x4 rav[DEPTH][NA], rbv[DEPTH][NB];
+  const unsigned xbytes = (unsigned)((((long long)S - 1) * ldx + K) * 2), wbytes = (unsigned)((long long)BN * K * 2);
+  unsigned xoff[NA], woff[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const long long r = row0 + rr + (NT / 8) * i;
-      ra[i] = (r < S && kc < K) ? *reinterpret_cast<const uint4*>(x + r * ldx + kc) : make_uint4(0u, 0u, 0u, 0u);
-    }
+  for (int i = 0; i < NA; ++i) {
+    const long long r = row0 + rr + (NT / 8) * i;
+    xoff[i] = r < S ? (unsigned)((r * ldx + cc * 8) * 2) : 0xFFFFF000u;
+  }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int n = rr + (NT / 8) * i;
-      rb[i] = kc < K ? *reinterpret_cast<const uint4*>(W + (long long)n * K + kc) : make_uint4(0u, 0u, 0u, 0u);
-    }
+  for (int i = 0; i < NB; ++i) woff[i] = (unsigned)(((rr + (NT / 8) * i) * K + cc * 8) * 2);
+  auto load_stage = [&](u32x4 (&ra)[NA], u32x4 (&rb)[NB], int k0) {
+    const bool live = k0 < K;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, live ? xbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(W), 0, live ? wbytes : 0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[i] + (unsigned)k0 * 2u, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff[i] + (unsigned)k0 * 2u, 0, 0);
   };
-  auto store_stage = [&](int buf, int k0) {
+  auto store_stage = [&](const u32x4 (&ra)[NA], const u32x4 (&rb)[NB], int buf, int k0) {
     unsigned char* At = lds + buf * STAGE_B;
     unsigned char* Bt = At + A_B;
     const int kc = k0 + cc * 8;
@@ -117,14 +131,15 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
     for (int i = 0; i < NA; ++i) {
       const int r = rr + (NT / 8) * i;
       const long long rg = row0 + r;
-      uint4 v = bn_relu_chunk(ra[i], sc, sh);
+      uint4 v = bn_relu_chunk(make_uint4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]), sc, sh);
       if (rg >= S) v = make_uint4(0u, 0u, 0u, 0u);
       *reinterpret_cast<uint4*>(At + r * 128 + ((cc ^ ((r >> 1) & 7)) << 4)) = v;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int n = rr + (NT / 8) * i;
-      *reinterpret_cast<uint4*>(Bt + n * 128 + ((cc ^ ((n >> 1) & 7)) << 4)) = rb[i];
+      *reinterpret_cast<uint4*>(Bt + n * 128 + ((cc ^ ((n >> 1) & 7)) << 4)) =
+          kc < K ? make_uint4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
 
@@ -144,12 +159,7 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   const int arow = (wm * RW + l31) * 128, brow = (wn * 64 + l31) * 128;
 
   const int nst = (K + BK - 1) / BK;
-  load_stage(0);
-  store_stage(0, 0);
-  __syncthreads();
-  for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nst) load_stage((st + 1) * BK);
+  auto multiply = [&](int buf) {
     const unsigned char* At = lds + buf * STAGE_B;
     const unsigned char* Bt = At + A_B;
 #pragma unroll
@@ -164,8 +174,40 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (st + 1 < nst) store_stage(buf ^ 1, (st + 1) * BK);
+  };
+  if (DEPTH == 1) {
+    load_stage(rav[0], rbv[0], 0);
+    store_stage(rav[0], rbv[0], 0, 0);
     __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      const int buf = st & 1;
+      load_stage(rav[0], rbv[0], (st + 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(buf);
+      if (st + 1 < nst) store_stage(rav[0], rbv[0], buf ^ 1, (st + 1) * BK);
+      __syncthreads();
+    }
+  } else {
+    // register set d holds stage st0 + d; once a stage is in LDS its set takes stage + DEPTH (loads past K are masked off
+    // lane by lane: no branch, no memory access).  The loads are pinned at the top of the stage.
+    static_assert(DEPTH == 1 || (DEPTH % 2) == 0, "LDS parity must follow the register set");
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_stage(rav[d], rbv[d], d * BK);
+    store_stage(rav[0], rbv[0], 0, 0);
+    __syncthreads();
+    for (int st0 = 0; st0 < nst; st0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int st = st0 + d;
+        if (st < nst) {
+          load_stage(rav[d], rbv[d], (st + DEPTH) * BK);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(d & 1);
+          if (st + 1 < nst) store_stage(rav[(d + 1) % DEPTH], rbv[(d + 1) % DEPTH], (d + 1) & 1, (st + 1) * BK);
+          __syncthreads();
+        }
+      }
+    }
   }
 
   // ---- epilogue.  acc[i][j][r]: row wm*RW + i*32 + (r&3) + 8*(r>>2) + 4*h, channel wn*64 + j*32 + l31
@@ -290,7 +332,8 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   if (!x || !gamma || !beta || !mean || !rstd || !W || !z || !workspace || S <= 0 || K <= 0) return MCL_EINVAL;
   const bool want_stats = zmean || zvar || zrstd;   // all three or none (inference: BN2 uses running statistics)
   if (want_stats && (!zmean || !zvar || !zrstd)) return MCL_EINVAL;
-  if ((K % 8) || K > 1024 || (ldx % 8) || (ldz % 8) || ldz < BN || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+  if ((K % 8) || K > 1024 || (ldx % 8) || (ldz % 8) || ldz < BN || S * ldx * 2 >= 0xFFFFF000LL /* 32-bit buffer offsets */ ||
+      (reinterpret_cast<uintptr_t>(x) & 15u) ||
       (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(z) & 15u))
     return MCL_EUNSUPPORTED;
   const int wm = pick_wm(S);
@@ -298,16 +341,23 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   const int nblk = (int)((S + bm - 1) / bm);
   hipStream_t st = mcl_stream(stream);
   float2* part = reinterpret_cast<float2*>(workspace);
-#define MCL_LAUNCH(WMV, RWV)                                                                                         \
-  hipLaunchKernelGGL((conv1x1_fwd_kernel<WMV, RWV>), dim3(nblk), dim3(128 * WMV), 0, st, (const bf16_t*)x,           \
+#define MCL_LAUNCH(WMV, RWV, DPV)                                                                                    \
+  hipLaunchKernelGGL((conv1x1_fwd_kernel<WMV, RWV, DPV>), dim3(nblk), dim3(128 * WMV), 0, st, (const bf16_t*)x,      \
                      (long long)ldx, (long long)S, K, gamma, beta, mean, rstd, (const bf16_t*)W, (bf16_t*)z,          \
                      (long long)ldz, part, nblk)
   static const char* e_half = getenv("MCL_C1F_HALF");
   const bool half_waves = !(e_half && atoi(e_half) == 0);
   // (the same doubling for the 128- / 256-row tiles, which already run two waves per SIMD, measured no gain)
-  if (wm == 2) MCL_LAUNCH(2, 64);
-  else if (half_waves) MCL_LAUNCH(2, 32);
-  else MCL_LAUNCH(1, 64);
+  static const char* e_dp = getenv("MCL_C1F_DEPTH");
+  const int depth = e_dp ? atoi(e_dp) : 4;
+  static const char* e_dl = getenv("MCL_C1F_DEPTH_LARGE");
+  const int depth_large = e_dl ? atoi(e_dl) : 2;     // 12.41-12.44 ms/step at 1, 12.34 at 2 (interleaved A/B)
+  if (wm == 2 && depth_large == 2) MCL_LAUNCH(2, 64, 2);
+  else if (wm == 2) MCL_LAUNCH(2, 64, 1);
+  else if (half_waves && depth == 4) MCL_LAUNCH(2, 32, 4);
+  else if (half_waves && depth == 2) MCL_LAUNCH(2, 32, 2);
+  else if (half_waves) MCL_LAUNCH(2, 32, 1);
+  else MCL_LAUNCH(1, 64, 1);
 #undef MCL_LAUNCH
   if (want_stats)
     hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(BN), dim3(256), 0, st, (const float2*)part, nblk, BN,
