@@ -312,17 +312,18 @@ int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, i
                      const float* gamma, const float* beta, const float* mean, const float* rstd, const float* coef,
                      void* gbuf, int64_t ldg, mcl_stream_t stream);
 /* Single-pass form of mcl_dense_bn1_bwd for the latency-bound small maps.  dx = gamma*rstd*(g - mean g - xhat*mean(g*xhat)) is
- * linear in the two means: ONE kernel adds gamma*rstd*g into gbuf and reduces the sums (no separate reduce pass over dz and
- * x); its finalize adds dgamma / dbeta and the layer's mean terms gamma*rstd*(mean g, mean g*xhat) to ``kacc`` (2*C_total
- * floats, [c][2], zeroed by the caller when the dense block's backward starts).  Channel statistics (mean, rstd) are those
- * of the block's concat buffer, identical for every layer, so the totals of all layers reading a channel are applied once,
- * by mcl_dense_bn1_fix, when that channel's gradient is complete:  gbuf[s][c] -= K1[c] + K2[c]*xhat[s][c]  for c in
- * [c0, c0 + nc) (c0, nc multiples of 8).  workspace: mcl_dense_bn1_bwd_workspace_floats(S, C).
- * Replaces the same torch sequence as mcl_dense_bn1_bwd (/root/reference/model.py:75-76 via torchvision _DenseLayer).   */
+ * linear in the two means, and the statistics (mean, rstd) of a concat-buffer channel are the same for every layer of a dense
+ * block.  ONE kernel adds gamma*rstd*g into gbuf, reduces the two sums (no separate reduce pass over dz and x) and, when
+ * have_prev != 0, subtracts on the same elements the mean terms of the PREVIOUS pass  kprev[c] = gamma*rstd*(mean g, mean g*xhat)
+ * (2*C_total floats, [c][2]); its finalize adds dgamma / dbeta and overwrites kprev[0 .. C) with this layer's terms.  Every
+ * layer's mean terms thus reach the channels the next layer reads one pass late, and mcl_dense_bn1_fix applies them to the
+ * channels [c0, c0 + nc) the next pass does not cover (c0, nc multiples of 8):  gbuf[s][c] -= K1[c] + K2[c]*xhat[s][c].
+ * workspace: mcl_dense_bn1_bwd_workspace_floats(S, C).  Replaces the same torch sequence as mcl_dense_bn1_bwd
+ * (/root/reference/model.py:75-76 via torchvision _DenseLayer).                                                        */
 int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
                           const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
-                          float* dgamma, float* dbeta, int32_t accumulate_params, float* kacc, void* gbuf, int64_t ldg,
-                          mcl_stream_t stream);
+                          float* dgamma, float* dbeta, int32_t accumulate_params, float* kprev, int32_t have_prev, void* gbuf,
+                          int64_t ldg, mcl_stream_t stream);
 int mcl_dense_bn1_fix(const void* x, int64_t ldx, void* gbuf, int64_t ldg, int64_t S, int32_t c0, int32_t nc,
                       const float* mean, const float* rstd, const float* kacc, mcl_stream_t stream);
 /* Deterministic 1x1 weight gradient dW[M][N] (+)= dz[S][M]^T a'[S][N]: a' = a (gamma..rstd NULL: transition

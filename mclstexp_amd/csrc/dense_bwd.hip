@@ -38,8 +38,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 }
 
 // MODE 0: reduce (partials of sum g, sum g*xhat)      MODE 1: dx accumulate
-// MODE 2: ONE pass -- gbuf += gamma*rstd*g (the data-dependent term of dx) AND the partials of the two sums; the two mean
-// terms of dx, which are per-channel constants times (1, xhat), are added later for all layers at once (bn1_fix_kernel)
+// MODE 2: ONE pass -- gbuf += gamma*rstd*g (the data-dependent term of dx) AND the partials of the two sums.  The layer's own
+// two mean terms, per-channel constants times (1, xhat), are not known yet: they are applied ONE LAYER LATE, by the next
+// layer's pass over the same channels (``coef`` = the previous pass's finalized terms, NULL for the first layer of a block's
+// backward), and by bn1_fix_kernel for the 32 channels the next layer does not read
 // A workgroup keeps ONE column tile (its W1 block and per-channel constants are loaded once) and walks row tiles.
 // All global loads of a row tile (dz, x and -- dx launch -- the gradient-buffer chunks) are issued together at the
 // top, so the x / gradient latency hides under the dz staging and the MFMAs; LDS holds W1 (32 KB) + one 32 KB tile
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
     rs[j] = cvalid ? rstd[c] : 0.0f;
     sc[j] = cvalid ? gamma[c] * rs[j] : 0.0f;
     sh[j] = cvalid ? fmaf(-mu[j], sc[j], beta[c]) : 0.0f;
-    c1[j] = (MODE == 1 && cvalid) ? coef[2 * c] : 0.0f;
-    c2[j] = (MODE == 1 && cvalid) ? coef[2 * c + 1] : 0.0f;
+    c1[j] = (MODE >= 1 && coef != nullptr && cvalid) ? coef[2 * c] : 0.0f;
+    c2[j] = (MODE >= 1 && coef != nullptr && cvalid) ? coef[2 * c + 1] : 0.0f;
   }
   const int q = (lane & 15) >> 2, jj = lane & 3;
   const int g2 = 2 * ((lane >> 4) & 1) + (jj >> 1);
@@ -162,7 +164,9 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
       const int cl = wn * 64 + j * 32 + l31;
       s1[j] = s2[j] = 0.0f;
       // dx = sc*(g - c1 - xhat*c2) = sc*g + (ka*x + kb);   sum g*xhat = rs*(sum g*x - mu*sum g)
-      const float ka = -sc[j] * c2[j] * rs[j], kb = fmaf(-ka, mu[j], -sc[j] * c1[j]);
+      // MODE 1: c = (mean g, mean g*xhat) of THIS layer.  MODE 2: c = gamma*rstd*(mean g, mean g*xhat) of the PREVIOUS pass
+      const float ka = MODE == 2 ? -c2[j] * rs[j] : -sc[j] * c2[j] * rs[j];
+      const float kb = fmaf(-ka, mu[j], MODE == 2 ? -c1[j] : -sc[j] * c1[j]);
 #pragma unroll
       for (int i = 0; i < RI; ++i)
 #pragma unroll
@@ -177,8 +181,7 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
             }
           }
           // the x value of this element is dead: its slot takes the bf16 delta for the read-modify-write below
-          if (MODE == 1) xt[row * TN + cl] = f2bf(fmaf(sc[j], gi, fmaf(ka, xv, kb)));
-          if (MODE == 2) xt[row * TN + cl] = f2bf(sc[j] * gi);
+          if (MODE >= 1) xt[row * TN + cl] = f2bf(fmaf(sc[j], gi, fmaf(ka, xv, kb)));
         }
       if (MODE != 1) s2[j] = rs[j] * fmaf(-mu[j], s1[j], s2[j]);
     }
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __r
                                                                long long S, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, float* __restrict__ coef,
                                                                int accumulate_params,
-                                                               float* __restrict__ kacc = nullptr /* [C][2], += */,
+                                                               float* __restrict__ kacc = nullptr /* [C][2], single-pass form */,
                                                                const float* __restrict__ gamma = nullptr,
                                                                const float* __restrict__ rstd = nullptr) {
   __shared__ double red[2][4];
@@ -263,19 +266,19 @@ __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __r
     dgamma[c] = (float)b;
   }
   if (kacc != nullptr) {
-    // single-pass form: the layer's mean terms gamma*rstd*(mean g, mean g*xhat) join the block's running totals
+    // single-pass form: the layer's mean terms gamma*rstd*(mean g, mean g*xhat), for the next pass / bn1_fix_kernel
     const double scv = (double)gamma[c] * (double)rstd[c];
-    kacc[2 * c] += (float)(scv * a / (double)S);
-    kacc[2 * c + 1] += (float)(scv * b / (double)S);
+    kacc[2 * c] = (float)(scv * a / (double)S);
+    kacc[2 * c + 1] = (float)(scv * b / (double)S);
     return;
   }
   coef[2 * c] = (float)(a / (double)S);
   coef[2 * c + 1] = (float)(b / (double)S);
 }
 
-// The deferred mean terms of the BatchNorm-1 backward of ALL layers that read channels [c0, c0 + nc) of a dense block's
-// concat buffer, applied once, when the gradient of those channels is complete:
-//     gbuf[s][c] -= K1[c] + K2[c]*xhat[s][c],   xhat = (x - mean)*rstd        (K = running totals of bn1_bwd_finalize_kernel)
+// Single-pass form: the mean terms of the LAST pass over channels [c0, c0 + nc) of a dense block's concat buffer, for the
+// channels no later pass covers (the 32 output channels of layer k once layer k+1's pass is done; the block input after
+// layer 0's):     gbuf[s][c] -= K1[c] + K2[c]*xhat[s][c],   xhat = (x - mean)*rstd     (K from bn1_bwd_finalize_kernel)
 // Elementwise over S x nc bf16, 16-byte chunks, both tensors strided (channel slices of the block's buffers).
 __global__ __launch_bounds__(256) void bn1_fix_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ gbuf,
                                                       long long ldg, long long S, int c0, int nc,
@@ -824,17 +827,19 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   return MCL_OK;
 }
 
-// Single-pass form for the latency-bound small maps: ONE kernel accumulates gamma*rstd*g into the gradient buffer and
-// reduces the two sums; the finalize adds dgamma / dbeta and the layer's mean terms to the block's running totals
-// ``kacc`` ([C_total][2] fp32, zeroed by the caller at the start of the block's backward); mcl_dense_bn1_fix applies the
-// totals to a channel range once its gradient is complete.  Saves the separate reduce pass over (dz, x) of
-// mcl_dense_bn1_bwd: dx = gamma*rstd*(g - mean g - xhat*mean(g*xhat)) is linear in those two means.
+// Single-pass form for the latency-bound small maps.  dx = gamma*rstd*(g - mean g - xhat*mean(g*xhat)) is linear in the two
+// means, and the statistics (mean, rstd) of a concat-buffer channel are the same for every layer of the block.  ONE kernel adds
+// gamma*rstd*g into the gradient buffer, reduces the two sums, and -- on the same elements -- subtracts the mean terms of the
+// PREVIOUS pass (``kprev``: [C_total][2] fp32, read when ``have_prev``, then overwritten by this layer's finalize).  So every
+// layer's mean terms reach the channels the next layer reads one pass late (the buffer never carries more than one layer's
+// un-subtracted mean component), and mcl_dense_bn1_fix applies them to the channels the next layer does not read.  Saves the
+// separate reduce pass over (dz, x) of mcl_dense_bn1_bwd.
 extern "C" int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
                                      const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                     float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, float* kacc,
-                                     void* gbuf, int64_t ldg, mcl_stream_t stream) {
+                                     float* workspace, float* dgamma, float* dbeta, int32_t accumulate_params, float* kprev,
+                                     int32_t have_prev, void* gbuf, int64_t ldg, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || !kacc || !gbuf || S <= 0 ||
+  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || !kprev || !gbuf || S <= 0 ||
       C <= 0)
     return MCL_EINVAL;
   if ((C % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
@@ -850,10 +855,11 @@ extern "C" int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, 
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<2, 64>), dim3(gx, nct), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,
-                     (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, (const float*)nullptr,
+                     (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd,
+                     have_prev ? (const float*)kprev : (const float*)nullptr,
                      (bf16_t*)gbuf, (long long)ldg, part, nrt);
   hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float2*)part, nrt, C, (long long)S, dgamma,
-                     dbeta, (float*)nullptr, accumulate_params, kacc, gamma, rstd);
+                     dbeta, (float*)nullptr, accumulate_params, kprev, gamma, rstd);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

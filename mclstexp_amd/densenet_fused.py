@@ -289,13 +289,13 @@ def dense_bn1_bwd(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, me
 
 
 def dense_bn1_dx_sums(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
-                      kacc: Tensor, into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-    """Single-pass form of ``dense_bn1_bwd`` (csrc/dense_bwd.hip, mcl_dense_bn1_dx_sums): gbuf += gamma*rstd*g and the norm1
-    parameter gradients in ONE pass over (dz, x); the layer's two mean terms go to the block's running totals ``kacc``
-    ((C_total, 2) fp32) and reach the gradient buffer through ``dense_bn1_fix``."""
+                      kprev: Tensor, have_prev: bool, into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """Single-pass form of ``dense_bn1_bwd`` (csrc/dense_bwd.hip, mcl_dense_bn1_dx_sums): gbuf += gamma*rstd*g, minus the
+    previous pass's mean terms (``kprev`` (C_total, 2) fp32, when ``have_prev``), and the norm1 parameter gradients in ONE pass
+    over (dz, x); the finalize then overwrites kprev with this layer's mean terms."""
     px, S, C, ldx = _rows(x)
     pg, S2, C2, ldg = _rows(gbuf)
-    assert (S2, C2) == (S, C) and dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128 and kacc.numel() >= 2 * C
+    assert (S2, C2) == (S, C) and dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128 and kprev.numel() >= 2 * C
     L = _lib.lib()
     ws = _ws(L.mcl_dense_bn1_bwd_workspace_floats(S, C), x.device)
     if into_param_grads:
@@ -305,13 +305,14 @@ def dense_bn1_dx_sums(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor
         db = torch.empty(C, device=x.device, dtype=torch.float32)
     check(L.mcl_dense_bn1_dx_sums(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
                                   mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                  int(into_param_grads), kacc.data_ptr(), pg, ldg, _stream()), "mcl_dense_bn1_dx_sums")
+                                  int(into_param_grads), kprev.data_ptr(), int(have_prev), pg, ldg, _stream()),
+          "mcl_dense_bn1_dx_sums")
     return (None, None) if into_param_grads else (dg, db)
 
 
 def dense_bn1_fix(buf: Tensor, gbuf: Tensor, c0: int, nc: int, mean: Tensor, rstd: Tensor, kacc: Tensor) -> None:
-    """gbuf[:, c0:c0+nc] -= K1 + K2*xhat: the mean terms of every layer that read these channels of the concat buffer
-    ``buf``, applied once their gradient is complete (mcl_dense_bn1_fix).  mean / rstd / kacc are the block's full arrays."""
+    """gbuf[:, c0:c0+nc] -= K1 + K2*xhat: the mean terms of the last single-pass layer, for the channels of the concat buffer
+    ``buf`` that no later pass covers (mcl_dense_bn1_fix).  mean / rstd / kacc are the block's full arrays."""
     px, S, _, ldx = _rows(buf)
     pg, S2, _, ldg = _rows(gbuf)
     assert S == S2
@@ -319,9 +320,20 @@ def dense_bn1_fix(buf: Tensor, gbuf: Tensor, c0: int, nc: int, mean: Tensor, rst
                                        _stream()), "mcl_dense_bn1_fix")
 
 
-# Single-pass BatchNorm-1 backward (mean terms deferred, one pass over (dz, x) less per layer) on the maps where the
-# bottleneck weight gradient does not ride on the reduction anyway (below FUSED_BN1_WRW_MIN_PIXELS)
+# Single-pass BatchNorm-1 backward (each layer's mean terms applied one pass late, one pass over (dz, x) less per layer) on
+# the maps where the bottleneck weight gradient does not ride on the reduction anyway (below FUSED_BN1_WRW_MIN_PIXELS).  A first
+# version deferred ALL layers' mean terms to one correction per channel range: the bf16 buffer then carried up to 24 layers'
+# un-subtracted mean components and the final subtraction cancelled them in bf16 (worst parameter-gradient deviation of
+# test_cfg4_backbone_256px_accuracy_vs_fp64: 2.1 -> 12.3-13.2; stock bf16 ops 2.6-5.5); an fp32 side accumulator fixed that
+# but doubled the read-modify-write bytes (the gain fell from 0.31 to 0.05 ms/step).
+# Only on maps of at most 16 x 16 pixels (the 14 x 14 / 7 x 7 blocks; 16 x 16 / 8 x 8 at 256-pixel patches), whatever the
+# batch: the one-pass-late subtraction leaves a slightly larger rounding residue ALONG the directions (1, xhat) that every
+# later BatchNorm backward annihilates again -- harmless inside the network, but the first block's input gradient feeds norm0
+# directly, whose weight has an exactly zero true gradient (the following BatchNorm layers make the loss invariant to its
+# scale): at B = 4, where all four blocks would otherwise qualify, the noise on that parameter grew 6x
+# (tools/diag_accuracy_batch.py; test_cfg4_backbone_256px_accuracy_vs_fp64's maximum 2.1 -> 12).
 USE_BN1_SINGLE_PASS = os.environ.get("MCL_BN1_SINGLE_PASS", "1") != "0"
+BN1_SINGLE_PASS_MAX_MAP = int(os.environ.get("MCL_BN1_SINGLE_PASS_MAX_MAP", "256"))
 
 # Deterministic fusion of the bottleneck weight gradient with the BatchNorm-backward reduction (csrc/wrw_fused.hip): one
 # pass over (dz, x) replaces conv1x1_wrw + the reduce launch + its finalize; then the dx pass alone.  It does the least
@@ -664,7 +676,7 @@ class DenseBlockFn(torch.autograd.Function):
             ctx.cap["dz"] = [None] * L
             ctx.cap["gbuf"] = gbuf
         grads = [None] * (6 * L)
-        kacc = None             # running totals of the deferred BatchNorm-1 mean terms (single-pass form), [C_total][2]
+        kacc = None             # single-pass BatchNorm-1 backward: the previous pass's mean terms, [C_total][2]
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
             a, z, a2 = saved[3 * l: 3 * l + 3]
@@ -686,7 +698,7 @@ class DenseBlockFn(torch.autograd.Function):
                 # exists (event) and are joined only at the end of the block; dz stays referenced until then.
                 d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
                 if kacc is not None:
-                    # this layer's 32 output channels have their complete gradient now: the later layers' mean terms
+                    # this layer's 32 output channels: the mean terms of layer l+1, which no later pass covers
                     dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 if ctx.cap is not None:
@@ -700,11 +712,12 @@ class DenseBlockFn(torch.autograd.Function):
                     dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                                 gbuf[:, :cin], w1, into_param_grads=d1)
                     gw1 = None
-                elif USE_BN1_SINGLE_PASS:
-                    if kacc is None:
-                        kacc = torch.zeros((buf.shape[1], 2), device=buf.device, dtype=torch.float32)
+                elif USE_BN1_SINGLE_PASS and dz.shape[2] * dz.shape[3] <= BN1_SINGLE_PASS_MAX_MAP:
+                    have_prev = kacc is not None
+                    if not have_prev:
+                        kacc = torch.empty((buf.shape[1], 2), device=buf.device, dtype=torch.float32)
                     dg1, db1 = dense_bn1_dx_sums(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
-                                                 gbuf[:, :cin], kacc, into_param_grads=d1)
+                                                 gbuf[:, :cin], kacc, have_prev, into_param_grads=d1)
                 else:
                     dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                              gbuf[:, :cin], into_param_grads=d1)
@@ -779,7 +792,7 @@ class DenseBlockFn(torch.autograd.Function):
         # (tens of MB) until a later block joins: 14.58 -> 14.28 ms/step on configs[1].  The network's first block is the
         # last one of the backward: it always joins, so nothing is left running when the backward returns.
         if kacc is not None:
-            dense_bn1_fix(buf, gbuf, 0, C0, stats.mean, stats.rstd, kacc)     # the block input's channels: every layer read them
+            dense_bn1_fix(buf, gbuf, 0, C0, stats.mean, stats.rstd, kacc)     # the block input: the mean terms of layer 0
         if buf.shape[0] * buf.shape[2] * buf.shape[3] >= JOIN_MIN_PIXELS or ctx.first_block:
             _side_join(buf.device)
         return (gbuf[:, :C0], None, *grads)

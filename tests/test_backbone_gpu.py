@@ -427,12 +427,12 @@ def test_dense_bn1_bwd_fused(S, C, ld):
 
 @pytest.mark.parametrize("S,C,ld", [(25088, 960, 1024), (6272, 512, 1024), (300, 64, 96), (129, 128, 512), (401408 // 16, 64, 256)])
 def test_dense_bn1_single_pass(S, C, ld):
-    """Single-pass BatchNorm-1 backward with deferred mean terms (mcl_dense_bn1_dx_sums + mcl_dense_bn1_fix): TWO layers of a
-    dense block -- layer B reads channels [0, C + 32), layer A reads [0, C) -- run in backward order with the running totals
-    ``kacc``; the totals are applied to [C, C + 32) after B and to [0, C) after A, exactly as DenseBlockFn.backward does.  The
-    final gradient buffer must equal  g0 + dx_B + dx_A  of fp64 autograd through train-mode BatchNorm on the same bf16 data
-    (same bound as the two-pass kernel plus the extra bf16 roundings of the deferred terms), and dgamma / dbeta of both
-    layers their autograd values."""
+    """Single-pass BatchNorm-1 backward (mcl_dense_bn1_dx_sums + mcl_dense_bn1_fix): TWO layers of a dense block -- layer B
+    reads channels [0, C + 32), layer A reads [0, C) -- run in backward order exactly as DenseBlockFn.backward does: B's pass
+    (no previous terms), fix of [C, C + 32) with B's terms, A's pass (subtracts B's terms on [0, C) while it adds its own data
+    term), fix of [0, C) with A's terms.  The final gradient buffer must equal  g0 + dx_B + dx_A  of fp64 autograd through
+    train-mode BatchNorm on the same bf16 data (8e-3 of max, the two-pass kernel's bound), dgamma / dbeta of both layers their
+    autograd values."""
     from mclstexp_amd import _lib, densenet_fused as dn
     L = _lib.lib()
     g = torch.Generator().manual_seed(S + C + 1)
@@ -443,7 +443,7 @@ def test_dense_bn1_single_pass(S, C, ld):
     xd = xw[:, :C2].double()
     mu, var = xd.mean(0), xd.var(0, unbiased=False)
     muf, rsf = mu.float().contiguous(), (1.0 / torch.sqrt(var + 1e-5)).float().contiguous()
-    kacc = torch.zeros((C2, 2), device=DEV)
+    kprev = torch.full((C2, 2), float("nan"), device=DEV)                # never initialised by the host
     ref = g0[:, :C2].double().clone()
     layers = []
     for Cl in (C2, C):                                                   # backward order: the later layer first
@@ -455,10 +455,10 @@ def test_dense_bn1_single_pass(S, C, ld):
         ws = torch.empty(L.mcl_dense_bn1_bwd_workspace_floats(S, Cl), device=DEV)
         _lib.check(L.mcl_dense_bn1_dx_sums(dz.data_ptr(), W1.data_ptr(), Cl, xw.data_ptr(), ld, S, gam.data_ptr(), bet.data_ptr(),
                                            muf.data_ptr(), rsf.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(), 1,
-                                           kacc.data_ptr(), gw.data_ptr(), ld, dn._stream()))
-        if Cl == C2:       # the 32 channels only layer B read are complete now
+                                           kprev.data_ptr(), int(Cl == C), gw.data_ptr(), ld, dn._stream()))
+        if Cl == C2:       # the 32 channels only layer B read: no later pass covers them
             _lib.check(L.mcl_dense_bn1_fix(xw.data_ptr(), ld, gw.data_ptr(), ld, S, C, 32, muf.data_ptr(), rsf.data_ptr(),
-                                           kacc.data_ptr(), dn._stream()))
+                                           kprev.data_ptr(), dn._stream()))
         xr = xw[:, :Cl].double().clone().requires_grad_(True)
         gr, br = gam.double().clone().requires_grad_(True), bet.double().clone().requires_grad_(True)
         a = torch.relu((xr - xr.mean(0)) / torch.sqrt(xr.var(0, unbiased=False) + 1e-5) * gr + br)
@@ -466,8 +466,8 @@ def test_dense_bn1_single_pass(S, C, ld):
         ref[:, :Cl] += xr.grad
         layers.append((dg, db, gr.grad, br.grad))
     _lib.check(L.mcl_dense_bn1_fix(xw.data_ptr(), ld, gw.data_ptr(), ld, S, 0, C, muf.data_ptr(), rsf.data_ptr(),
-                                   kacc.data_ptr(), dn._stream()))
-    assert_close_scaled(gw[:, :C2].float().cpu(), ref.cpu(), 1.2e-2, what="gbuf += dx_B + dx_A (single pass, deferred mean terms)")
+                                   kprev.data_ptr(), dn._stream()))
+    assert_close_scaled(gw[:, :C2].float().cpu(), ref.cpu(), 8e-3, what="gbuf + dx_B + dx_A (single pass, mean terms one pass late)")
     for dg, db, rg, rb in layers:
         assert_close_scaled((dg - 0.5).cpu(), rg.cpu(), 2e-4, what="dgamma")
         assert_close_scaled((db + 0.25).cpu(), rb.cpu(), 2e-4, what="dbeta")
