@@ -114,6 +114,17 @@ int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
                       int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate_params, int32_t rows, int32_t cols,
                       mcl_stream_t stream);
 
+/* Fused attention core of the spot Transformer (/root/reference/model.py:49-57), head dimension 64, fp32 on the matrix cores
+ * (v_mfma_f32_32x32x2_f32), no (heads, B, B) tensor in HBM.  qkv: (B, 3*heads*64) fp32, row stride ld, columns q | k | v,
+ * head-major inside each; out: (B, heads*64), row stride ldo; lse: (heads, B) row log-sum-exp of the scaled scores (all the
+ * backward needs beside qkv and out).  Backward: dqkv (B, 3*heads*64, row stride ldq) from dout (row stride ldo, as out);
+ * dvec: (heads, B) fp32 scratch.  One launch forward, two backward (the unfused sequence: 3 + 5).  16-byte aligned bases,
+ * strides multiples of 4 floats; dim_head != 64 -> MCL_EUNSUPPORTED (callers keep the GEMM + softmax path for it).      */
+int mcl_attention_fwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale, float* out,
+                      int64_t ldo, float* lse, mcl_stream_t stream);
+int mcl_attention_bwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale, const float* out,
+                      const float* dout, int64_t ldo, const float* lse, float* dvec, float* dqkv, int64_t ldq,
+                      mcl_stream_t stream);
 /* ---------------------------------------------------------------- K4 attention softmax (model.py:53-54)
  * In place over n_rows rows of length cols (row stride ld):  p = softmax(scale * s).           */
 int mcl_softmax_rows_fwd(float* s, int64_t ld, int32_t n_rows, int32_t cols, float scale, mcl_stream_t stream);

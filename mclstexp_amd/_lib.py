@@ -60,6 +60,8 @@ PROTOTYPES = {
     "mcl_embed_scatter_rows": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
     "mcl_layernorm_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_f, c_p],
     "mcl_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p],
+    "mcl_attention_fwd": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
+    "mcl_attention_bwd": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p],
     "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],

@@ -94,6 +94,15 @@ def _bn1_dx(a):                 # (dz, W1, C, x, ldx, S, ...): dz + x + g read, 
     return 2 * S * (128 + 3 * C)
 
 
+def _bn1_dx_sums(a):            # (dz, W1, C, x, ldx, S, ...): dz + x + g read, g written -- the whole BatchNorm-1 backward of a layer
+    C, S = a[2], a[5]
+    return 2 * S * (128 + 3 * C)
+
+
+def _bn1_fix(a):                # (x, ldx, gbuf, ldg, S, c0, nc, ...): x + g read, g written on nc channels
+    return 2 * a[4] * 3 * a[6]
+
+
 def _adam_table(a):             # (p, m, v, rows, cols, ...): read p, m, v; write p, m, v
     return 24 * a[3] * a[4]
 
@@ -112,10 +121,14 @@ def _e(kernels, b, strict=None, flops=_zero, bound=None):
 
 TABLE = {
     "mcl_conv1x1_wrw_det": _e("wrw_partial_kernel + wrw_merge_kernel", _conv1x1_wrw_det, flops=_conv1x1_wrw_det_flops),
-    "mcl_dense_conv3x3_wrw_det": _e("conv3x3_wrw_ky_kernel + wrw_merge_kernel", _conv3x3_wrw_det, flops=_conv3x3_flops_S3,
+    "mcl_dense_conv3x3_wrw_det": _e("conv3x3_wrw_rows_kernel (56x56, 28x28 maps) / conv3x3_wrw_ky_kernel + wrw_merge_kernel",
+                                    _conv3x3_wrw_det, flops=_conv3x3_flops_S3,
                                     bound="mfma/lds"),
     "mcl_dense_bn1_wrw": _e("wrw_partial_kernel<Gram> + wrw_merge_kernel", _bn1_wrw, flops=_bn1_wrw_flops),
     "mcl_dense_bn1_dx": _e("bn1_bwd_kernel<1>", _bn1_dx, flops=_bn1_flops),
+    "mcl_dense_bn1_dx_sums": _e("bn1_bwd_kernel<2> (single pass: dx data term + previous layer's mean terms + sums) + "
+                                "bn1_bwd_finalize_kernel", _bn1_dx_sums, flops=_bn1_flops),
+    "mcl_dense_bn1_fix": _e("bn1_fix_kernel", _bn1_fix, bound="latency"),
     "mcl_dense_bn1_bwd": _e("bn1_bwd_kernel<0> + bn1_bwd_finalize_kernel + bn1_bwd_kernel<1>", _bn1_bwd, _bn1_bwd_strict,
                             flops=lambda a: 2 * _bn1_flops(a)),
     "mcl_dense_conv3x3_bwd": _e("conv3x3_bwd_kernel + finalize + bn2_dz_kernel", _conv3x3_bwd, _conv3x3_bwd_strict,

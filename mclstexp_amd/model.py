@@ -65,15 +65,15 @@ def _gelu_grad(x: Tensor) -> Tensor:
 class _AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, heads, dim_head):
-        out, P = ops.attention_core_fwd(qkv, heads, dim_head)
-        ctx.save_for_backward(qkv, P)
+        out, aux = ops.attention_core_fwd(qkv, heads, dim_head)
+        ctx.save_for_backward(qkv, out, aux)
         ctx.hd = (heads, dim_head)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, P = ctx.saved_tensors
-        return ops.attention_core_bwd(dout, qkv, P, *ctx.hd), None, None
+        qkv, out, aux = ctx.saved_tensors
+        return ops.attention_core_bwd(dout, qkv, out, aux, *ctx.hd), None, None
 
 
 def _linear(m: nn.Linear, x: Tensor, gelu: bool = False) -> Tensor:

@@ -222,8 +222,44 @@ class LayerNormFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- attention core (v1: materialised P)
+def _attention_fusable(qkv: Tensor, dim_head: int) -> bool:
+    return (dim_head == 64 and qkv.dtype == torch.float32 and qkv.stride(1) == 1 and qkv.stride(0) % 4 == 0
+            and qkv.data_ptr() % 16 == 0)
+
+
 def attention_core_fwd(qkv: Tensor, heads: int, dim_head: int) -> Tuple[Tensor, Tensor]:
-    """model.py:52-56 on the (B, 3*h*d) to_qkv output: returns (out (B, h*d), P (h, B, B))."""
+    """model.py:52-56 on the (B, 3*h*d) to_qkv output: returns (out (B, h*d), aux) where aux is what the backward needs:
+    the row log-sum-exp (h, B) of the fused kernel (csrc/attention.hip: head dimension 64, no (h, B, B) tensor in HBM), or
+    the probabilities P (h, B, B) of the GEMM + softmax sequence (any head dimension, unaligned views)."""
+    if _attention_fusable(qkv, dim_head):
+        B, inner = qkv.shape[0], heads * dim_head
+        out = torch.empty((B, inner), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((heads, B), device=qkv.device, dtype=torch.float32)
+        check(_lib.lib().mcl_attention_fwd(qkv.data_ptr(), qkv.stride(0), B, heads, dim_head, dim_head ** -0.5, out.data_ptr(),
+                                           inner, lse.data_ptr(), _stream()), "mcl_attention_fwd")
+        return out, lse
+    return attention_core_fwd_unfused(qkv, heads, dim_head)
+
+
+def attention_core_bwd(dout: Tensor, qkv: Tensor, out: Tensor, aux: Tensor, heads: int, dim_head: int) -> Tensor:
+    """Returns dqkv (B, 3*h*d); ``aux`` as returned by attention_core_fwd."""
+    if aux.dim() == 3:
+        return attention_core_bwd_unfused(dout, qkv, aux, heads, dim_head)
+    B, inner = qkv.shape[0], heads * dim_head
+    dout = _rowmajor(dout, "dout")
+    if dout.data_ptr() % 16 or dout.stride(0) != inner or out.stride(0) != inner:
+        dout = dout.contiguous()
+        out = out.contiguous()
+    dqkv = torch.empty((B, 3 * inner), device=qkv.device, dtype=torch.float32)
+    dvec = torch.empty((heads, B), device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().mcl_attention_bwd(qkv.data_ptr(), qkv.stride(0), B, heads, dim_head, dim_head ** -0.5, out.data_ptr(),
+                                       dout.data_ptr(), inner, aux.data_ptr(), dvec.data_ptr(), dqkv.data_ptr(), 3 * inner,
+                                       _stream()), "mcl_attention_bwd")
+    return dqkv
+
+
+def attention_core_fwd_unfused(qkv: Tensor, heads: int, dim_head: int) -> Tuple[Tensor, Tensor]:
+    """The GEMM + softmax sequence: returns (out (B, h*d), P (h, B, B))."""
     B = qkv.shape[0]
     inner = heads * dim_head
     ld = qkv.stride(0)
@@ -238,7 +274,7 @@ def attention_core_fwd(qkv: Tensor, heads: int, dim_head: int) -> Tuple[Tensor, 
     return out, P
 
 
-def attention_core_bwd(dout: Tensor, qkv: Tensor, P: Tensor, heads: int, dim_head: int) -> Tensor:
+def attention_core_bwd_unfused(dout: Tensor, qkv: Tensor, P: Tensor, heads: int, dim_head: int) -> Tensor:
     """Returns dqkv (B, 3*h*d)."""
     B = qkv.shape[0]
     inner = heads * dim_head
@@ -300,7 +336,7 @@ class AttnBlockFn(torch.autograd.Function):
         dwo = linear_bwd_weight(dx1, o, p_o)
         dbo = colsum(dx1, q_bo)
         do = linear_bwd_data(dx1, wo)
-        dqkv = attention_core_bwd(do, qkv, P, ctx.heads, ctx.dim_head)
+        dqkv = attention_core_bwd(do, qkv, o, P, ctx.heads, ctx.dim_head)
         dwqkv = linear_bwd_weight(dqkv, u1, p_qkv)
         du1 = linear_bwd_data(dqkv, wqkv)
         dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, params=(q_g1, q_be1))

@@ -113,7 +113,7 @@ def test_gemm_unaligned_views(ops):
     """Operands that are strided views (q/k/v slices of qkv) and 4-byte-aligned-only bases."""
     B, H, d = 19, 3, 64
     qkv = _rand(B, 3 * H * d, seed=3).to(DEV)
-    out, P = ops.attention_core_fwd(qkv, H, d)
+    out, P = ops.attention_core_fwd_unfused(qkv, H, d)
     q, k, v = qkv.cpu().double().view(B, 3, H, d).permute(1, 2, 0, 3)
     Pref = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1)
     assert_close(P.cpu(), Pref, 2e-6, what="attention probabilities")
@@ -123,6 +123,30 @@ def test_gemm_unaligned_views(ops):
     W = _rand(7, 40, seed=10).to(DEV)
     y, _ = ops.linear_fwd(x, W)
     assert_close_scaled(y.cpu(), x.cpu().double() @ W.cpu().double().t(), 2e-6, what="unaligned base")
+
+
+@pytest.mark.parametrize("B,H", [(128, 8), (19, 3), (8, 8), (300, 2), (257, 1), (33, 8)])
+def test_attention_fused_fwd_bwd(ops, B, H):
+    """csrc/attention.hip (head dimension 64, fp32 on the matrix cores, online softmax over key blocks of 128, no (h, B, B)
+    tensor in HBM) vs fp64 autograd of model.py:52-56 on the same qkv: output, log-sum-exp and all three gradients; ragged
+    query / key blocks, more than one key block, and agreement with the GEMM + softmax sequence it replaces."""
+    d = 64
+    qkv = (_rand(B, 3 * H * d, seed=B + H) * 1.5).to(DEV)
+    dout = _rand(B, H * d, seed=B + H + 1).to(DEV)
+    out, lse = ops.attention_core_fwd(qkv, H, d)
+    assert lse.shape == (H, B)
+    dqkv = ops.attention_core_bwd(dout, qkv, out, lse, H, d)
+    x = qkv.double().clone().requires_grad_(True)
+    q, k, v = x.view(B, 3, H, d).permute(1, 2, 0, 3)
+    sc = q @ k.transpose(1, 2) * d ** -0.5
+    ref = (torch.softmax(sc, -1) @ v).permute(1, 0, 2).reshape(B, H * d)
+    ref.backward(dout.double())
+    assert_close_scaled(out.cpu(), ref.detach().cpu(), 3e-6, what="fused attention out")
+    assert_close(lse.cpu(), torch.logsumexp(sc, -1).detach().cpu(), 1e-5, rtol=1e-6, what="row log-sum-exp")
+    assert_close_scaled(dqkv.cpu(), x.grad.cpu(), 5e-6, what="fused attention dqkv")
+    out_u, P = ops.attention_core_fwd_unfused(qkv, H, d)
+    assert_close_scaled(out.cpu(), out_u.cpu().double(), 3e-6, what="fused vs unfused out")
+    assert_close_scaled(dqkv.cpu(), ops.attention_core_bwd(dout, qkv, out_u, P, H, d).cpu().double(), 5e-6, what="fused vs unfused dqkv")
 
 
 def test_gemm_bf16_mode(ops):

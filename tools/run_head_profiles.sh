@@ -29,6 +29,6 @@ python tools/bench_spot_path.py > gpurun_out/head_spot.json 2>/dev/null
 MCL_FORCE_DIST=1 python bench.py --steps 100 --warmup 20 --no_cpu_baseline --profile_steps 0 > gpurun_out/head_bench_dp_size1.json 2>/dev/null
 MCL_FORCE_DIST=1 MCL_GRAD_WIRE=bf16 MCL_GRAD_BUCKETS=4 python bench.py --steps 60 --warmup 15 --no_cpu_baseline --profile_steps 0 > gpurun_out/head_bench_dp_size1_bf16wire.json 2>/dev/null
 # per-layer kernel durations of one step (serial trace)
-python tools/layer_times.py $(ls -d gpurun_out/hp_keep_ks/*.db | head -1) conv3x3_fwd conv3x3_bwd bn2_dz conv3x3_wrw conv1x1_fwd "bn1_bwd_kernel<1" "bn1_bwd_kernel<0" "wrw_partial_kernel<1" "wrw_partial_kernel<2" > gpurun_out/head_layer_times_serial.txt 2>/dev/null
+python tools/layer_times.py $(ls -d gpurun_out/hp_keep_ks/*.db | head -1) conv3x3_fwd conv3x3_bwd bn2_dz conv3x3_wrw conv1x1_fwd "bn1_bwd_kernel<1" "bn1_bwd_kernel<0" "bn1_bwd_kernel<2" bn1_fix "wrw_partial_kernel<1" "wrw_partial_kernel<2" > gpurun_out/head_layer_times_serial.txt 2>/dev/null
 bash tools/run_other_configs.sh > /dev/null 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
