@@ -697,22 +697,26 @@ class DenseBlockFn(torch.autograd.Function):
                 # waits: the two atomics-bound weight-gradient kernels of the layer start on the side stream once dz
                 # exists (event) and are joined only at the end of the block; dz stays referenced until then.
                 d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
+                fused_wrw = _bn1_wrw_ok(w1) and z.shape[0] * z.shape[2] * z.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS
+                single = not fused_wrw and USE_BN1_SINGLE_PASS and z.shape[2] * z.shape[3] <= BN1_SINGLE_PASS_MAX_MAP
                 if kacc is not None:
-                    # this layer's 32 output channels: the mean terms of layer l+1, which no later pass covers
-                    dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
+                    if single:      # this layer's 32 output channels: the mean terms of layer l+1, which no later pass covers
+                        dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
+                    else:           # (a two-pass layer after single-pass ones: it will not apply them -- all channels now)
+                        dense_bn1_fix(buf, gbuf, 0, cin + growth, stats.mean, stats.rstd, kacc)
+                        kacc = None
                 dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 if ctx.cap is not None:
                     ctx.cap["dz"][l] = dz
                 ev = torch.cuda.Event()
                 ev.record(main)
-                fused_wrw = _bn1_wrw_ok(w1) and dz.shape[0] * dz.shape[2] * dz.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS
                 if fused_wrw:
                     # the bottleneck weight gradient rides on the BatchNorm-backward reduction (one pass over dz, x;
                     # no atomics): it is part of the main chain now, only the 3x3 weight gradient forks off
                     dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                                 gbuf[:, :cin], w1, into_param_grads=d1)
                     gw1 = None
-                elif USE_BN1_SINGLE_PASS and dz.shape[2] * dz.shape[3] <= BN1_SINGLE_PASS_MAX_MAP:
+                elif single:
                     have_prev = kacc is not None
                     if not have_prev:
                         kacc = torch.empty((buf.shape[1], 2), device=buf.device, dtype=torch.float32)
@@ -731,8 +735,14 @@ class DenseBlockFn(torch.autograd.Function):
                 continue
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
-            if kacc is not None:                                # (a layer off the fast path inside a single-pass block)
-                dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
+            sp_here = (USE_BN1_SINGLE_PASS and fused1 and z.shape[2] * z.shape[3] <= BN1_SINGLE_PASS_MAX_MAP
+                       and not (_bn1_wrw_ok(w1) and z.shape[0] * z.shape[2] * z.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS))
+            if kacc is not None:
+                if sp_here:                                     # the previous pass's mean terms: this layer's 32 output channels
+                    dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
+                else:                                           # a two-pass layer follows: it will not apply them -- all channels now
+                    dense_bn1_fix(buf, gbuf, 0, cin + growth, stats.mean, stats.rstd, kacc)
+                    kacc = None
             if fused2:
                 # fused forward: a2 = relu(bn2(z)) was never stored.  Both kernels read dy in place from the gradient
                 # buffer (row stride C_total): no contiguous copy, no MIOpen call
@@ -773,8 +783,15 @@ class DenseBlockFn(torch.autograd.Function):
                         dw1 = ("direct", conv1x1_wrw(dz, buf[:, :cin], w1, bn=bn1))
                 else:
                     dw1 = ("direct", conv1x1_wrw(dz, buf[:, :cin], w1, bn=bn1))
-                dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
-                                         gbuf[:, :cin], into_param_grads=d1)
+                if sp_here:
+                    have_prev = kacc is not None                # (the same kernels as the side-stream schedule above)
+                    if not have_prev:
+                        kacc = torch.empty((buf.shape[1], 2), device=buf.device, dtype=torch.float32)
+                    dg1, db1 = dense_bn1_dx_sums(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                                 gbuf[:, :cin], kacc, have_prev, into_param_grads=d1)
+                else:
+                    dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
+                                             gbuf[:, :cin], into_param_grads=d1)
                 if side is not None:
                     main.wait_stream(side)                      # join: dz / dy may be released or overwritten now
             else:

@@ -179,6 +179,35 @@ def test_model_uses_fused_backbone_and_matches_unfused():
     assert (g1 - g2).abs().max() < 5e-3 * g2.abs().max()
 
 
+def test_backward_schedules_agree_bit_for_bit():
+    """The dense blocks' backward with the weight gradients on the side stream (one fork per layer, joins per block) and the
+    same kernels issued on one stream (MCL_SIDE_STREAM=0: the schedule the serial profiles trace) must give bit-identical
+    features and parameter gradients -- both run the single-pass BatchNorm-1 backward on the small maps, the Gram path on the
+    large ones, and every kernel is deterministic."""
+    from mclstexp_amd import backbones, densenet_fused as dn
+    torch.manual_seed(1)
+    enc = backbones.ImageEncoder().to(DEV).to(memory_format=torch.channels_last).train()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand((32, 3, 224, 224), device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    dy = torch.rand((32, 1024), device=DEV, generator=g) - 0.5
+    runs = []
+    keep = dn.USE_SIDE_STREAM
+    try:
+        for side in (True, False):
+            dn.USE_SIDE_STREAM = side
+            for p in enc.parameters():
+                p.grad = torch.zeros_like(p)
+            y = enc.forward_fused(x, torch.bfloat16)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            runs.append((y.detach().clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}))
+    finally:
+        dn.USE_SIDE_STREAM = keep
+    assert torch.equal(runs[0][0], runs[1][0])
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
 def test_direct_param_grads_and_bf16_shadow():
     """FusedAdam's flat bucket lets the fused backbone (a) add gradients straight into .grad and (b) read bf16
     weight views of ONE flat shadow cast.  (a) must equal the plain autograd hand-over; (b) must equal
