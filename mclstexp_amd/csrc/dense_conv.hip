@@ -79,12 +79,16 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   const int wm = wave >> 1, wn = wave & 1;
   const long long row0 = (long long)blockIdx.x * BM;
 
-  for (int k = tid; k < K; k += NT) {
-    const float sc = gamma[k] * rstd[k];
-    tab[k] = sc;
-    tab[1024 + k] = fmaf(-mean[k], sc, beta[k]);
-  }
-  __syncthreads();
+  // (built AFTER the first stages' loads are in flight: its four dependent global loads per channel would otherwise sit in
+  // front of them -- one memory round trip at the head of every workgroup)
+  auto build_tab = [&]() {
+    for (int k = tid; k < K; k += NT) {
+      const float sc = gamma[k] * rstd[k];
+      tab[k] = sc;
+      tab[1024 + k] = fmaf(-mean[k], sc, beta[k]);
+    }
+    __syncthreads();
+  };
 
   // staging roles: A chunk column ca = tid & 7, rows (tid >> 3) + (NT/8)*i; B chunk column the same, rows (tid>>3) + (NT/8)*i
   const int cc = tid & 7, rr = tid >> 3;
@@ -177,6 +181,8 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   };
   if (DEPTH == 1) {
     load_stage(rav[0], rbv[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
+    build_tab();
     store_stage(rav[0], rbv[0], 0, 0);
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
@@ -193,6 +199,8 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
     static_assert(DEPTH == 1 || (DEPTH % 2) == 0, "LDS parity must follow the register set");
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) load_stage(rav[d], rbv[d], d * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    build_tab();
     store_stage(rav[0], rbv[0], 0, 0);
     __syncthreads();
     for (int st0 = 0; st0 < nst; st0 += DEPTH) {
