@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // top, so the x / gradient latency hides under the dz staging and the MFMAs; LDS holds W1 (32 KB) + one 32 KB tile
 // that is first dz, then x, then (dx launch) the bf16 deltas: 64 KB, two workgroups per CU.
 template <int MODE, int TMv>
-__global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ W1,
+__global__ __launch_bounds__(256, (TMv == 64 && MODE != 2 ? 3 : 2)) void bn1_bwd_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ W1,
                                                          int K /* C_in: row length of W1 */,
                                                          const bf16_t* __restrict__ x, long long ldx, long long S,
                                                          const float* __restrict__ gamma,
@@ -69,16 +69,39 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
 
   const int cc = tid & 15, rr = tid >> 4;
   const bool cok = n0 + cc * 8 < K;
-  // ---- once per workgroup: W1[:, n0:n0+128] and the per-channel constants of this lane's two channels
+  // ---- the first row tile's global loads go out BEFORE the once-per-workgroup staging below (otherwise they would wait
+  // behind its memory round trip: on the small maps a workgroup multiplies one to four tiles)
+  constexpr int NL = TMv / 16, RI = TMv / 64;   // 16-byte chunks per thread and tile; 32-row blocks per wave
+  uint4 dzr[NL], xr[NL], gr[NL];
+  auto issue_loads = [&](int rt) {
+    const long long row0 = (long long)rt * TMv;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int k = rr + 16 * i;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (cok) v = *reinterpret_cast<const uint4*>(W1 + (long long)k * K + n0 + cc * 8);
-    // swizzle for the transposing read: 4 consecutive k rows (k & 3) must land in 4 different 64-byte bank
-    // windows -> XOR the chunk's bits 2-3 with (k & 3); bits 0-1 with ((k >> 2) & 3)
-    const int f = ((k & 3) << 2) | ((k >> 2) & 3);
-    *reinterpret_cast<uint4*>(wt + k * 256 + ((cc ^ f) << 4)) = v;
+    for (int i = 0; i < NL; ++i) {
+      const long long rg = row0 + rr + 16 * i;
+      const bool ok = rg < S;
+      dzr[i] = ok ? *reinterpret_cast<const uint4*>(dz + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      xr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(x + rg * ldx + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      if (MODE >= 1)
+        gr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(gbuf + rg * ldg + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if ((int)blockIdx.x < nrt) issue_loads(blockIdx.x);
+  // ---- once per workgroup: W1[:, n0:n0+128] and the per-channel constants of this lane's two channels
+  {
+    uint4 wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = rr + 16 * i;
+      wv[i] = cok ? *reinterpret_cast<const uint4*>(W1 + (long long)k * K + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = rr + 16 * i;
+      // swizzle for the transposing read: 4 consecutive k rows (k & 3) must land in 4 different 64-byte bank
+      // windows -> XOR the chunk's bits 2-3 with (k & 3); bits 0-1 with ((k >> 2) & 3)
+      const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+      *reinterpret_cast<uint4*>(wt + k * 256 + ((cc ^ f) << 4)) = wv[i];
+    }
   }
   float mu[2], rs[2], sc[2], sh[2], c1[2], c2[2];
 #pragma unroll
@@ -97,18 +120,8 @@ __global__ __launch_bounds__(256, (TMv == 64 ? 3 : 2)) void bn1_bwd_kernel(const
 
   for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
     const long long row0 = (long long)rt * TMv;
-    // ---- all global loads of this row tile, issued together
-    constexpr int NL = TMv / 16, RI = TMv / 64;   // 16-byte chunks per thread and tile; 32-row blocks per wave
-    uint4 dzr[NL], xr[NL], gr[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const long long rg = row0 + rr + 16 * i;
-      const bool ok = rg < S;
-      dzr[i] = ok ? *reinterpret_cast<const uint4*>(dz + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
-      xr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(x + rg * ldx + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
-      if (MODE >= 1)
-        gr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(gbuf + rg * ldg + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
-    }
+    // ---- all global loads of this row tile, issued together (the first tile's are in flight already)
+    if (rt != (int)blockIdx.x) issue_loads(rt);
     __syncthreads();   // the previous row tile is done with the shared tile
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -792,11 +805,9 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
       (reinterpret_cast<uintptr_t>(W1) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
       (reinterpret_cast<uintptr_t>(gbuf) & 15u))
     return MCL_EUNSUPPORTED;
-  // 64-row tiles: 50 KB of LDS and <= 168 VGPRs -> three workgroups per CU instead of two.  These kernels spend
-  // 55 % of their wave cycles in s_waitcnt (memory latency): 2302 -> 1835 us/step (dx) and 1774 -> 1561 us/step (reduce)
-  // summed over the 58 layers, faster in every block; MCL_BN1_TM=128 selects the 128-row tiling for A/B runs.
-  static const char* e_tm = getenv("MCL_BN1_TM");
-  const int tmv = (e_tm && atoi(e_tm) == 128) ? 128 : 64;
+  // 64-row tiles: 50 KB of LDS and <= 168 VGPRs -> three workgroups per CU instead of two (the 128-row tiling of round 1 lost
+  // in every block: 2302 -> 1835 us/step (dx), 1774 -> 1561 us/step (reduce) summed over the 58 layers).
+  const int tmv = 64;
   const int nrt = (int)((S + tmv - 1) / tmv), nct = (C + TN - 1) / TN;
   float2* part = reinterpret_cast<float2*>(workspace);
   float* coef = workspace + (int64_t)nrt * 2 * C;
@@ -810,18 +821,16 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   static const char* e_gx = getenv("MCL_MAIN_GRID");
   static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
   const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
-  int gx = ((tmv == 64 ? gcap : 512) + nct - 1) / nct;
+  int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
 #define MCL_BN1(MODE, TMV, COEF, GB, LDG, PART)                                                                         \
   hipLaunchKernelGGL((bn1_bwd_kernel<MODE, TMV>), grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,       \
                      (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, COEF, GB, LDG, PART, nrt)
-  if (tmv == 64) MCL_BN1(0, 64, (const float*)nullptr, (bf16_t*)nullptr, 0LL, part);
-  else MCL_BN1(0, 128, (const float*)nullptr, (bf16_t*)nullptr, 0LL, part);
+  MCL_BN1(0, 64, (const float*)nullptr, (bf16_t*)nullptr, 0LL, part);
   hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float2*)part, nrt, C,
                      (long long)S, dgamma, dbeta, coef, accumulate_params);
-  if (tmv == 64) MCL_BN1(1, 64, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
-  else MCL_BN1(1, 128, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
+  MCL_BN1(1, 64, (const float*)coef, (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr);
 #undef MCL_BN1
   MCL_CHECK_LAUNCH();
   return MCL_OK;
