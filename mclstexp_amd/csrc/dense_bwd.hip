@@ -299,11 +299,35 @@ __global__ __launch_bounds__(256) void bn1_fix_kernel(const bf16_t* __restrict__
                                                       const float* __restrict__ kacc) {
   const int cpr = nc >> 3;                                   // chunks per row
   const long long n = S * cpr;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  // a thread keeps its channel chunk for the whole launch when the grid stride is a multiple of the chunks per row (always
+  // for the 32-channel ranges, cpr = 4): its 16 constants are computed once, after the first chunk's loads have gone out
+  const long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, istride = (long long)gridDim.x * 256;
+  const bool fixed = (istride % cpr) == 0;
+  uint4 xv = make_uint4(0u, 0u, 0u, 0u), gv = xv;
+  if (i0 < n) {
+    const long long row = i0 / cpr;
+    const int c = c0 + (int)(i0 - row * cpr) * 8;
+    xv = *reinterpret_cast<const uint4*>(x + row * ldx + c);
+    gv = *reinterpret_cast<const uint4*>(gbuf + row * ldg + c);
+  }
+  float kav[8], kbv[8];
+  auto consts = [&](int c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float k1 = kacc[2 * (c + e)], k2 = kacc[2 * (c + e) + 1];
+      kav[e] = k2 * rstd[c + e];
+      kbv[e] = fmaf(-kav[e], mean[c + e], k1);
+    }
+  };
+  if (i0 < n) consts(c0 + (int)(i0 % cpr) * 8);
+  for (long long i = i0; i < n; i += istride) {
     const long long row = i / cpr;
     const int c = c0 + (int)(i - row * cpr) * 8;
-    const uint4 xv = *reinterpret_cast<const uint4*>(x + row * ldx + c);
-    uint4 gv = *reinterpret_cast<const uint4*>(gbuf + row * ldg + c);
+    if (i != i0) {
+      xv = *reinterpret_cast<const uint4*>(x + row * ldx + c);
+      gv = *reinterpret_cast<const uint4*>(gbuf + row * ldg + c);
+      if (!fixed) consts(c);
+    }
     const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
     unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -311,9 +335,7 @@ __global__ __launch_bounds__(256) void bn1_fix_kernel(const bf16_t* __restrict__
       float o[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int ch = c + 2 * u + e;
-        const float k1 = kacc[2 * ch], k2 = kacc[2 * ch + 1];
-        const float ka = k2 * rstd[ch], kb = fmaf(-ka, mean[ch], k1);
+        const float ka = kav[2 * u + e], kb = kbv[2 * u + e];
         const float xf = e ? __uint_as_float(xw[u] & 0xFFFF0000u) : __uint_as_float(xw[u] << 16);
         const float gf = e ? __uint_as_float(gw[u] & 0xFFFF0000u) : __uint_as_float(gw[u] << 16);
         o[e] = gf - fmaf(ka, xf, kb);
@@ -341,7 +363,7 @@ __global__ __launch_bounds__(256) void bn1_fix_kernel(const bf16_t* __restrict__
 // BatchNorm reduce pass disappear; the ReLU mask and the BatchNorm sums come out of the accumulators.
 constexpr int C3I = 128, C3O = 32, T3B = 128;
 
-__global__ __launch_bounds__(256, 2) void conv3x3_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, long long S,
+__global__ __launch_bounds__(256, 1) void conv3x3_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, long long S,
                                                              int H, int W, const bf16_t* __restrict__ W2,
                                                              const bf16_t* __restrict__ z,
                                                              const float* __restrict__ gamma,
@@ -358,6 +380,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_kernel(const bf16_t* __res
   const int zero_off = T3B * 256 + nrow * 64;                       // 64 B of zeros
   const int Si = (int)S;
 
+  // the first tile's z chunks go out before the weight gather below (144 two-byte loads per lane: otherwise the tile's loads
+  // wait behind their round trip; on the 14 x 14 / 7 x 7 maps, where this kernel runs, a workgroup multiplies ONE tile)
+  uint4 zr[8];
+  auto load_z_tile = [&](int tile) {
+    const int p0 = tile * T3B;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = p0 + (tid >> 4) + 16 * i;
+      zr[i] = p < Si ? *reinterpret_cast<const uint4*>(z + (long long)p * C3I + (tid & 15) * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if ((int)blockIdx.x < ntile) load_z_tile(blockIdx.x);
   // this wave's weight fragments: B[k = co][n = ci], ci = 32*wave + l31, k-step i -> tap = i >> 1, co = 16*(i&1) + 8h + j
   bf16x8 breg[18];
 #pragma unroll
@@ -383,13 +417,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_kernel(const bf16_t* __res
 
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int p0 = tile * T3B;
-    // ---- global loads of the tile: z chunks (8 per thread), dy slab chunks (<= 5 per thread at W = 56)
-    uint4 zr[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = p0 + (tid >> 4) + 16 * i;
-      zr[i] = p < Si ? *reinterpret_cast<const uint4*>(z + (long long)p * C3I + (tid & 15) * 8) : make_uint4(0u, 0u, 0u, 0u);
-    }
+    // ---- global loads of the tile: z chunks (8 per thread; the first tile's are in flight), dy slab chunks
+    if (tile != (int)blockIdx.x) load_z_tile(tile);
     __syncthreads();   // previous tile done with LDS
     for (int q = tid; q < nrow * 4; q += 256) {
       const int j = q >> 2, ch = q & 3;
@@ -759,6 +788,15 @@ __global__ __launch_bounds__(256) void bn2_dz_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ coef, bf16_t* __restrict__ dz) {
   const int cc = threadIdx.x & 15;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long q0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  // the first chunk's data loads go out before the 40 coefficient loads (otherwise two memory round trips in series at the
+  // head of a 5 us kernel)
+  uint4 gv = make_uint4(0u, 0u, 0u, 0u), zv = gv;
+  if (q0 < n_chunks) {
+    gv = *reinterpret_cast<const uint4*>(g2 + q0 * 8);
+    zv = *reinterpret_cast<const uint4*>(z + q0 * 8);
+  }
   float mu[8], rs[8], sc[8], c1[8], c2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -769,9 +807,11 @@ __global__ __launch_bounds__(256) void bn2_dz_kernel(const bf16_t* __restrict__ 
     c1[i] = coef[2 * c];
     c2[i] = coef[2 * c + 1];
   }
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n_chunks; q += stride) {
-    const uint4 gv = *reinterpret_cast<const uint4*>(g2 + q * 8), zv = *reinterpret_cast<const uint4*>(z + q * 8);
+  for (long long q = q0; q < n_chunks; q += stride) {
+    if (q != q0) {
+      gv = *reinterpret_cast<const uint4*>(g2 + q * 8);
+      zv = *reinterpret_cast<const uint4*>(z + q * 8);
+    }
     const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, zw[4] = {zv.x, zv.y, zv.z, zv.w};
     unsigned o[4];
 #pragma unroll
