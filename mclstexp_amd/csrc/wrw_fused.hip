@@ -17,7 +17,8 @@
 //     dbeta[c] = sum_m W1[m][c]*R[m][c]                 dgamma[c] = sum_m W1[m][c]*Q[m][c]
 //
 // mask*x is the raw bf16 input with masked elements zeroed (no re-rounding) and mask is exactly 0/1, so the operands
-// are exact; the matrix cores do twice the (free: the kernel is HBM-bound, AI ~ 256 flop/B) work and the separate
+// are exact; the matrix cores do twice the work (at one workgroup per CU the kernel is issue-bound: 32 MFMAs per
+// 64-pixel tile = 1024 cycles, measured ~1800 with the pipeline below; the HBM floor is half of that) and the separate
 // reduce launch + its finalize launch disappear.
 //
 // Kernel A (wrw_partial_kernel): "TN" GEMM with the huge dimension (S pixels, up to 401k) as K.  A workgroup owns one
@@ -43,7 +44,10 @@ constexpr int BT = 128;       // channel-tile width of both operands
 constexpr int ROWB = BT * 2;  // bytes per LDS tile row (raw rows as they lie in HBM: 128 bf16)
 constexpr int TILE_B = BK * ROWB;          // 16 KB per operand tile
 constexpr int STAGE_B = 2 * TILE_B;        // dz tile + x tile
-constexpr int NSTAGE = 2;
+// Tiles in LDS per workgroup (128 KB): one being multiplied, the next one landed (the software pipeline reads its first
+// fragments early), one in flight, one being refilled.  Three stages stall on vmcnt(0) at every tile (r03: 183k vs 115k
+// cycles for the 65 tiles of a 56 x 56 slab).
+constexpr int NSTAGE = 4;
 
 // Slab stride of the partial workspace in floats: (M + 2) x N (two extra rows: the BatchNorm-backward sums) plus 256
 // bytes, so that the stride is never a power of two (same-offset reads of all slabs would share HBM channels).
@@ -51,16 +55,24 @@ __host__ __device__ inline long long slab_stride(long long MN, int N) { return M
 
 #define MCL_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 
-// One LDS-DMA instruction: every lane fetches 16 bytes from its own global address; the wave's 1 KiB lands lane-linear
-// at the (wave-uniform) LDS address in M0 -- no VGPR round trip, so a whole tile can be in flight while the previous
-// one is being multiplied.  Inline asm on purpose: hidden from the compiler's vmcnt bookkeeping, the DMA is covered by
-// the explicit vmcnt(0) + barrier that opens every tile (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16(const void* src, unsigned dst) {
+// One LDS-DMA instruction (buffer form): every lane fetches 16 bytes at its own 32-bit byte offset from a per-workgroup
+// descriptor (base = the slab's first row, num_records = the slab's bytes); the wave's 1 KiB lands lane-linear at the
+// (wave-uniform) LDS address in M0 -- no VGPR round trip, no 64-bit address arithmetic per piece.  A 16-byte chunk beyond
+// the slab's end is out of range: it lands in LDS as ZEROS and touches no memory (checked on MI355X), so ragged last
+// tiles and the pipeline's run-out past the last tile need no branch.  Inline asm on purpose: hidden from the compiler's
+// vmcnt bookkeeping, the DMA is covered by the explicit vmcnt(N) + barrier that opens every tile
+// (cdna_hip_programming.md 5.7).
+typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void blds16(u32x4_s rsrc, unsigned voff, unsigned dst) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
-               : "v"(src), "s"(dst)
+               : "v"(voff), "s"(rsrc), "s"(dst)
                : "memory");
+}
+__device__ __forceinline__ u32x4_s raw_rsrc(const void* base, unsigned long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return u32x4_s{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, (unsigned)(bytes < 0xFFFFFFFFull ? bytes : 0xFFFFFFFFull), 0x00020000u};
 }
 
 // Raw tiles keep 256-byte rows (what the DMA writes), so the transposing reads are de-conflicted by an XOR swizzle
@@ -69,12 +81,17 @@ __device__ __forceinline__ void glds16(const void* src, unsigned dst) {
 // The swizzle is applied on the SOURCE side of the DMA (lane l of a 4-row piece fetches logical chunk
 // (l & 15) ^ ((l >> 4) << 2) and lands on physical chunk l & 15).
 // Fragment: 8 consecutive-k bf16 of channel (cbase + (lane & 31)) starting at tile row kbase (kbase % 4 == 0).
-__device__ __forceinline__ bf16x8 frag_sw(const unsigned char* tile, int kbase, int cbase, int lane) {
+// frag_off: the lane's byte offset inside a tile for tile row 0; frag_rd adds the (compile-time) row offset, so a tile's
+// reads are one address register per operand block + immediates.
+__device__ __forceinline__ unsigned frag_off(int kg, int cbase, int lane) {
   const int i = lane & 15, q = i >> 2;
   const int lchunk = (cbase + 16 * ((lane >> 4) & 1)) / 8 + ((i & 3) >> 1);
-  const unsigned char* p = tile + (kbase + q) * ROWB + ((lchunk ^ (q << 2)) << 4) + (i & 1) * 8;
-  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)p);
-  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(p + 4 * ROWB));
+  return (unsigned)((kg + q) * ROWB + ((lchunk ^ (q << 2)) << 4) + (i & 1) * 8);
+}
+__device__ __forceinline__ bf16x8 frag_rd(unsigned addr, int kbase) {
+  typedef v4s __attribute__((address_space(3))) * lp_t;
+  const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(size_t)(addr + kbase * ROWB));
+  const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(size_t)(addr + (kbase + 4) * ROWB));
   bf16x8 r;
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -84,6 +101,7 @@ __device__ __forceinline__ bf16x8 frag_sw(const unsigned char* tile, int kbase, 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
 
 // Workgroup = 4 waves; wave w owns output columns [32w, 32w + 32) of the 128-column tile and ALL 128 rows (four
 // 32 x 32 blocks, for Q and for R: 128 accumulator registers).  Its x fragment holds ONE channel per lane, so the
@@ -92,7 +110,7 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // MODE 0: dW = dz^T a (plain).  MODE 1: Gram matrices Qx, R -> dW1 + BatchNorm-backward sums (see the header).
 // MODE 2: dW = dz^T relu(bn(x)) with the prologue applied in registers (one GEMM; for the side stream).
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void wrw_partial_kernel(
+__global__ __launch_bounds__(256, 1) void wrw_partial_kernel(
     const bf16_t* __restrict__ dz, long long ldz, const bf16_t* __restrict__ x, long long ldx,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ rstd, const bf16_t* __restrict__ W1 /* [M][N] */, float* __restrict__ wpart /* [ks][M][N] */,
@@ -125,17 +143,27 @@ __global__ __launch_bounds__(256, 2) void wrw_partial_kernel(
   const int lchunk = (lane & 15) ^ (prow << 2);                 // logical 16-byte chunk this lane fetches
   const int ca = lchunk * 8 < M ? lchunk * 8 : 0;               // dz column (elements); chunks beyond M: any valid one
   const int cx = n0 + lchunk * 8 < N ? n0 + lchunk * 8 : n0;    // x column; chunks beyond N: any valid one (unused)
-  auto dma_tile = [&](int t, int stage) {
-    const long long s0 = s_begin + (long long)t * BK;
-    const unsigned dst = lds_base + stage * STAGE_B;
+  // Piece u (u = 0..3) of tile t: tile rows 4p .. 4p+3, p = wave + 4u, of both operands.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const long long nrow = s_end - s_begin;
+  const u32x4_s rsrc_a = raw_rsrc(dz + s_begin * ldz, nrow > 0 ? (unsigned long long)nrow * ldz * 2 : 0ull);
+  const u32x4_s rsrc_x = raw_rsrc(x + s_begin * ldx, nrow > 0 ? (unsigned long long)((nrow - 1) * ldx + N) * 2 : 0ull);
+  unsigned offa[4], offx[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = wave + 4 * u;
-      long long row = s0 + 4 * p + prow;
-      row = row < S ? row : S - 1;                              // ragged last tile: clamped rows are masked out of dz
-      glds16(dz + row * ldz + ca, __builtin_amdgcn_readfirstlane(dst + p * 1024));
-      glds16(x + row * ldx + cx, __builtin_amdgcn_readfirstlane(dst + TILE_B + p * 1024));
-    }
+  for (int u = 0; u < 4; ++u) {
+    const long long r = 4 * (wave + 4 * u) + prow;
+    offa[u] = (unsigned)((r * ldz + ca) * 2);
+    offx[u] = (unsigned)((r * ldx + cx) * 2);
+  }
+  const unsigned tstep_a = (unsigned)(BK * ldz * 2), tstep_x = (unsigned)(BK * ldx * 2);
+  auto dma_piece = [&](int t, int stage, int u) {
+    const unsigned dst = lds_base + stage * STAGE_B + (wave_u + 4 * u) * 1024;
+    blds16(rsrc_a, offa[u] + (unsigned)t * tstep_a, dst);
+    blds16(rsrc_x, offx[u] + (unsigned)t * tstep_x, dst + TILE_B);
+  };
+  auto dma_tile = [&](int t, int stage) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dma_piece(t, stage, u);
   };
 
   f32x16 accq[4], accr[4];
@@ -148,65 +176,110 @@ __global__ __launch_bounds__(256, 2) void wrw_partial_kernel(
     }
 
   const int kg = 8 * hh;
-  // Both stages are free at the start: tiles 0 and 1 go out together.  From then on tile t+1 is fetched while tile t
-  // is multiplied (its stage was released by the barrier that opens iteration t).
-  if (nt > 0) dma_tile(0, 0);
-  if (nt > 1) dma_tile(1, 1);
-  for (int t = 0; t < nt; ++t) {
-    if (t == 0 && nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 only (8 pieces of tile 1 pending)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's pieces of tile t have landed
-    __syncthreads();                                     // ... everybody's; and the other stage is free again
-    if (t >= 1 && t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);   // in flight under this tile's MFMAs
-    const unsigned char* tA = lds + (t & 1) * STAGE_B;
-    const unsigned char* tX = tA + TILE_B;
-    const int nvalid = (int)min((long long)BK, s_end - (s_begin + (long long)t * BK));
+  // One 64-pixel tile into the accumulators; the whole loop body is one basic block (no ragged-tile or end-of-slab
+  // branch: out-of-range DMA chunks are zeros), so the mask arithmetic is scheduled under the MFMAs.
+  // B operands of one 16-pixel step from the raw x fragment.  MODE 1: mask*x and mask (bf16 1.0 / 0).  The mask bit is
+  // the SIGN of u = fma(x, -sc, nsh), nsh = -sh (or +0 when sh is a zero): u < 0 or u = -0 exactly when
+  // fma(x, sc, sh) > 0 -- fma is odd in (sc, sh), an exact cancellation gives +0 in both, and with nsh never -0 the sum
+  // of two zeros is +0 -- so the 16-bit masks are an arithmetic shift of the packed sign bits instead of two compares and
+  // two selects per element.
+  const float nsc = -sc, nsh = sh == 0.0f ? 0.0f : -sh;
+  auto prep = [&](const bf16x8 fx, bf16x8& o0, bf16x8& o1) {
+    const u32x4 w = __builtin_bit_cast(u32x4, fx);
+    if (MODE == 0) {
+      o0 = fx;
+    } else if (MODE == 2) {
+      u32x4 av;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 16) {
-      bf16x8 fa[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = frag_sw(tA, kk + kg, i * 32, lane);
-      if (nvalid < BK) {                                 // ragged tile (only the last slab): zero dz beyond the end
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (kk + kg + e >= nvalid) fa[i][e] = 0;
+      for (int d = 0; d < 4; ++d) {
+        const float lo = fmaxf(fmaf(__uint_as_float(w[d] << 16), sc, sh), 0.0f);
+        const float hi = fmaxf(fmaf(__uint_as_float(w[d] & 0xFFFF0000u), sc, sh), 0.0f);
+        const f32x2 pv = {lo, hi};
+        av[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));      // RNE, as the forward
       }
-      const bf16x8 fx = frag_sw(tX, kk + kg, wave * 32, lane);
-      if (MODE == 0) {
+      o0 = __builtin_bit_cast(bf16x8, av);
+    } else {
+      u32x4 xm, mk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fx, accq[i], 0, 0, 0);
-      } else if (MODE == 2) {
-        const u32x4 w = __builtin_bit_cast(u32x4, fx);
-        u32x4 av;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const float lo = fmaxf(fmaf(__uint_as_float(w[d] << 16), sc, sh), 0.0f);
-          const float hi = fmaxf(fmaf(__uint_as_float(w[d] & 0xFFFF0000u), sc, sh), 0.0f);
-          const f32x2 pv = {lo, hi};
-          av[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));      // RNE, as the forward
-        }
-        const bf16x8 fav = __builtin_bit_cast(bf16x8, av);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fav, accq[i], 0, 0, 0);
-      } else {
-        const u32x4 w = __builtin_bit_cast(u32x4, fx);
-        u32x4 xm, mk;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const float lo = __uint_as_float(w[d] << 16), hi = __uint_as_float(w[d] & 0xFFFF0000u);
-          const unsigned sel = (fmaf(lo, sc, sh) > 0.0f ? 0x0000FFFFu : 0u) | (fmaf(hi, sc, sh) > 0.0f ? 0xFFFF0000u : 0u);
-          xm[d] = w[d] & sel;
-          mk[d] = 0x3F803F80u & sel;
-        }
-        const bf16x8 fxm = __builtin_bit_cast(bf16x8, xm), fmk = __builtin_bit_cast(bf16x8, mk);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fxm, accq[i], 0, 0, 0);
-          accr[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fmk, accr[i], 0, 0, 0);
-        }
+      for (int d = 0; d < 4; ++d) {
+        const float ul = fmaf(__uint_as_float(w[d] << 16), nsc, nsh);
+        const float uh = fmaf(__uint_as_float(w[d] & 0xFFFF0000u), nsc, nsh);
+        const unsigned sg = __builtin_amdgcn_perm(__float_as_uint(uh), __float_as_uint(ul), 0x07060302u);   // [uh.hi16 | ul.hi16]
+        const unsigned sel = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2_t, sg) >> 15);         // 0xFFFF where the sign is set
+        xm[d] = w[d] & sel;
+        mk[d] = 0x3F803F80u & sel;
       }
+      o0 = __builtin_bit_cast(bf16x8, xm);
+      o1 = __builtin_bit_cast(bf16x8, mk);
     }
+  };
+  unsigned fo[5];                                        // lane offsets of the four dz row blocks and of the x block
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fo[i] = frag_off(kg, i * 32, lane);
+  fo[4] = TILE_B + frag_off(kg, wave * 32, lane);
+
+  // ---- main loop: one software pipeline over the 16-pixel steps g = 4 t + kq of the whole slab ----------------------
+  // A wave alone on its SIMD hides about five single-issue instructions per MFMA, and only if they sit BETWEEN the MFMAs
+  // (MI355X_MICROARCH.md); at most 15 LDS reads are in flight per wave.  So under the 8 MFMAs of step g the wave issues
+  // the 8 dz-fragment reads of step g+1, the 2 x-fragment reads of step g+2 and the mask arithmetic of step g+1 (hipcc
+  // clusters instruction classes: the interleave is spelled out with scheduling groups), plus one piece pair of tile
+  // t + NSTAGE - 1.  The pipeline runs across tile boundaries: the barrier that opens iteration t certifies tile t+1
+  // (not t) as landed, so that the last steps of tile t can already read the first fragments of tile t+1.
+  //   stages: tile t being multiplied, t+1 landed, t+2 .. t+NSTAGE-2 in flight, the stage of tile t-1 being refilled.
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t) dma_tile(t, t);
+  static_assert(NSTAGE == 4, "vmcnt immediates: 8 DMA instructions per tile, completion in issue order");
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // tile 0 (tiles 1 and 2 behind it)
+  __syncthreads();
+  unsigned adc[5], adn[5];                               // operand block addresses in the current / next tile's stage
+#pragma unroll
+  for (int j = 0; j < 5; ++j) adc[j] = lds_base + fo[j];
+  bf16x8 fa_c[4], fx_n, b0, b1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa_c[i] = frag_rd(adc[i], 0);
+  prep(frag_rd(adc[4], 0), b0, b1);
+  fx_n = frag_rd(adc[4], 16);
+  int stage = 0, fill = NSTAGE - 1;                      // stage of tile t; stage tile t + NSTAGE - 1 is fetched into
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile t+1 (tile t+2 behind it)
+    __syncthreads();                                     // ... everybody's pieces; and the stage of tile t-1 is free
+    stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) adn[j] = lds_base + stage * STAGE_B + fo[j];
+#pragma unroll
+    for (int kq = 0; kq < BK / 16; ++kq) {
+      bf16x8 fa_n[4], n0v, n1v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa_n[i] = kq + 1 < BK / 16 ? frag_rd(adc[i], (kq + 1) * 16) : frag_rd(adn[i], 0);
+      const bf16x8 fx_nn = kq + 2 < BK / 16 ? frag_rd(adc[4], (kq + 2) * 16) : frag_rd(adn[4], (kq + 2 - BK / 16) * 16);
+      prep(fx_n, n0v, n1v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        accq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_c[i], b0, accq[i], 0, 0, 0);
+        if (FUSED) accr[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_c[i], b1, accr[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                      // 10 LDS reads over the step: 2 2 1 1 1 1 1 1 (or 3 3 2 2)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, FUSED ? 2 : 3, 0);              // LDS reads of the next steps
+        if (MODE != 0) __builtin_amdgcn_sched_group_barrier(0x002, FUSED ? 4 : 8, 0);   // the next step's mask arithmetic
+      }
+#pragma unroll
+      for (int j = 2; j < (FUSED ? 8 : 4); ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, FUSED ? 1 : 2, 0);
+        if (MODE != 0) __builtin_amdgcn_sched_group_barrier(0x002, FUSED ? 4 : 8, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dma_piece(t + NSTAGE - 1, fill, kq);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa_c[i] = fa_n[i];
+      b0 = n0v; b1 = n1v; fx_n = fx_nn;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) adc[j] = adn[j];
+    fill = fill + 1 == NSTAGE ? 0 : fill + 1;
   }
 
   // ---- epilogue: acc[i][r] is element m = i*32 + (r&3) + 8*(r>>2) + 4*hh, n = n_lane
@@ -218,23 +291,39 @@ __global__ __launch_bounds__(256, 2) void wrw_partial_kernel(
     g = gamma[n_lane]; b = beta[n_lane]; mu = mean[n_lane]; rs = rstd[n_lane];
   }
   if (nok) {
+    // the 64 weights of this lane's column go out as one batch of loads (clamped row: no branch between them); a load
+    // per element inside the loop below is a chain of 64 dependent round trips (~0.5 us each) at one workgroup per CU
+    constexpr int IB = 4;                                // 32-row blocks per batch of loads
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i0 = 0; i0 < 4; i0 += IB) {
+      unsigned short wv[FUSED ? IB * 16 : 1];
+      if (FUSED) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m >= M) continue;
-        if (FUSED) {
-          const float R = accr[i][r];
-          const float Q = rs * fmaf(-mu, R, accq[i][r]);
-          const float w = __uint_as_float(((unsigned)W1[(long long)m * N + n_lane]) << 16);
-          t1 = fmaf(w, R, t1);
-          t2 = fmaf(w, Q, t2);
-          wp[(long long)m * N + n_lane] = fmaf(g, Q, b * R);
-        } else {
-          wp[(long long)m * N + n_lane] = accq[i][r];
-        }
+        for (int i = i0; i < i0 + IB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            wv[(i - i0) * 16 + r] = W1[(long long)(m < M ? m : M - 1) * N + n_lane];
+          }
       }
+#pragma unroll
+      for (int i = i0; i < i0 + IB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (m >= M) continue;
+          if (FUSED) {
+            const float R = accr[i][r];
+            const float Q = rs * fmaf(-mu, R, accq[i][r]);
+            const float w = __uint_as_float(((unsigned)wv[(i - i0) * 16 + r]) << 16);
+            t1 = fmaf(w, R, t1);
+            t2 = fmaf(w, Q, t2);
+            wp[(long long)m * N + n_lane] = fmaf(g, Q, b * R);
+          } else {
+            wp[(long long)m * N + n_lane] = accq[i][r];
+          }
+        }
+    }
   }
   if (FUSED) {
     t1 += __shfl_xor(t1, 32, 64);          // the two lane halves hold disjoint rows m of the same column
@@ -333,12 +422,11 @@ struct Split {
 inline Split plan(long long S, int N) {
   Split p;
   p.tn = (N + BT - 1) / BT;
-  // A workgroup's time is a chain of (tiles x DMA latency ~3 us) + prologue + epilogue, so the
-  // small maps (blocks 3-4: the whole operand set is 8-56 MB) want FEW tiles per workgroup even though every extra
-  // workgroup costs a 64 KB partial that the merge re-reads: at least 4 tiles (2 on the 7 x 7 maps) per workgroup.
-  // (192 workgroups, not two per CU: alone the kernel is a little faster at 512, but in the step it shares the chip with
-  //  the other lane's kernels and every workgroup costs a partial the merge re-reads: 13.83 ms/step at 512, 13.57-13.66
-  //  at 192-256 together with the smaller 3x3 weight-gradient grids; MCL_WRW_TARGET for A/B)
+  // 192 workgroups, one per CU on three quarters of the chip, not two per CU: alone the kernel is faster at 512 (two
+  // waves per SIMD cover each other's issue gaps), but in the step it shares the chip with the other lane's kernels and
+  // every workgroup costs a 64 KB partial that the merge re-reads (r03 same-box: 12.00 ms/step at 192, 12.18 at 256).
+  // The small maps (blocks 3-4: the whole operand set is 8-56 MB) keep at least 4 tiles (2 on the 7 x 7 maps) per
+  // workgroup.  MCL_WRW_TARGET for A/B.
   static const char* e_t = getenv("MCL_WRW_TARGET");
   const long long target = e_t ? atoll(e_t) : 192;
   long long ks = (target + p.tn - 1) / p.tn;

@@ -561,6 +561,58 @@ def test_dense_bn1_wrw_dx_fused(S, C, ld):
     assert float((xw[:, :C] - x).abs().max()) == 0.0
 
 
+def test_dense_bn1_wrw_mask_zero_cases():
+    """The Gram kernel takes the ReLU mask [fma(x, sc, sh) > 0] from a sign bit (csrc/wrw_fused.hip, prep): the cases
+    where the fused multiply-add is an exact zero -- a zero affine (gamma = beta = 0), a dead all-zero channel, exact
+    cancellation, negative scale, signed zeros in x -- must give mask 0 as the compare does."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    L = _lib.lib()
+    S, C, ld = 320, 64, 64
+    g = torch.Generator().manual_seed(7)
+    x = ((torch.rand(S, ld, generator=g) - 0.4) * 2).to(torch.bfloat16)
+    gam = torch.rand(C, generator=g) + 0.5
+    bet = torch.rand(C, generator=g) - 0.5
+    mu = torch.rand(C, generator=g) - 0.5
+    rs = torch.rand(C, generator=g) + 0.5
+    vals = torch.tensor([0.5, 1.0, 0.25, 0.0, -0.0, 2.0 ** -120, -0.5, 0.75], dtype=torch.float32)
+    pat = vals[torch.arange(S) % len(vals)].to(torch.bfloat16)
+    gam[0], bet[0] = 0.0, 0.0                                            # zero affine: t = +-0 everywhere
+    x[:, 1] = 0; gam[1], bet[1], mu[1], rs[1] = 1.0, 0.0, 0.0, 316.22777   # dead channel at the default initialisation
+    x[:, 2] = pat; gam[2], bet[2], mu[2], rs[2] = 1.0, -0.5, 0.0, 1.0      # x = 0.5 cancels exactly
+    x[:, 3] = pat; gam[3], bet[3], mu[3], rs[3] = -1.0, 0.5, 0.0, 1.0      # negative scale
+    x[:, 4] = pat; gam[4], bet[4], mu[4], rs[4] = 1.0, 0.0, 0.0, 1.0       # sh = 0: signed zeros of x
+    x[:, 5] = pat; gam[5], bet[5], mu[5], rs[5] = 1.0, -0.0, 0.0, 1.0      # sh = -0
+    gam[6], bet[6] = 0.0, 1.0                                            # constant positive: mask 1
+    gam[7], bet[7] = 0.0, -1.0                                           # constant negative: mask 0
+    x[:, 8] = pat; gam[8], bet[8], mu[8], rs[8] = -1.0, 0.0, 0.0, 1.0      # sh = 0, negative scale
+    dz = ((torch.rand(S, 128, generator=g) - 0.5) * 0.2).to(torch.bfloat16)
+    W1 = ((torch.rand(128, C, generator=g) - 0.5) / 8).to(torch.bfloat16)
+    sc32 = gam * rs                                                      # the kernel's fp32 constants
+    sh32 = (bet.double() - mu.double() * sc32.double()).float()          # = fmaf(-mean, sc, beta)
+    t = x.double() * sc32.double() + sh32.double()                       # exact; its sign is the sign of the fp32 fma
+    mask = (t > 0).double()
+    assert mask[:, 0].sum() == 0 and mask[:, 1].sum() == 0 and mask[:, 7].sum() == 0 and mask[:, 6].sum() == S
+    assert 0 < mask[:, 2].sum() < S and 0 < mask[:, 4].sum() < S
+    xhat = (x.double() - mu.double()) * rs.double()
+    gcol = dz.double() @ W1.double()                                     # dL/da
+    ref_db = (gcol * mask).sum(0)
+    ref_dg = (gcol * mask * xhat).sum(0)
+    ref_dW = dz.double().t() @ (mask * (gam.double() * xhat + bet.double()))
+    xd, dzd, Wd = x.to(DEV), dz.to(DEV), W1.to(DEV)
+    gd, bd, md, rd = gam.to(DEV), bet.to(DEV), mu.to(DEV), rs.to(DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dW, coef = torch.zeros(128, C, device=DEV), torch.empty(2 * C, device=DEV)
+    ws = torch.empty(L.mcl_wrw_workspace_floats(S, 128, C), device=DEV)
+    _lib.check(L.mcl_dense_bn1_wrw(dzd.data_ptr(), Wd.data_ptr(), C, xd.data_ptr(), ld, S, gd.data_ptr(), bd.data_ptr(),
+                                   md.data_ptr(), rd.data_ptr(), ws.data_ptr(), dW.data_ptr(), 0, dg.data_ptr(),
+                                   db.data_ptr(), 0, coef.data_ptr(), dn._stream()))
+    for c in (0, 1, 7):
+        assert float(db[c]) == 0.0 and float(dg[c]) == 0.0 and float(dW[:, c].abs().max()) == 0.0, c
+    assert_close_scaled(db.cpu(), ref_db, 2e-4, what="dbeta")
+    assert_close_scaled(dg.cpu(), ref_dg, 2e-4, what="dgamma")
+    assert_close_scaled(dW.cpu(), ref_dW, 2e-4, what="dW1")
+
+
 @pytest.mark.parametrize("S,M,N,lda", [(4096, 128, 256, 256), (1000, 128, 96, 96), (777, 128, 160, 416), (25088, 256, 512, 512),
                                        (6272, 512, 1024, 1024), (100352, 128, 256, 256), (50000, 128, 64, 64),
                                        (300, 256, 512, 512), (31, 128, 992, 1024)])
