@@ -411,10 +411,18 @@ __global__ __launch_bounds__(256) void sums_finalize_kernel(const float2* __rest
   const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float2* p = partial + c;
   double sum = 0.0, q = 0.0;
-  for (int t = threadIdx.x; t < nunits; t += 256) {
-    const float2 v = p[(long long)t * CO];
-    sum += (double)v.x;
-    q += (double)v.y;
+  // batches of eight independent loads (clamped index, surplus zeroed after the load), added in ascending order
+  constexpr int U = 8;
+  for (int t0 = threadIdx.x; t0 < nunits; t0 += 256 * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = p[(long long)min(t0 + 256 * u, nunits - 1) * CO];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t0 + 256 * u >= nunits) v[u] = make_float2(0.0f, 0.0f);
+      sum += (double)v[u].x;
+      q += (double)v[u].y;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -253,10 +253,19 @@ __global__ __launch_bounds__(256) void bn1_bwd_finalize_kernel(const float2* __r
   const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float2* p = partial + (long long)c * nrt;
   double a = 0.0, b = 0.0;
-  for (int t = threadIdx.x; t < nrt; t += 256) {
-    const float2 v = p[t];
-    a += (double)v.x;
-    b += (double)v.y;
+  // batches of eight independent loads (clamped index, surplus zeroed after the load), added in ascending order: one
+  // load per loop trip would be one memory round trip per trip
+  constexpr int U = 8;
+  for (int t0 = threadIdx.x; t0 < nrt; t0 += 256 * U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = p[min(t0 + 256 * u, nrt - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t0 + 256 * u >= nrt) v[u] = make_float2(0.0f, 0.0f);
+      a += (double)v[u].x;
+      b += (double)v[u].y;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
