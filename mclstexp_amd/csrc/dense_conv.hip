@@ -1153,10 +1153,17 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
 
 // Deterministic: per-workgroup partials in the workspace (mcl_conv0_wrw_workspace_floats floats) + a fixed-order merge
 // launch; accumulate_w != 0 adds into dW.
+// Workgroups of the stem weight gradient: each owns a 37.6 KB fp32 partial.  Three per CU are resident (42 KB of LDS each):
+// the kernel's phases (transposing stores of the dy tile, the input slab, the MFMA loop) are separated by barriers, and a
+// single workgroup per CU -- the former grid of 256 -- overlaps none of them.  MCL_C0W_GRID for A/B.
+inline int conv0_wrw_grid(int ntile) {
+  static const char* e = getenv("MCL_C0W_GRID");
+  const int cap = e ? atoi(e) : 768;
+  return ntile < cap ? ntile : cap;
+}
 extern "C" int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W) {
   if (N <= 0 || H <= 0 || W <= 0) return -1;
-  const int ntile = N * (H / 4);
-  return (int64_t)(ntile < 256 ? ntile : 256) * (C0_OUT * C0_K * 21);
+  return (int64_t)conv0_wrw_grid(N * (H / 4)) * (C0_OUT * C0_K * 21);
 }
 
 extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, const void* dy, float* workspace, float* dW,
@@ -1177,7 +1184,7 @@ extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, con
     attr_set = true;
   }
   hipStream_t st = mcl_stream(stream);
-  const int grid = ntile < 256 ? ntile : 256;
+  const int grid = conv0_wrw_grid(ntile);
   hipLaunchKernelGGL(conv0_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H, W,
                      (const bf16_t*)dy, dW, ntile, workspace);
   mcl_launch_wrw_merge(workspace, grid, (long long)C0_OUT * C0_K * 21, dW, accumulate_w, st);
