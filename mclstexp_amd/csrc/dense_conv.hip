@@ -71,8 +71,11 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   constexpr int NA = (BM * 8) / NT;          // A chunks per thread and stage
   constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;
   constexpr int NB = (BN * 8) / NT;  // W chunks per thread and stage
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE_B + 2 * 1024 * 4];
-  float* tab = reinterpret_cast<float*>(lds + 2 * STAGE_B);  // scale[K] then shift[K], K <= 1024
+  // DEPTH 0: ONE LDS stage (40 KB with the table: three workgroups per CU instead of two) and one register set; the
+  // stage is overwritten between two barriers
+  constexpr int NBUF = DEPTH == 0 ? 1 : 2, NSET = DEPTH == 0 ? 1 : DEPTH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * STAGE_B + 2 * 1024 * 4];
+  float* tab = reinterpret_cast<float*>(lds + NBUF * STAGE_B);  // scale[K] then shift[K], K <= 1024
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   // drain ALL outstanding loads -- s_waitcnt vmcnt(0) -- before it touches a register set again, which serialises the
   // stages in flight.)  Chunks past K inside a row read the neighbouring channels / the next weight row: store_stage zeroes
   // them.
-  u32x4 rav[DEPTH][NA], rbv[DEPTH][NB];
+  u32x4 rav[NSET][NA], rbv[NSET][NB];
   const unsigned xbytes = (unsigned)((((long long)S - 1) * ldx + K) * 2), wbytes = (unsigned)((long long)BN * K * 2);
   unsigned xoff[NA], woff[NB];
 #pragma unroll
@@ -179,7 +182,21 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   };
-  if (DEPTH == 1) {
+  if (DEPTH == 0) {
+    load_stage(rav[0], rbv[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
+    build_tab();
+    store_stage(rav[0], rbv[0], 0, 0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+      load_stage(rav[0], rbv[0], (st + 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(0);
+      __syncthreads();                                   // everybody has read the stage
+      if (st + 1 < nst) store_stage(rav[0], rbv[0], 0, (st + 1) * BK);
+      __syncthreads();
+    }
+  } else if (DEPTH == 1) {
     load_stage(rav[0], rbv[0], 0);
     __builtin_amdgcn_sched_barrier(0);
     build_tab();
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(128 * WM) void conv1x1_fwd_kernel(const bf16_t* __r
   } else {
     // register set d holds stage st0 + d; once a stage is in LDS its set takes stage + DEPTH (loads past K are masked off
     // lane by lane: no branch, no memory access).  The loads are pinned at the top of the stage.
-    static_assert(DEPTH == 1 || (DEPTH % 2) == 0, "LDS parity must follow the register set");
+    static_assert(DEPTH <= 1 || (DEPTH % 2) == 0, "LDS parity must follow the register set");
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) load_stage(rav[d], rbv[d], d * BK);
     __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +355,7 @@ __global__ __launch_bounds__(256) void tile_stats_finalize_kernel(const float2* 
   rstd[c] = (float)(1.0 / sqrt(v + (double)eps));
 }
 
-// 128-row tiles (WM = 2: 72 KB of LDS, two workgroups per CU) also on the 56 x 56 maps: the 256-row tile (104 KB, ONE
+// 128-row tiles (WM = 2) also on the 56 x 56 maps: the 256-row tile (104 KB, ONE
 // workgroup per CU, nothing overlaps its load / multiply / store phases) is faster alone but 0.1 ms/step slower in the step
 // (13.07 / 13.09 vs 12.94 / 13.01 ms, interleaved A/B)
 inline int pick_wm(long long S) { return S >= 32768 ? 2 : 1; }
@@ -378,9 +395,14 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   static const char* e_dp = getenv("MCL_C1F_DEPTH");
   const int depth = e_dp ? atoi(e_dp) : 4;
   static const char* e_dl = getenv("MCL_C1F_DEPTH_LARGE");
-  const int depth_large = e_dl ? atoi(e_dl) : 2;     // 12.41-12.44 ms/step at 1, 12.34 at 2 (interleaved A/B)
-  if (wm == 2 && depth_large == 2) MCL_LAUNCH(2, 64, 2);
-  else if (wm == 2) MCL_LAUNCH(2, 64, 1);
+  // 56 x 56 / 28 x 28 maps: ONE LDS stage and one register set (40 KB, 166 registers: three workgroups per CU).  In-kernel
+  // timestamps of the two-stage form showed a workgroup loading nothing for half of its life (prologue 2.7 us, K loop 5.7
+  // at the HBM rate, statistics + store 3.4): a third resident workgroup fills more of that than the second stage hid.
+  // r03 same box: 102 -> 88 us (C = 224), 57 -> 48 (C = 64) alone; 11.77 / 11.80 -> 11.65 / 11.70 ms/step.  On the
+  // small maps the same form (64-row tiles, 4 per CU) measured 11.90 / 11.94 vs 11.88 / 11.85: they keep 4 stages ahead.
+  const int depth_large = e_dl ? atoi(e_dl) : 0;
+  if (wm == 2 && depth_large == 0) MCL_LAUNCH(2, 64, 0);
+  else if (wm == 2) MCL_LAUNCH(2, 64, 2);
   else if (half_waves && depth == 4) MCL_LAUNCH(2, 32, 4);
   else if (half_waves && depth == 2) MCL_LAUNCH(2, 32, 2);
   else if (half_waves) MCL_LAUNCH(2, 32, 1);
