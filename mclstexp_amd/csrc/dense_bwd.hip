@@ -29,7 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int TM = 128, TN = 128, TK = 128;   // pixels, input channels, bottleneck channels per tile
+constexpr int TN = 128, TK = 128;   // input channels, bottleneck channels per tile (pixels per tile: template TMv)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -910,7 +910,7 @@ extern "C" int mcl_dense_conv3x3_wrw_det(const void* dy, int64_t lddy, const voi
 namespace {
 
 constexpr int C0_OUT = 64, C0_K = 7, C0_KP = 24;        // output channels, kernel size, padded (kx, c) run
-constexpr int C0_CHUNKS = 22;                            // 7 * 3 chunks of 8 + one zero chunk -> 11 k-steps of 16
+// (a kernel row is 7 * 3 chunks of 8 + one zero chunk = 22 chunks -> 11 k-steps of 16)
 
 __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
                                                            const bf16_t* __restrict__ Wt, bf16_t* __restrict__ y,
