@@ -187,11 +187,21 @@ def kernel_roofline(step_fn, n_steps: int, model) -> list:
         except Exception:
             traffic = {}
     rows = []
+    # entry points that are the same launch unit (kernel_costs "unit": e.g. mcl_dense_conv3x3_bwd_fix = mcl_dense_conv3x3_bwd
+    # with the folded bn1_fix on the 14 x 14 / 7 x 7 layers) are merged into one row, each call priced by its own formula
+    units = {}
     for name, s in summ.items():
         spec = table[name]
-        alg = [float(spec["bytes"](a)) for a in s["args"]]
-        strict = [float(spec["strict"](a)) for a in s["args"]]
-        flops = [float(spec["flops"](a)) for a in s["args"]]
+        u = units.setdefault(spec.get("unit") or name, {"calls": 0, "total_ms": 0.0, "alg": [], "strict": [], "flops": []})
+        u["calls"] += s["calls"]
+        u["total_ms"] += s["total_ms"]
+        u["alg"] += [float(spec["bytes"](a)) for a in s["args"]]
+        u["strict"] += [float(spec["strict"](a)) for a in s["args"]]
+        u["flops"] += [float(spec["flops"](a)) for a in s["args"]]
+    for name, u in units.items():
+        spec = table[name]
+        s = {"calls": u["calls"], "total_ms": u["total_ms"], "avg_ms": u["total_ms"] / u["calls"]}
+        alg, strict, flops = u["alg"], u["strict"], u["flops"]
         tot_b, tot_s = sum(alg), s["total_ms"] * 1e-3
         ach = tot_b / tot_s / 1e9
         tfs = sum(flops) / tot_s / 1e12
@@ -203,7 +213,11 @@ def kernel_roofline(step_fn, n_steps: int, model) -> list:
             bound = "latency" if (max(strict) < MALL_BYTES and s["avg_ms"] < 0.030) else "hbm"
         rows.append({"abi": name, "kernel": spec["kernels"], "bound": bound, "achieved": round(ach, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                     "traffic": tr, "launches_per_step": s["calls"] / n_steps,
+                     "traffic": tr,
+                     "traffic_source": "profiles/kernel_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                       "command in an earlier run (FETCH doubled per the gfx950 correction), NOT measured in "
+                                       "this run",
+                     "launches_per_step": s["calls"] / n_steps,
                      "avg_launch_ms": round(s["avg_ms"], 5), "ms_per_step": round(s["total_ms"] / n_steps, 4),
                      "algorithmic_bytes": round(tot_b / s["calls"], 1),
                      "algorithmic_bytes_strict": round(sum(strict) / s["calls"], 1),
@@ -330,12 +344,24 @@ def main():
     # per-kernel roofline: eager pass with HIP events around the hot C-ABI calls (rank 0's GPU; N = 1 only, so that the
     # collectives of the other ranks are not left waiting)
     roof_rows = []
+    foreign_kernels = None
     if args.profile_steps > 0 and world == 1 and args.encoder == "densenet121" and not args.unfused_backbone:
         log(f"kernel timing pass: {args.profile_steps} eager steps, HIP events per C-ABI call")
         eager = TrainStep(model, opt, reducer, graphs=False)
         if getattr(model, "embedding_grad", "dense") == "rowsparse":
             model.sparse_grads.clear()                   # the eager pass owns the sink from here on
         roof_rows = kernel_roofline(lambda i: eager(batches[i % len(batches)]), args.profile_steps, model)
+        # which kernels did a step launch?  One eager issue of exactly the sequence the step graph records, under
+        # torch.profiler's kernel activity records (mclstexp_amd/kernel_audit.py; tests/test_own_kernels_gpu.py asserts the
+        # same): library kernels (hipBLASLt Cijk_*, at::native::*, MIOpen) would be listed here by name
+        try:
+            from mclstexp_amd import kernel_audit
+            eager.run_sequence_eager(batches[0])
+            ks = kernel_audit.step_kernels(lambda: eager.run_sequence_eager(batches[1 % len(batches)]))
+            foreign_kernels = {"kernel_records": sum(ks.values()), "distinct": len(ks),
+                               "foreign": {n[:100]: ks[n] for n in kernel_audit.foreign(ks)}}
+        except Exception as e:                       # the audit must never cost the bench line
+            foreign_kernels = {"error": repr(e)[:200]}
 
     if rank == 0:
         steps_per_s = args.steps / dt
@@ -361,6 +387,7 @@ def main():
                        "dp_semantics": "spot-encoder attention and BatchNorm statistics are per shard (per GPU); "
                                        "InfoNCE is global over the all-gathered embeddings",
                        "fallbacks": densenet_fused.fallback_counts(),
+                       "step_kernel_audit": foreign_kernels,
                        "final_loss": round(final_loss, 4),
                        "final_loss_note": f"{args.n_batches} synthetic batches are cycled: the loss reflects "
                                           "memorisation of that set, it is not a convergence claim"},

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 3
+#define MCL_ABI_VERSION 4
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -153,6 +153,11 @@ int mcl_infonce_loss(const float* S, int64_t ldS, const float* row_lse, const fl
                      float* loss_sum, mcl_stream_t stream);
 /* dS_ij = coef * (exp(S_ij-row_lse[i]) + exp(S_ij-col_lse[j]) - 2*[row0+i == col0+j]), written to
  * dS (may alias S).  coef = 1/(2*B_glob*T) folds the temperature of model.py:242.              */
+/* loss_out[0] = (sum_t (row_lse[t] - S[t][t]) + sum_t (col_lse[t] - S[t][t])) / denom over the n diagonal entries: the
+ * scalar of /root/reference/model.py:244-247 in ONE launch (mcl_infonce_loss accumulates the two sums for the strip form
+ * and leaves the final add / divide to the caller).                                                                    */
+int mcl_infonce_loss_mean(const float* S, int64_t ldS, const float* row_lse, const float* col_lse, int32_t n, float denom,
+                          float* loss_out, mcl_stream_t stream);
 int mcl_infonce_dlogits(const float* S, int64_t ldS, const float* row_lse, const float* col_lse, int32_t R,
                         int32_t C, int32_t row0, int32_t col0, float coef, float* dS, int64_t lddS,
                         mcl_stream_t stream);
@@ -354,6 +359,15 @@ int64_t mcl_dense_conv3x3_bwd_workspace_floats(int64_t S);
 int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2, const void* z,
                           const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
                           float* dgamma, float* dbeta, int32_t accumulate_params, void* g2, void* dz, mcl_stream_t stream);
+/* mcl_dense_conv3x3_bwd with mcl_dense_bn1_fix folded into the dy staging (single-pass BatchNorm-1 backward, maps narrower
+ * than 17 pixels): dy' = dy - (K1 + K2*xhat) on the layer's 32 output channels (xfix: those channels of the concat buffer,
+ * row stride ldxf; fmean / frstd: their statistics; fk: [32][2] mean terms of the previous pass), used for the data
+ * gradient and written to dyc (S x 32 bf16 contiguous) for mcl_dense_conv3x3_wrw_det.  Bit-identical to the two launches. */
+int mcl_dense_conv3x3_bwd_fix(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2, const void* z,
+                              const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
+                              float* dgamma, float* dbeta, int32_t accumulate_params, void* g2, void* dz, const void* xfix,
+                              int64_t ldxf, const float* fmean, const float* frstd, const float* fk, void* dyc,
+                              mcl_stream_t stream);
 
 /* Pooling layers of the DenseNet stem / transitions on channels-last bf16 (C % 8 == 0, 16-byte aligned, dense NHWC).
  * mcl_avgpool2_nhwc_bf16: AvgPool2d(2, 2); backward == 0: x (N,H,W,C) -> y (N,H/2,W/2,C); backward != 0: x is dy
@@ -367,6 +381,10 @@ int mcl_maxpool3s2_nhwc_bf16_fwd(const void* x, void* y, void* idx, int32_t N, i
                                  mcl_stream_t stream);
 int mcl_maxpool3s2_nhwc_bf16_bwd(const void* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                                  mcl_stream_t stream);
+/* the same with dy addressed through a row stride (elements per pooled pixel): the channel slice [:C] of a wider gradient
+ * buffer is read in place (no contiguous copy of the first dense block's input gradient).                             */
+int mcl_maxpool3s2_nhwc_bf16_bwd_ld(const void* idx, const void* dy, int64_t lddy, void* dx, int32_t N, int32_t H, int32_t W,
+                                    int32_t C, mcl_stream_t stream);
 
 /* DenseNet transition (torchvision _Transition: norm -> relu -> conv1x1 -> AvgPool2d(2,2)) with the pool moved in
  * front of the (linear, per-pixel) convolution:  p = avgpool2x2(relu(bn(x))), bf16 NHWC, x (N*H*W, C) with row stride
@@ -408,6 +426,37 @@ int mcl_bn_act_maxpool_fwd(const void* x, int32_t N, int32_t H, int32_t W, int32
  * weight gradient into the fp32 .grad view of the flat optimizer bucket (both dense, identical strides). */
 int mcl_accum_into_f32(float* dst, const void* src, int64_t n, int32_t src_dtype, mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- the last pieces of the step (csrc/step_misc.hip)
+ * mcl_bn_gap_fwd: the tail of the DenseNet feature extractor, norm5 -> adaptive_avg_pool2d((1,1)) -> flatten
+ *   (/root/reference/model.py:81-85; no ReLU): out[b][c] = gamma*rstd*(mean_hw x[b][hw][c] - mean[c]) + beta, fp32 (B, C);
+ *   x = (B, HW, C) bf16 rows of stride ldx; xmean (B, C) fp32 (may be NULL) receives the raw pooled means for the backward.
+ * mcl_bn_gap_bwd: from g = dL/dout (B, C) fp32: dgamma / dbeta (accumulate_params != 0: +=), coef (2C floats of scratch:
+ *   the two BatchNorm-backward means) and dx (B, HW, C) bf16 = gamma*rstd*(g/HW - mean(dy) - xhat*mean(dy*xhat)) -- the
+ *   train-mode BatchNorm backward with dy = g/HW broadcast over the map.  Deterministic (fixed-order sums over B).
+ * mcl_bn_running_update: nn.BatchNorm2d's bookkeeping for n layers (HOST arrays of n device pointers / values):
+ *   running_mean.lerp_(mean, momentum); running_var.lerp_(var * factor, momentum)  (factor = count / (count - 1): unbiased);
+ *   num_batches_tracked += 1 (entries may be NULL).  The pointer table travels by value in the kernel arguments, 64 layers
+ *   per launch.
+ * mcl_image_to_bf16_nhwc: y (B, H, W, C) bf16 contiguous = x[b*sb + c*sc + y*sy + x*sx] (fp32, element strides): the
+ *   ``image.to(bf16).contiguous(channels_last)`` in front of the stem for NCHW and channels-last inputs alike.
+ * mcl_fill_zero: bytes (a multiple of 4, p 4-byte aligned) of zeros written by a kernel -- not hipMemsetAsync: a memset
+ *   node inside the captured step graph cost the step its two-lane execution (measured).                              */
+int mcl_bn_gap_fwd(const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t C, const float* gamma, const float* beta,
+                   const float* mean, const float* rstd, float* out, float* xmean, mcl_stream_t stream);
+int mcl_bn_gap_bwd(const float* g, const float* xmean, const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t C,
+                   const float* gamma, const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta,
+                   int32_t accumulate_params, void* dx, int64_t lddx, mcl_stream_t stream);
+int mcl_bn_running_update(int32_t n, float* const* running_mean, float* const* running_var, const float* const* mean,
+                          const float* const* var, int64_t* const* num_batches_tracked, const int32_t* C,
+                          const float* factor, const float* momentum, mcl_stream_t stream);
+int mcl_image_to_bf16_nhwc(const float* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t C, int32_t H,
+                           int32_t W, void* y, mcl_stream_t stream);
+int mcl_fill_zero(void* p, int64_t bytes, mcl_stream_t stream);
+/* ya[i] = a[i] * s[0] (i < na), yb[i] = b[i] * s[0] (i < nb): a loss gradient scaled by autograd's upstream scalar (a
+ * DEVICE value: no host read) for both embedding gradients in one launch.                                             */
+int mcl_scale2_f32(const float* a, int64_t na, const float* b, int64_t nb, const float* s, float* ya, float* yb,
+                   mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
@@ -436,6 +485,10 @@ int mcl_adam_consts_update(int64_t* step, float* consts, const double* hyper, mc
 int mcl_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* consts, mcl_stream_t stream);
 int mcl_adam_table_step_dev(float* p, float* m, float* v, int32_t n_rows, int32_t cols, const int32_t* row_slot,
                             const float* row_grad, int64_t ld_rg, const float* consts, mcl_stream_t stream);
+/* mcl_adam_step_dev with a bf16 shadow: additionally stores round-to-nearest-even(p) into shadow_bf16[i] (the flat low-
+ * precision weight copy the backbone kernels read), so no separate cast pass over the parameters runs after the step. */
+int mcl_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, const float* consts,
+                             void* shadow_bf16, mcl_stream_t stream);
 /* row_slot maintenance: set row_slot[owner_idx[b]] = b for owners (fill != 0) or back to -1.    */
 int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill, mcl_stream_t stream);
 

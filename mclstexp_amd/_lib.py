@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib: Optional[C.CDLL] = None
 
@@ -72,6 +72,15 @@ PROTOTYPES = {
     "mcl_infonce_fused_lse": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_l, c_p],
     "mcl_infonce_fused_grad": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_p, c_p, c_l, c_p],
     "mcl_cast_f32_to_bf16": [c_p, c_l, c_p, c_l, c_l, c_i, c_p],
+    "mcl_infonce_loss_mean": [c_p, c_l, c_p, c_p, c_i, c_f, c_p, c_p],
+    "mcl_adam_step_dev_shadow": [c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p],
+    "mcl_bn_gap_fwd": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mcl_bn_gap_bwd": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
+    "mcl_bn_running_update": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mcl_image_to_bf16_nhwc": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_fill_zero": [c_p, c_l, c_p],
+    "mcl_scale2_f32": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p],
+    "mcl_maxpool3s2_nhwc_bf16_bwd_ld": [c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_gemm_bf16_workspace_floats": [c_i, c_l, c_i],
     "mcl_gemm_bf16": [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_f, c_i, c_p,
                       c_p, c_l, c_l, c_p, c_l, c_p, c_l, c_i, c_p, c_i, c_p],
@@ -100,6 +109,8 @@ PROTOTYPES = {
     "mcl_maxpool3s2_nhwc_bf16_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_maxpool3s2_nhwc_bf16_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_dense_conv3x3_bwd": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
+    "mcl_dense_conv3x3_bwd_fix": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p,
+                                  c_l, c_p, c_p, c_p, c_p, c_p],
     "mcl_dense_bn1_bwd": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "mcl_dense_conv3x3_wrw_workspace_floats": [c_l],
     "mcl_dense_conv3x3_wrw_det": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],

@@ -181,16 +181,12 @@ class ImageEncoder(_PooledSequential):
 
     def forward_fused(self, x, act_dtype=torch.bfloat16):
         from .densenet_fused import densenet_features_fused
-        y = densenet_features_fused(self.model[0], x, act_dtype)
-        y = F.adaptive_avg_pool2d(y.float(), (1, 1))
-        return y.view(y.size(0), -1)
+        return densenet_features_fused(self.model[0], x, act_dtype, pooled=True)
 
     def forward_eval_fused(self, x, act_dtype=torch.bfloat16):
         """Eval-mode (running statistics) forward on the fused kernels: the inference path of evel_her2st.py:50."""
         from .densenet_fused import densenet_features_eval
-        y = densenet_features_eval(self.model[0], x, act_dtype)
-        y = F.adaptive_avg_pool2d(y.float(), (1, 1))
-        return y.view(y.size(0), -1)
+        return densenet_features_eval(self.model[0], x, act_dtype, pooled=True)
 
 
 class ImageEncoder_Resnet(_PooledSequential):

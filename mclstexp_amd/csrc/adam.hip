@@ -28,9 +28,20 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
   p -= c.lr_over_bc1 * (m / denom);
 }
 
+__device__ __forceinline__ unsigned bf16_rne(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7F800000u) == 0x7F800000u) return u >> 16;
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// SHADOW: also store the updated parameter rounded to bf16 (the flat low-precision copy the backbone kernels read: the
+// separate 63 MB -> 31 MB cast pass after the step disappears)
+template <bool SHADOW>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
-                                                   AdamC c_host, const AdamC* __restrict__ c_dev) {
+                                                   AdamC c_host, const AdamC* __restrict__ c_dev,
+                                                   unsigned short* __restrict__ shadow) {
   const AdamC c = c_dev ? *c_dev : c_host;      // device-resident constants: the launch can be replayed from a HIP graph
   const long long n4 = n >> 2;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -45,10 +56,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     adam1(pp.z, gg.z, mm.z, vv.z, c);
     adam1(pp.w, gg.w, mm.w, vv.w, c);
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (SHADOW)
+      reinterpret_cast<uint2*>(shadow)[i] = make_uint2(bf16_rne(pp.x) | (bf16_rne(pp.y) << 16),
+                                                       bf16_rne(pp.z) | (bf16_rne(pp.w) << 16));
   }
   const long long tail0 = n4 << 2;
-  for (long long i = tail0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+  for (long long i = tail0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     adam1(p[i], g[i], m[i], v[i], c);
+    if (SHADOW) shadow[i] = (unsigned short)bf16_rne(p[i]);
+  }
 }
 
 // unaligned fallback (base pointers not 16-byte aligned)
@@ -159,12 +175,17 @@ inline AdamC make_consts(double lr, double b1, double b2, double eps, double wd,
 
 namespace {
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, const AdamC& c, const AdamC* c_dev,
-                hipStream_t st) {
+                hipStream_t st, unsigned short* shadow = nullptr) {
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  if (al16(p) && al16(g) && al16(m) && al16(v))
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, c, c_dev);
+  if (shadow != nullptr) {
+    if (!(al16(p) && al16(g) && al16(m) && al16(v)) || (reinterpret_cast<uintptr_t>(shadow) & 7u)) return MCL_EUNSUPPORTED;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, c, c_dev,
+                       shadow);
+  } else if (al16(p) && al16(g) && al16(m) && al16(v))
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, c, c_dev,
+                       (unsigned short*)nullptr);
   else
     hipLaunchKernelGGL(adam_kernel_scalar, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, (long long)n, c, c_dev);
   MCL_CHECK_LAUNCH();
@@ -224,6 +245,14 @@ extern "C" int mcl_adam_step_dev(float* p, const float* g, float* m, float* v, i
   MCL_CLEAR_ERROR();
   if (!p || !g || !m || !v || !consts || n <= 0) return MCL_EINVAL;
   return launch_adam(p, g, m, v, n, AdamC{}, reinterpret_cast<const AdamC*>(consts), mcl_stream(stream));
+}
+
+extern "C" int mcl_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, const float* consts,
+                                        void* shadow_bf16, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!p || !g || !m || !v || !consts || !shadow_bf16 || n <= 0) return MCL_EINVAL;
+  return launch_adam(p, g, m, v, n, AdamC{}, reinterpret_cast<const AdamC*>(consts), mcl_stream(stream),
+                     reinterpret_cast<unsigned short*>(shadow_bf16));
 }
 
 extern "C" int mcl_adam_table_step_dev(float* p, float* m, float* v, int32_t n_rows, int32_t cols,

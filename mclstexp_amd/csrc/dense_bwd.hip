@@ -379,7 +379,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bwd_kernel(const bf16_t* __res
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, bf16_t* __restrict__ g2,
-                                                             float2* __restrict__ partial, int ntile) {
+                                                             float2* __restrict__ partial, int ntile,
+                                                             // single-pass BatchNorm-1 backward: the mean
+                                                             // terms of the PREVIOUS pass for these 32 channels are subtracted
+                                                             // while dy is staged (xfix = the layer's output channels in the
+                                                             // concat buffer), and the corrected dy of the tile's own pixels
+                                                             // goes to dyc (S x 32) for the weight-gradient kernel: no
+                                                             // separate bn1_fix launch on the critical chain.  NULL: plain dy.
+                                                             const bf16_t* __restrict__ xfix, long long ldxf,
+                                                             const float* __restrict__ fmean,
+                                                             const float* __restrict__ frstd,
+                                                             const float* __restrict__ fk, bf16_t* __restrict__ dyc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -423,6 +433,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bwd_kernel(const bf16_t* __res
     abase[i] = T3B * 256 + row * 64 + (((2 * (i & 1) + h) ^ ((row >> 2) & 3)) << 4);
   }
   if (tid < 4) *reinterpret_cast<uint4*>(lds + zero_off + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  // mean-term constants of this thread's dy chunk (q & 3 == tid & 3 for every q it stages): dy -= fma(ka, x, kb), the
+  // arithmetic of bn1_fix_kernel, bit for bit
+  float fka[8], fkb[8];
+  if (xfix != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cf = (tid & 3) * 8 + e;
+      const float k1 = fk[2 * cf], k2 = fk[2 * cf + 1];
+      fka[e] = k2 * frstd[cf];
+      fkb[e] = fmaf(-fka[e], fmean[cf], k1);
+    }
+  }
 
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int p0 = tile * T3B;
@@ -433,7 +455,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bwd_kernel(const bf16_t* __res
       const int j = q >> 2, ch = q & 3;
       const int p = p0 - (W + 1) + j;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (p >= 0 && p < Si) v = *reinterpret_cast<const uint4*>(dy + (long long)p * lddy + ch * 8);
+      if (p >= 0 && p < Si) {
+        v = *reinterpret_cast<const uint4*>(dy + (long long)p * lddy + ch * 8);
+        if (xfix != nullptr) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(xfix + (long long)p * ldxf + ch * 8);
+          const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+          unsigned gw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float o_lo = __uint_as_float(gw[u] << 16) - fmaf(fka[2 * u], __uint_as_float(xw[u] << 16), fkb[2 * u]);
+            const float o_hi = __uint_as_float(gw[u] & 0xFFFF0000u) -
+                               fmaf(fka[2 * u + 1], __uint_as_float(xw[u] & 0xFFFF0000u), fkb[2 * u + 1]);
+            const f32x2 pv = {o_lo, o_hi};
+            gw[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));
+          }
+          v = make_uint4(gw[0], gw[1], gw[2], gw[3]);
+          // the tile's own pixels (slab rows W+1 .. W+128): hand the corrected dy to the weight-gradient kernel
+          if (dyc != nullptr && j >= W + 1 && j < W + 1 + T3B) *reinterpret_cast<uint4*>(dyc + (long long)p * C3O + ch * 8) = v;
+        }
+      }
       *reinterpret_cast<uint4*>(slab + j * 64 + ((ch ^ ((j >> 2) & 3)) << 4)) = v;
     }
 #pragma unroll
@@ -969,10 +1009,11 @@ extern "C" int64_t mcl_dense_conv3x3_bwd_workspace_floats(int64_t S) {
   return (flat > rows ? flat : rows) * 2 * (int64_t)C3I + 2 * (int64_t)C3I;
 }
 
-extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2,
-                                     const void* z, const float* gamma, const float* beta, const float* mean,
-                                     const float* rstd, float* workspace, float* dgamma, float* dbeta,
-                                     int32_t accumulate_params, void* g2, void* dz, mcl_stream_t stream) {
+namespace {
+int conv3x3_bwd_impl(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2, const void* z,
+                     const float* gamma, const float* beta, const float* mean, const float* rstd, float* workspace,
+                     float* dgamma, float* dbeta, int32_t accumulate_params, void* g2, void* dz, const void* xfix,
+                     int64_t ldxf, const float* fmean, const float* frstd, const float* fk, void* dyc, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!dy || !W2 || !z || !gamma || !beta || !mean || !rstd || !workspace || !dgamma || !dbeta || !g2 || !dz || S <= 0 ||
       H <= 0 || W <= 0)
@@ -981,6 +1022,12 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
       (reinterpret_cast<uintptr_t>(dy) & 15u) || (reinterpret_cast<uintptr_t>(z) & 15u) ||
       (reinterpret_cast<uintptr_t>(g2) & 15u) || (reinterpret_cast<uintptr_t>(dz) & 15u))
     return MCL_EUNSUPPORTED;
+  if (xfix != nullptr) {
+    if (!fmean || !frstd || !fk || !dyc) return MCL_EINVAL;
+    if (bwd_rows_applicable(S, H, W) || (ldxf % 8) || (reinterpret_cast<uintptr_t>(xfix) & 15u) ||
+        (reinterpret_cast<uintptr_t>(dyc) & 15u))
+      return MCL_EUNSUPPORTED;                        // (the folded fix lives in the flat-tile kernel: maps narrower than 17)
+  }
   hipStream_t st = mcl_stream(stream);
   float2* part = reinterpret_cast<float2*>(workspace);
   float* coef;
@@ -1007,7 +1054,7 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
     const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
     hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
                        (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
-                       (bf16_t*)g2, part, ntile);
+                       (bf16_t*)g2, part, ntile, (const bf16_t*)xfix, (long long)ldxf, fmean, frstd, fk, (bf16_t*)dyc);
     hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C3I), dim3(256), 0, st, (const float2*)part, ntile, C3I,
                        (long long)S, dgamma, dbeta, coef, accumulate_params);
   }
@@ -1018,4 +1065,29 @@ extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, in
                      n_chunks, gamma, mean, rstd, (const float*)coef, (bf16_t*)dz);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
+}
+}  // namespace
+
+extern "C" int mcl_dense_conv3x3_bwd(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2,
+                                     const void* z, const float* gamma, const float* beta, const float* mean,
+                                     const float* rstd, float* workspace, float* dgamma, float* dbeta,
+                                     int32_t accumulate_params, void* g2, void* dz, mcl_stream_t stream) {
+  return conv3x3_bwd_impl(dy, lddy, S, H, W, W2, z, gamma, beta, mean, rstd, workspace, dgamma, dbeta, accumulate_params, g2,
+                          dz, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// The same with mcl_dense_bn1_fix folded into the dy staging (maps narrower than 17 pixels: the flat-tile kernel):
+// dy'[s][c] = dy[s][c] - (K1[c] + K2[c]*xhat[s][c]) for the layer's 32 output channels (xfix / fmean / frstd / fk = the
+// concat buffer, its statistics and the previous pass's mean terms [32][2], all offset to the layer's first output
+// channel); dyc (S x 32 bf16, contiguous) receives dy' for mcl_dense_conv3x3_wrw_det.  Same arithmetic as the separate
+// launch, bit for bit.
+extern "C" int mcl_dense_conv3x3_bwd_fix(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t W, const void* W2,
+                                         const void* z, const float* gamma, const float* beta, const float* mean,
+                                         const float* rstd, float* workspace, float* dgamma, float* dbeta,
+                                         int32_t accumulate_params, void* g2, void* dz, const void* xfix, int64_t ldxf,
+                                         const float* fmean, const float* frstd, const float* fk, void* dyc,
+                                         mcl_stream_t stream) {
+  if (!xfix) return MCL_EINVAL;
+  return conv3x3_bwd_impl(dy, lddy, S, H, W, W2, z, gamma, beta, mean, rstd, workspace, dgamma, dbeta, accumulate_params, g2,
+                          dz, xfix, ldxf, fmean, frstd, fk, dyc, stream);
 }

@@ -82,6 +82,31 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ S, 
   }
 }
 
+// the same two sums as loss_kernel (same thread mapping and tree), finished in the launch: (sum_r + sum_c) / denom
+__global__ __launch_bounds__(256) void loss_mean_kernel(const float* __restrict__ S, long long ld,
+                                                        const float* __restrict__ row_lse,
+                                                        const float* __restrict__ col_lse, int n, float denom,
+                                                        float* __restrict__ loss_out) {
+  __shared__ float sr[256], sc[256];
+  float ar = 0.0f, ac = 0.0f;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    const float d = S[(long long)t * ld + t];
+    ar += row_lse[t] - d;
+    ac += col_lse[t] - d;
+  }
+  sr[threadIdx.x] = ar;
+  sc[threadIdx.x] = ac;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      sr[threadIdx.x] += sr[threadIdx.x + s];
+      sc[threadIdx.x] += sc[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = (sr[0] + sc[0]) / denom;
+}
+
 __global__ __launch_bounds__(256) void dlogits_kernel(const float* __restrict__ S, long long ldS,
                                                       const float* __restrict__ row_lse,
                                                       const float* __restrict__ col_lse, int R, int C, int row0,
@@ -116,6 +141,16 @@ extern "C" int mcl_infonce_loss(const float* S, int64_t ldS, const float* row_ls
   if ((use_rows && !row_lse) || (use_cols && !col_lse)) return MCL_EINVAL;
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, mcl_stream(stream), S, ldS, row_lse, col_lse, di0, dj0,
                      n_diag, use_rows, use_cols, loss_sum);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_infonce_loss_mean(const float* S, int64_t ldS, const float* row_lse, const float* col_lse, int32_t n,
+                                     float denom, float* loss_out, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!S || !row_lse || !col_lse || !loss_out || n <= 0 || denom == 0.0f) return MCL_EINVAL;
+  hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(256), 0, mcl_stream(stream), S, ldS, row_lse, col_lse, n, denom,
+                     loss_out);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
 // pixel.  Gather form: deterministic, no atomics.
 __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const unsigned char* __restrict__ idx,
                                                              const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
-                                                             int N, int H, int W, int OH, int OW, int C8) {
+                                                             int N, int H, int W, int OH, int OW, int C8,
+                                                             long long lddy /* elements per pooled pixel row of dy */) {
   const long long total = (long long)N * H * W * C8;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
     const int c8 = (int)(q % C8);
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const unsigned char
         const uint2 pk = *reinterpret_cast<const uint2*>(idx + oq);
         const unsigned me = (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));   // my position in that window
         float gv[8];
-        unpack8(*reinterpret_cast<const uint4*>(dy + oq), gv);
+        unpack8(*reinterpret_cast<const uint4*>(dy + (((long long)n * OH + oy) * OW + ox) * lddy + c8 * 8), gv);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (((pk.x >> (8 * i)) & 0xFFu) == me) acc[i] += gv[i];
@@ -218,15 +219,20 @@ extern "C" int mcl_bn_act_maxpool_fwd(const void* x, int32_t N, int32_t H, int32
   return MCL_OK;
 }
 
-extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd(const void* idx, const void* dy, void* dx, int32_t N, int32_t H,
-                                            int32_t W, int32_t C, mcl_stream_t stream) {
+extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd_ld(const void* idx, const void* dy, int64_t lddy, void* dx, int32_t N, int32_t H,
+                                               int32_t W, int32_t C, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!idx || !ok16(dy) || !ok16(dx) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MCL_EINVAL;
-  if (C % 8) return MCL_EUNSUPPORTED;
+  if (!idx || !ok16(dy) || !ok16(dx) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || lddy < C) return MCL_EINVAL;
+  if ((C % 8) || (lddy % 8)) return MCL_EUNSUPPORTED;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * H * W * (C / 8);
   hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream),
-                     (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8);
+                     (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8, (long long)lddy);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
+}
+
+extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd(const void* idx, const void* dy, void* dx, int32_t N, int32_t H,
+                                            int32_t W, int32_t C, mcl_stream_t stream) {
+  return mcl_maxpool3s2_nhwc_bf16_bwd_ld(idx, dy, C, dx, N, H, W, C, stream);
 }

@@ -209,19 +209,28 @@ class _RunningStats:
 
     @torch.no_grad()
     def flush(self):
+        """ONE C-ABI call (mcl_bn_running_update, csrc/step_misc.hip: 64 layers per launch, the pointer table by value in
+        the kernel arguments) instead of seven torch._foreach launches."""
         if not self.mods:
             return
-        # one momentum per group (nn.BatchNorm2d default 0.1 everywhere in DenseNet)
-        by_m = {}
-        for i, bn in enumerate(self.mods):
-            by_m.setdefault(bn.momentum if bn.momentum is not None else 0.1, []).append(i)
-        for m, idx in by_m.items():
-            rms = [self.mods[i].running_mean for i in idx]
-            rvs = [self.mods[i].running_var for i in idx]
-            torch._foreach_lerp_(rms, [self.means[i] for i in idx], m)
-            unb = torch._foreach_mul([self.vars[i] for i in idx], [self.factors[i] for i in idx])
-            torch._foreach_lerp_(rvs, unb, m)
-        torch._foreach_add_([bn.num_batches_tracked for bn in self.mods], 1)
+        n = len(self.mods)
+        import ctypes as C
+        vp = C.c_void_p * n
+        rm = vp(*[bn.running_mean.data_ptr() for bn in self.mods])
+        rv = vp(*[bn.running_var.data_ptr() for bn in self.mods])
+        mean = vp(*[t.data_ptr() for t in self.means])
+        var = vp(*[t.data_ptr() for t in self.vars])
+        nbt = vp(*[(bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None) for bn in self.mods])
+        cs = (C.c_int32 * n)(*[bn.running_mean.numel() for bn in self.mods])
+        fac = (C.c_float * n)(*self.factors)
+        # nn.BatchNorm2d(momentum=None) means a cumulative average: 1 / num_batches_tracked -- not used by DenseNet; keep
+        # torch's default 0.1 semantics explicit
+        mom = (C.c_float * n)(*[(bn.momentum if bn.momentum is not None else 0.1) for bn in self.mods])
+        for bn, t in zip(self.mods, self.means):
+            if (bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous()
+                    or not bn.running_var.is_contiguous() or not t.is_contiguous() or bn.running_mean.device != t.device):
+                raise RuntimeError("densenet_fused: BatchNorm running statistics must be contiguous fp32 on the GPU")
+        check(_lib.lib().mcl_bn_running_update(n, rm, rv, mean, var, nbt, cs, fac, mom, _stream()), "mcl_bn_running_update")
         self.mods, self.means, self.vars, self.factors = [], [], [], []
 
 
@@ -232,6 +241,8 @@ class _BlockStats:
         self.mean = torch.empty(c_total, device=device, dtype=torch.float32)
         self.var = torch.empty(c_total, device=device, dtype=torch.float32)
         self.rstd = torch.empty(c_total, device=device, dtype=torch.float32)
+        # the block's concat buffer when the producer of its input (TransitionFn) already wrote x0 into [:, :C0] of it
+        self.buf: Optional[Tensor] = None
 
 
 def _as2d(t: Tensor) -> Tensor:
@@ -378,9 +389,25 @@ def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor,
 # conv2 (3x3) backward-data + norm2/relu2 backward (csrc/dense_bwd.hip): dy is read in place from the gradient buffer
 
 
+# The 32-channel mean-term correction of the single-pass BatchNorm-1 backward (mcl_dense_bn1_fix: a 5 us launch in front of
+# every 3x3 backward-data kernel of the 14 x 14 / 7 x 7 blocks, 38 per step on the critical chain) folded into that kernel's
+# dy staging.  MCL_FOLD_BN1_FIX=0: the separate launch (A/B; bit-identical results).
+FOLD_BN1_FIX = os.environ.get("MCL_FOLD_BN1_FIX", "1") != "0"
+
+
+def _c3_flat_kernel(W: int) -> bool:
+    """True when the 3x3 backward-data of a W-wide map runs the flat-tile kernel (csrc/dense_bwd.hip bwd_rows_applicable)."""
+    if os.environ.get("MCL_C3_ROWS", "1") == "0":
+        return True
+    return W < int(os.environ.get("MCL_C3_ROWS_MINW", "17")) or W > 150
+
+
 def dense_conv3x3_bwd(dy: Tensor, w16: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor,
-                      into_param_grads: bool) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
-    """(dz, dgamma2, dbeta2): gradient of the loss w.r.t. the bottleneck output z through conv2 <- relu2 <- norm2."""
+                      into_param_grads: bool, fix=None) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor], Optional[Tensor]]:
+    """(dz, dgamma2, dbeta2, dyc): gradient of the loss w.r.t. the bottleneck output z through conv2 <- relu2 <- norm2.
+    ``fix`` = (x, mean, rstd, k): the layer's 32 output channels of the concat buffer, their statistics and the previous
+    single-pass layer's mean terms -- dy is corrected while it is staged (mcl_dense_conv3x3_bwd_fix) and the corrected copy
+    comes back as ``dyc`` (B, 32, H, W) for the weight-gradient kernel; else dyc is None."""
     B, C, H, W = z.shape
     pd, S, Co, lddy = _rows(dy)
     assert C == 128 and Co == 32 and S == B * H * W and z.is_contiguous(memory_format=CL)
@@ -393,11 +420,23 @@ def dense_conv3x3_bwd(dy: Tensor, w16: Tensor, z: Tensor, g2: Tensor, b2: Tensor
     else:
         dg = torch.empty(C, device=z.device, dtype=torch.float32)
         db = torch.empty(C, device=z.device, dtype=torch.float32)
-    check(L.mcl_dense_conv3x3_bwd(pd, lddy, S, H, W, w16.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
-                                  m2.data_ptr(), r2.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                  int(into_param_grads), scratch.data_ptr(), dz.data_ptr(), _stream()),
-          "mcl_dense_conv3x3_bwd")
-    return (dz, None, None) if into_param_grads else (dz, dg, db)
+    dyc = None
+    if fix is not None:
+        xf, fm, fr, fk = fix
+        pxf, S2, C2, ldxf = _rows(xf)
+        assert (S2, C2) == (S, 32) and fk.is_contiguous() and fk.numel() == 64
+        dyc = torch.empty((B, 32, H, W), device=z.device, dtype=z.dtype, memory_format=CL)
+        check(L.mcl_dense_conv3x3_bwd_fix(pd, lddy, S, H, W, w16.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
+                                          m2.data_ptr(), r2.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                          int(into_param_grads), scratch.data_ptr(), dz.data_ptr(), pxf, ldxf,
+                                          fm.data_ptr(), fr.data_ptr(), fk.data_ptr(), dyc.data_ptr(), _stream()),
+              "mcl_dense_conv3x3_bwd_fix")
+    else:
+        check(L.mcl_dense_conv3x3_bwd(pd, lddy, S, H, W, w16.data_ptr(), z.data_ptr(), g2.data_ptr(), b2.data_ptr(),
+                                      m2.data_ptr(), r2.data_ptr(), ws.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                      int(into_param_grads), scratch.data_ptr(), dz.data_ptr(), _stream()),
+              "mcl_dense_conv3x3_bwd")
+    return (dz, None, None, dyc) if into_param_grads else (dz, dg, db, dyc)
 
 
 # norm2 + relu2 + conv2 (3x3) + the new feature map's statistics as ONE kernel writing into the concat buffer
@@ -592,6 +631,9 @@ def _side_join(device) -> None:
 # per layer, final gradient buffer), so that each kernel can be checked against an fp64 evaluation of exactly its inputs
 # at the benched shapes.  None (the default) = nothing is recorded.
 CAPTURE_BLOCKS: Optional[list] = None
+# The same for everything around the dense blocks (stem convolution, norm0 + pool0, the transitions, norm5 + global pool):
+# a list of dicts {"kind": ..., tensors consumed / produced forward and backward}.
+CAPTURE_MISC: Optional[list] = None
 
 
 class DenseBlockFn(torch.autograd.Function):
@@ -611,9 +653,18 @@ class DenseBlockFn(torch.autograd.Function):
         B, C0, H, W = x0.shape
         Ct = C0 + L * growth
         dev, dt = x0.device, x0.dtype
-        buf = torch.empty((B, Ct, H, W), device=dev, dtype=dt, memory_format=CL)
-        x0 = x0.contiguous(memory_format=CL)
-        if prefilled:
+        pre = getattr(stats, "buf", None) if prefilled else None
+        if (pre is not None and tuple(pre.shape) == (B, Ct, H, W) and pre.dtype == dt and x0.data_ptr() == pre.data_ptr()
+                and x0.stride() == pre[:, :C0].stride()):
+            # the transition's convolution wrote x0 straight into the buffer: no copy (a fresh tensor object on the same
+            # storage: x0 is a view of `pre` and this function's output must not be that view's base object)
+            buf, adopted = pre.detach(), True
+        else:
+            buf, adopted = torch.empty((B, Ct, H, W), device=dev, dtype=dt, memory_format=CL), False
+            x0 = x0.contiguous(memory_format=CL)
+        if adopted:
+            pass
+        elif prefilled:
             buf[:, :C0].copy_(x0)
         else:
             bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
@@ -699,15 +750,22 @@ class DenseBlockFn(torch.autograd.Function):
                 d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
                 fused_wrw = _bn1_wrw_ok(w1) and z.shape[0] * z.shape[2] * z.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS
                 single = not fused_wrw and USE_BN1_SINGLE_PASS and z.shape[2] * z.shape[3] <= BN1_SINGLE_PASS_MAX_MAP
+                fold = None
                 if kacc is not None:
                     if single:      # this layer's 32 output channels: the mean terms of layer l+1, which no later pass covers
-                        dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
+                        if FOLD_BN1_FIX and growth == 32 and _c3_flat_kernel(z.shape[3]):
+                            c1_ = cin + growth          # applied inside the 3x3 backward-data kernel's dy staging
+                            fold = (buf[:, cin:c1_], stats.mean[cin:c1_], stats.rstd[cin:c1_], kacc[cin:c1_])
+                        else:
+                            dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
                     else:           # (a two-pass layer after single-pass ones: it will not apply them -- all channels now)
                         dense_bn1_fix(buf, gbuf, 0, cin + growth, stats.mean, stats.rstd, kacc)
                         kacc = None
-                dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
+                dz, dg2, db2, dyc = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2, fix=fold)
+                dy_w = dyc if dyc is not None else dy_view      # what the 3x3 weight gradient reads
                 if ctx.cap is not None:
                     ctx.cap["dz"][l] = dz
+                    ctx.cap.setdefault("dyc", [None] * L)[l] = dyc
                 ev = torch.cuda.Event()
                 ev.record(main)
                 if fused_wrw:
@@ -727,23 +785,36 @@ class DenseBlockFn(torch.autograd.Function):
                                              gbuf[:, :cin], into_param_grads=d1)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
+                    dense_conv3x3_wrw(dy_w, z, g2, b2, m2, r2, w2)
                     if not fused_wrw:
                         gw1 = conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
-                _side_park(z.device, dz, gbuf, z, buf)
+                _side_park(z.device, dz, gbuf, z, buf, dy_w)
                 grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None]
                 continue
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
             sp_here = (USE_BN1_SINGLE_PASS and fused1 and z.shape[2] * z.shape[3] <= BN1_SINGLE_PASS_MAX_MAP
                        and not (_bn1_wrw_ok(w1) and z.shape[0] * z.shape[2] * z.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS))
+            fold = None
             if kacc is not None:
                 if sp_here:                                     # the previous pass's mean terms: this layer's 32 output channels
-                    dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
+                    if (FOLD_BN1_FIX and growth == 32 and fused2 and _c3_flat_kernel(z.shape[3])
+                            and _wrw3_direct_ok(w2, z, dy_view)):
+                        c1_ = cin + growth
+                        fold = (buf[:, cin:c1_], stats.mean[cin:c1_], stats.rstd[cin:c1_], kacc[cin:c1_])
+                    else:
+                        dense_bn1_fix(buf, gbuf, cin, growth, stats.mean, stats.rstd, kacc)
                 else:                                           # a two-pass layer follows: it will not apply them -- all channels now
                     dense_bn1_fix(buf, gbuf, 0, cin + growth, stats.mean, stats.rstd, kacc)
                     kacc = None
-            if fused2:
+            if fold is not None:
+                # (the same two kernels as the side-stream schedule: backward-data with the folded correction first, then the
+                # weight gradient on the corrected copy)
+                dz, dg2, db2, dyc = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2, fix=fold)
+                dw2_done = dense_conv3x3_wrw(dyc, z, g2, b2, m2, r2, w2)
+                assert dw2_done
+                dw2 = None
+            elif fused2:
                 # fused forward: a2 = relu(bn2(z)) was never stored.  Both kernels read dy in place from the gradient
                 # buffer (row stride C_total): no contiguous copy, no MIOpen call
                 if side is not None:
@@ -752,8 +823,10 @@ class DenseBlockFn(torch.autograd.Function):
                         dw2_done = dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
                 else:
                     dw2_done = dense_conv3x3_wrw(dy_view, z, g2, b2, m2, r2, w2)
-            if dw2_done:
-                dz, dg2, db2 = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
+            if fold is not None:
+                pass
+            elif dw2_done:
+                dz, dg2, db2, _ = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 dw2 = None
             else:
                 dy = dy_view.contiguous(memory_format=CL)
@@ -886,6 +959,10 @@ class Conv0Fn(torch.autograd.Function):
         y = conv0_fwd(x, w16, eps, stats)
         ctx.save_for_backward(x, w16)
         ctx.w = w
+        ctx.cap = None
+        if CAPTURE_MISC is not None:
+            ctx.cap = {"kind": "conv0", "x": x, "w16": w16, "y": y, "stats": stats, "w": w}
+            CAPTURE_MISC.append(ctx.cap)
         return y
 
     @staticmethod
@@ -893,6 +970,8 @@ class Conv0Fn(torch.autograd.Function):
         x, w16 = ctx.saved_tensors
         dy = dy.contiguous(memory_format=CL)
         w = ctx.w
+        if ctx.cap is not None:
+            ctx.cap["dy"] = dy
         B, _, H, W = x.shape
         if DIRECT_PARAM_GRADS and _direct_grad_ok(w) and dy.dtype == torch.bfloat16:
             L = _lib.lib()
@@ -975,6 +1054,10 @@ class StemTailFn(torch.autograd.Function):
                                                 _stream()), "mcl_bn_act_maxpool_fwd")
         ctx.save_for_backward(x, idx, mean, rstd)
         ctx.params = (gamma, beta)
+        ctx.cap = None
+        if CAPTURE_MISC is not None:
+            ctx.cap = {"kind": "stem_tail", "x": x, "y": y, "mean": mean, "rstd": rstd, "params": (gamma, beta)}
+            CAPTURE_MISC.append(ctx.cap)
         return y
 
     @staticmethod
@@ -982,12 +1065,18 @@ class StemTailFn(torch.autograd.Function):
         x, idx, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
         B, C, H, W = x.shape
-        dy = dy.contiguous(memory_format=CL)
+        # dy = the channel slice [:C] of the first dense block's gradient buffer: read in place through its row stride
+        pdy, _, Cd, lddy = _rows(dy)
+        assert Cd == C and dy.dtype == x.dtype
+        if ctx.cap is not None:
+            ctx.cap["dy"] = dy.clone(memory_format=CL)
         g = torch.empty_like(x, memory_format=CL)           # un-pooled gradient (gather, deterministic)
-        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd(idx.data_ptr(), dy.data_ptr(), g.data_ptr(), B, H, W, C, _stream()),
+        check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd_ld(idx.data_ptr(), pdy, lddy, g.data_ptr(), B, H, W, C, _stream()),
               "mcl_maxpool bwd")
         direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
         dg, db = bn_act_bwd(g, x, gamma, beta, mean, rstd, True, g, False, into_param_grads=direct)   # dx in place of g
+        if ctx.cap is not None:
+            ctx.cap["dx"] = g
         return g, dg, db, None, None
 
 
@@ -1037,20 +1126,24 @@ def bn_act_avgpool_fwd(x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rst
     return p
 
 
-def pooled_conv1x1_fwd(p: Tensor, w16: Tensor, eps: float, stats: Optional[_BlockStats]) -> Tensor:
+def pooled_conv1x1_fwd(p: Tensor, w16: Tensor, eps: float, stats: Optional[_BlockStats], out: Optional[Tensor] = None
+                       ) -> Tensor:
     """y = conv1x1(p, w16) for C_out a multiple of 128 (one launch per 128 output channels, each with its statistics
-    epilogue writing stats.mean/var/rstd[n0:n0+128]); ``stats`` None: no statistics (inference)."""
+    epilogue writing stats.mean/var/rstd[n0:n0+128]); ``stats`` None: no statistics (inference).  ``out``: a channels-last
+    (possibly channel-sliced) view that receives y -- the first C_out channels of the next dense block's concat buffer."""
     B, C, H, W = p.shape
     Co = w16.shape[0]
-    y = torch.empty((B, Co, H, W), device=p.device, dtype=p.dtype, memory_format=CL)
+    y = out if out is not None else torch.empty((B, Co, H, W), device=p.device, dtype=p.dtype, memory_format=CL)
+    py, Sy, Cy, ldy = _rows(y)
     one, zero = _identity_bn(p.device)
     pp, S, _, ldp = _rows(p)
+    assert (Sy, Cy) == (S, Co) and y.dtype == p.dtype
     L = _lib.lib()
     ws = _ws(L.mcl_dense_conv1x1_workspace_floats(S), p.device)
     for n0 in range(0, Co, 128):
         st = (None, None, None) if stats is None else tuple(t.data_ptr() + 4 * n0 for t in (stats.mean, stats.var, stats.rstd))
         check(L.mcl_dense_conv1x1_fwd(pp, ldp, S, C, one.data_ptr(), zero.data_ptr(), zero.data_ptr(), one.data_ptr(),
-                                      w16.data_ptr() + 2 * n0 * C, y.data_ptr() + 2 * n0, Co, ws.data_ptr(), eps,
+                                      w16.data_ptr() + 2 * n0 * C, py + 2 * n0, ldy, ws.data_ptr(), eps,
                                       *st, _stream()), "mcl_dense_conv1x1_fwd (transition)")
     return y
 
@@ -1072,10 +1165,17 @@ class TransitionFn(torch.autograd.Function):
         stats, next_stats, eps_next = meta
         p = bn_act_avgpool_fwd(buf, gamma, beta, stats.mean, stats.rstd)
         w16 = _weight(w, buf.dtype)
-        y = pooled_conv1x1_fwd(p, w16, eps_next, next_stats)
+        nbuf = getattr(next_stats, "buf", None)
+        out = nbuf[:, :w16.shape[0]] if nbuf is not None else None
+        y = pooled_conv1x1_fwd(p, w16, eps_next, next_stats, out=out)
         ctx.save_for_backward(buf, p, w16)
         ctx.params = (gamma, beta, w)
         ctx.stats = stats
+        ctx.cap = None
+        if CAPTURE_MISC is not None:
+            ctx.cap = {"kind": "transition", "buf": buf, "p": p, "w16": w16, "y": y, "stats": stats, "next_stats": next_stats,
+                       "params": (gamma, beta, w), "eps_next": eps_next}
+            CAPTURE_MISC.append(ctx.cap)
         return y
 
     @staticmethod
@@ -1092,7 +1192,14 @@ class TransitionFn(torch.autograd.Function):
         if deferred:
             ev = torch.cuda.Event()
             ev.record(main)                                   # dy is final
-        dp = torch.mm(_as2d(dy), w16.view(Co, C))             # (S/4, C): plain library GEMM (hipBLASLt)
+        # dp = dy . W: (S/4, Co) x (Co, C), the weight consumed in place as the reduction-major operand of mcl_gemm_bf16
+        # (csrc/gemm_bf16.hip); dy may be the channel slice [:Co] of the next block's gradient buffer (row stride lddy)
+        pdy, Sq, Co_, lddy = _rows(dy)
+        assert Co_ == Co and dy.dtype == torch.bfloat16
+        dp = torch.empty((B, C, dy.shape[2], dy.shape[3]), device=buf.device, dtype=torch.bfloat16, memory_format=CL)
+        check(_lib.lib().mcl_gemm_bf16(pdy, lddy, 0, w16.data_ptr(), C, 0, dp.data_ptr(), C, 0, Sq, C, Co, 1, 1, 0, 0, 0,
+                                       1.0, 2, None, None, 0, 0, None, 0, None, 0, 1, None, 0, _stream()),
+              "mcl_gemm_bf16 (transition backward-data)")
         dx = torch.empty_like(buf, memory_format=CL)
         direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
         if direct:
@@ -1117,20 +1224,90 @@ class TransitionFn(torch.autograd.Function):
         else:
             dw = conv1x1_wrw(dy, p, w)                        # dW += dy^T p, straight into w.grad when it exists
         gw = None if dw is None else dw.view_as(w).to(w.dtype)
+        if ctx.cap is not None:
+            ctx.cap.update({"dy": dy, "dp": dp, "dx": dx.clone(memory_format=CL)})   # (dx becomes a gradient buffer, in place)
         return dx, (None if direct else dg), (None if direct else db), gw, None
+
+
+class BNGlobalPoolFn(torch.autograd.Function):
+    """norm5 -> F.adaptive_avg_pool2d(., (1, 1)) -> flatten, the tail of /root/reference/model.py:81-85 (no ReLU between
+    them), as ONE forward launch and two backward launches (csrc/step_misc.hip): the pool of an affine map is the affine
+    map of the pool, so the normalised map is never written, and the BatchNorm backward of a gradient that is constant
+    over each image's map needs only sums over the B images.  (B, C, H, W) bf16 channels-last -> (B, C) fp32."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, rstd):
+        B, C, H, W = x.shape
+        px, S, _, ld = _rows(x)
+        out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+        xm = torch.empty((B, C), device=x.device, dtype=torch.float32)
+        check(_lib.lib().mcl_bn_gap_fwd(px, ld, B, H * W, C, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), out.data_ptr(), xm.data_ptr(), _stream()), "mcl_bn_gap_fwd")
+        ctx.save_for_backward(x, xm, mean, rstd)
+        ctx.params = (gamma, beta)
+        ctx.cap = None
+        if CAPTURE_MISC is not None:
+            ctx.cap = {"kind": "norm5_pool", "x": x, "out": out, "mean": mean, "rstd": rstd, "params": (gamma, beta)}
+            CAPTURE_MISC.append(ctx.cap)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xm, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        B, C, H, W = x.shape
+        g = g.contiguous()
+        if g.dtype != torch.float32:
+            g = g.float()
+        px, S, _, ld = _rows(x)
+        dx = torch.empty_like(x, memory_format=CL)
+        direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
+        if direct:
+            dg, db = gamma.grad, beta.grad
+        else:
+            dg = torch.empty(C, device=x.device, dtype=torch.float32)
+            db = torch.empty(C, device=x.device, dtype=torch.float32)
+        coef = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        check(_lib.lib().mcl_bn_gap_bwd(g.data_ptr(), xm.data_ptr(), px, ld, B, H * W, C, gamma.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr(), int(direct),
+                                        dx.data_ptr(), C, _stream()), "mcl_bn_gap_bwd")
+        if ctx.cap is not None:
+            ctx.cap.update({"g": g, "dx": dx.clone(memory_format=CL)})     # (dx becomes block 4's gradient buffer, in place)
+        return dx, (None if direct else dg), (None if direct else db), None, None
+
+
+def _gap_ok(buf: Tensor) -> bool:
+    return (buf.is_cuda and buf.dtype == torch.bfloat16 and buf.dim() == 4 and buf.shape[1] % 8 == 0
+            and buf.is_contiguous(memory_format=CL))
+
+
+def image_to_act(x: Tensor, act_dtype: torch.dtype) -> Tensor:
+    """``x.to(act_dtype).contiguous(memory_format=channels_last)`` of the input image; fp32 -> bf16 as one launch of
+    mcl_image_to_bf16_nhwc for any input strides (NCHW from a DataLoader, channels-last from bench.py)."""
+    if (act_dtype == torch.bfloat16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad
+            and x.numel() > 0):
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H, W), device=x.device, dtype=torch.bfloat16, memory_format=CL)
+        sb, sc, sy, sx = x.stride()
+        check(_lib.lib().mcl_image_to_bf16_nhwc(x.data_ptr(), sb, sc, sy, sx, B, C, H, W, y.data_ptr(), _stream()),
+              "mcl_image_to_bf16_nhwc")
+        return y
+    return x.to(dtype=act_dtype).contiguous(memory_format=CL)
 
 
 # dense block index -> callable invoked on the main stream right after that block's forward has been enqueued
 FORWARD_BLOCK_HOOKS: dict = {}
 
 
-def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16,
+                            pooled: bool = False) -> Tensor:
     """Train-mode forward of torchvision-layout DenseNet ``features`` (conv0 ... norm5), returning the
-    (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly)."""
+    (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly) or, ``pooled``, the (B, C) fp32 features
+    after model.py:83-84's adaptive_avg_pool2d + flatten (norm5 and the pool as one kernel on the bf16 path)."""
     if not x.is_cuda:
         raise RuntimeError("densenet_features_fused: input is on the CPU; the fused backbone path is GPU-only")
     rec = _RunningStats()
-    x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
+    x = image_to_act(x, act_dtype)
     own_conv0 = _conv0_ok(x, features.conv0)
     if own_conv0:
         mean0, var0, rstd0 = (torch.empty(64, device=x.device, dtype=torch.float32) for _ in range(3))
@@ -1167,6 +1344,9 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
             if nxt is not None and _transition_ok(buf, tr.conv.weight):
                 co = tr.conv.weight.shape[0]
                 next_stats = _BlockStats(co + len(nxt) * nxt[0].conv2.out_channels, buf.device)
+                # the next block's concat buffer exists already: the transition's convolution writes its first `co` channels
+                next_stats.buf = torch.empty((buf.shape[0], next_stats.mean.numel(), buf.shape[2] // 2, buf.shape[3] // 2),
+                                             device=buf.device, dtype=buf.dtype, memory_format=CL)
                 x = TransitionFn.apply(buf, tr.norm.weight, tr.norm.bias, tr.conv.weight,
                                        (stats, next_stats, nxt[0].norm1.eps))
             else:
@@ -1175,7 +1355,12 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
                 x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
                 x = avg_pool_2(x.contiguous(memory_format=CL))
         else:
-            out = BNActFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd, False)
+            if pooled and _gap_ok(buf):
+                out = BNGlobalPoolFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd)
+            else:
+                out = BNActFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd, False)
+                if pooled:
+                    out = F.adaptive_avg_pool2d(out.float(), (1, 1)).flatten(1)
             rec.add(features.norm5, stats.mean, stats.var, n)
         i += 1
     rec.flush()
@@ -1184,7 +1369,8 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
 
 # --------------------------------------------------------------------------- inference (eval mode, running statistics)
 @torch.no_grad()
-def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16,
+                           pooled: bool = False) -> Tensor:
     """Eval-mode forward of torchvision-layout DenseNet ``features`` (what ``model.image_encoder`` computes for
     /root/reference/evel_her2st.py:50) on the same fused kernels as training: every BatchNorm is the affine map of
     its RUNNING statistics, applied inside the convolution prologues, so a dense layer is two launches (no statistics,
@@ -1206,7 +1392,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
         bn_act_fwd(t, bn.weight, bn.bias, bn.running_mean, rs[id(bn)], relu, out)
         return out
 
-    x = x.to(dtype=act_dtype).contiguous(memory_format=CL)
+    x = image_to_act(x, act_dtype)
     if _conv0_ok(x, features.conv0):
         x = conv0_fwd(x, _weight(features.conv0.weight, act_dtype), features.norm0.eps, None)
     else:
@@ -1249,7 +1435,16 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 _fallback("eval.transition:miopen", buf)
                 a = affine(buf, tr.norm, True)
                 x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
+        elif pooled and _gap_ok(buf):
+            bn = features.norm5
+            B, C, H, W = buf.shape
+            out = torch.empty((B, C), device=buf.device, dtype=torch.float32)
+            check(_lib.lib().mcl_bn_gap_fwd(buf.data_ptr(), C, B, H * W, C, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                            bn.running_mean.data_ptr(), rs[id(bn)].data_ptr(), out.data_ptr(), None,
+                                            _stream()), "mcl_bn_gap_fwd")
         else:
             out = affine(buf, features.norm5, False)
+            if pooled:
+                out = F.adaptive_avg_pool2d(out.float(), (1, 1)).flatten(1)
         i += 1
     return out

@@ -49,14 +49,51 @@ class TrainStep:
         self._sizes_ex = None
         self._all_regular = True
         self.opt_in_graph = False
+        self._one = None
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
         loss = self.model(batch)
         self.opt.zero_grad()
-        loss.backward()
+        # (an explicit, cached root gradient: a bare loss.backward() makes autograd launch an ATen fill for ones_like(loss))
+        if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype:
+            self._one = torch.ones_like(loss)
+        loss.backward(self._one)
         self._reduce_and_step()
         return loss.detach()
+
+    def _sequence(self, inp):
+        """The launch sequence of the single step graph up to the optimizer, shared by the capture and by
+        ``run_sequence_eager``: forward, closed-form InfoNCE forward + backward, zero_grad, backward from the embeddings."""
+        m = self.model
+        es, ei = m.embed(inp)
+        loss, d_es, d_ei = m.loss_and_grads(es, ei)
+        self.opt.zero_grad()
+        torch.autograd.backward((es, ei), (d_es, d_ei))
+        return es, ei, loss
+
+    def run_sequence_eager(self, batch) -> Tensor:
+        """One optimisation step issued EAGERLY with exactly the calls the single step graph records (``_sequence`` +
+        ``optimizer.step()``, the position tables updated from inside the backward): what a kernel-level audit of the
+        captured step profiles (tests/test_own_kernels_gpu.py) -- kernels of a replayed graph are not individually visible
+        to torch.profiler on this stack."""
+        if self.reducer is not None or getattr(self.model, "process_group", None) is not None:
+            raise RuntimeError("run_sequence_eager mirrors the single-process step graph")
+        m = self.model
+        batch = {k: batch[k] for k in ("image", "expression", "position")}
+        sink = getattr(m, "sparse_grads", None)
+        early = (self.opt_will_be_in_graph() and sink is not None and hasattr(self.opt, "_early_tables")
+                 and getattr(m, "embedding_grad", "dense") == "rowsparse" and "hook" not in sink
+                 and os.environ.get("MCL_EARLY_TABLES", "1") != "0")
+        if early:
+            sink["hook"] = self.opt._early_tables
+        try:
+            _, _, loss = self._sequence(batch)
+            self.opt.step()
+        finally:
+            if early:
+                sink.pop("hook", None)
+        return loss
 
     def _reduce_and_step(self) -> None:
         """Data parallel: the 63 MB flat-gradient all-reduce is enqueued asynchronously and overlaps the HBM-bound
@@ -94,12 +131,9 @@ class TrainStep:
             if early:
                 sink["hook"] = self.opt._early_tables
             with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
-                self.es, self.ei = m.embed(self.static_in)
-                self.loss, d_es, d_ei = m.loss_and_grads(self.es, self.ei)
-                self.opt.zero_grad()
                 if getattr(m, "embedding_grad", "dense") == "rowsparse":
                     m.sparse_grads["static"] = True          # the captured backward's dout / ix / iy are static buffers
-                torch.autograd.backward((self.es, self.ei), (d_es, d_ei))
+                self.es, self.ei, self.loss = self._sequence(self.static_in)
                 # the optimizer too: FusedAdam keeps its step counter and constants on the device (optim._begin_step), so
                 # its launches replay unchanged -- no eager launches between two replays
                 self.opt_in_graph = hasattr(self.opt, "_begin_step") and os.environ.get("MCL_OPT_IN_GRAPH", "1") != "0"

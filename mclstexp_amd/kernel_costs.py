@@ -62,6 +62,14 @@ def _conv3x3_flops_S2(a):
     return 2 * a[2] * 32 * 1152
 
 
+def _conv3x3_bwd_fix(a):        # + the layer's 32 concat-buffer channels read and the corrected dy written (folded bn1_fix)
+    return _conv3x3_bwd(a) + 2 * a[2] * (32 + 32)
+
+
+def _conv3x3_bwd_fix_strict(a):
+    return _conv3x3_bwd_strict(a) + 2 * a[2] * (32 + 32)
+
+
 def _conv1x1_fwd(a):            # (x, ldx, S, K, ...)
     S, K = a[2], a[3]
     return 2 * S * (K + 128)
@@ -111,12 +119,18 @@ def _adam(a):                   # (p, g, m, v, n, ...): read p, g, m, v; write p
     return 28 * a[4]
 
 
+def _adam_shadow(a):            # + the bf16 shadow written
+    return 30 * a[4]
+
+
 def _zero(a):
     return 0
 
 
-def _e(kernels, b, strict=None, flops=_zero, bound=None):
-    return {"kernels": kernels, "bytes": b, "strict": strict or b, "flops": flops, "bound": bound}
+def _e(kernels, b, strict=None, flops=_zero, bound=None, unit=None):
+    """``unit``: the launch unit this entry point is reported under (two entry points that run the same kernels on different
+    layers -- with / without the folded bn1_fix -- are one row of the roofline table)."""
+    return {"kernels": kernels, "bytes": b, "strict": strict or b, "flops": flops, "bound": bound, "unit": unit}
 
 
 TABLE = {
@@ -131,11 +145,16 @@ TABLE = {
     "mcl_dense_bn1_fix": _e("bn1_fix_kernel", _bn1_fix, bound="latency"),
     "mcl_dense_bn1_bwd": _e("bn1_bwd_kernel<0> + bn1_bwd_finalize_kernel + bn1_bwd_kernel<1>", _bn1_bwd, _bn1_bwd_strict,
                             flops=lambda a: 2 * _bn1_flops(a)),
-    "mcl_dense_conv3x3_bwd": _e("conv3x3_bwd_kernel + finalize + bn2_dz_kernel", _conv3x3_bwd, _conv3x3_bwd_strict,
-                                flops=_conv3x3_flops_S2, bound="mfma/lds"),
+    "mcl_dense_conv3x3_bwd": _e("conv3x3_bwd_rows_kernel (56x56, 28x28 maps) / conv3x3_bwd_kernel (14x14, 7x7; with the "
+                                "folded bn1_fix as mcl_dense_conv3x3_bwd_fix) + bn1_bwd_finalize_kernel + bn2_dz_kernel",
+                                _conv3x3_bwd, _conv3x3_bwd_strict, flops=_conv3x3_flops_S2, bound="mfma/lds"),
+    "mcl_dense_conv3x3_bwd_fix": _e("conv3x3_bwd_kernel (folded bn1_fix) + bn1_bwd_finalize_kernel + bn2_dz_kernel",
+                                    _conv3x3_bwd_fix, _conv3x3_bwd_fix_strict, flops=_conv3x3_flops_S2, bound="mfma/lds",
+                                    unit="mcl_dense_conv3x3_bwd"),
     "mcl_dense_conv1x1_fwd": _e("conv1x1_fwd_kernel + tile_stats_finalize_kernel", _conv1x1_fwd, flops=_conv1x1_fwd_flops),
     "mcl_dense_conv3x3_fwd": _e("conv3x3_fwd_rows_kernel + sums_finalize_kernel (56x56, 28x28 maps) / conv3x3_fwd_kernel + "
                                 "tile_stats_finalize_kernel", _conv3x3_fwd, flops=_conv3x3_flops_S1, bound="mfma/lds"),
     "mcl_adam_table_step_dev": _e("adam_table_kernel", _adam_table, bound="hbm"),
     "mcl_adam_step_dev": _e("adam_kernel", _adam, bound="hbm"),
+    "mcl_adam_step_dev_shadow": _e("adam_kernel<shadow> (update + bf16 shadow of the parameters)", _adam_shadow, bound="hbm"),
 }

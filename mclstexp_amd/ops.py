@@ -487,10 +487,9 @@ def infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, want_logi
     gemm_raw(B, B, P, 1, es, es.stride(0), 1, 0, ei, 1, ei.stride(0), 0, S, B, 0, alpha=1.0 / temperature)
     lse = torch.empty((2, B), device=dev, dtype=torch.float32)
     check(L.mcl_infonce_lse(S.data_ptr(), B, B, B, lse[0].data_ptr(), lse[1].data_ptr(), _stream()), "mcl_infonce_lse")
-    sums = torch.zeros((2,), device=dev, dtype=torch.float32)
-    check(L.mcl_infonce_loss(S.data_ptr(), B, lse[0].data_ptr(), lse[1].data_ptr(), 0, 0, B, 1, 1, sums.data_ptr(),
-                             _stream()), "mcl_infonce_loss")
-    loss = (sums[0] + sums[1]) / (2.0 * B)
+    loss = torch.empty((), device=dev, dtype=torch.float32)
+    check(L.mcl_infonce_loss_mean(S.data_ptr(), B, lse[0].data_ptr(), lse[1].data_ptr(), B, 2.0 * B, loss.data_ptr(),
+                                  _stream()), "mcl_infonce_loss_mean")
     dS = torch.empty_like(S)
     check(L.mcl_infonce_dlogits(S.data_ptr(), B, lse[0].data_ptr(), lse[1].data_ptr(), B, B, 0, 0,
                                 1.0 / (2.0 * B * temperature), dS.data_ptr(), B, _stream()), "mcl_infonce_dlogits")
@@ -692,6 +691,12 @@ class InfoNCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gl):
         d_es, d_ei = ctx.saved_tensors
+        if (gl.is_cuda and gl.numel() == 1 and gl.dtype == torch.float32 and d_es.is_contiguous() and d_ei.is_contiguous()
+                and d_es.dtype == d_ei.dtype == torch.float32):
+            ya, yb = torch.empty_like(d_es), torch.empty_like(d_ei)     # both scaled in ONE launch, gl read on the device
+            check(_lib.lib().mcl_scale2_f32(d_es.data_ptr(), d_es.numel(), d_ei.data_ptr(), d_ei.numel(), gl.data_ptr(),
+                                            ya.data_ptr(), yb.data_ptr(), _stream()), "mcl_scale2_f32")
+            return ya, yb, None, None, None
         return d_es * gl, d_ei * gl, None, None, None
 
 

@@ -132,12 +132,16 @@ class FusedAdam(torch.optim.Optimizer):
         return v
 
     @torch.no_grad()
-    def _refresh_shadows(self) -> None:
-        for f in self._flat.values():
+    def _refresh_shadows(self, fused_bf16=()) -> None:
+        """``fused_bf16``: group indices whose bf16 shadow was just written by the Adam kernel itself
+        (mcl_adam_step_dev_shadow) -- no cast pass for those."""
+        for gi, f in self._flat.items():
             if not f.get("shadow_keys"):
                 continue
-            for key, _ in f["shadow_keys"]:
-                f[key].copy_(f["p"])
+            for key, dt in f["shadow_keys"]:
+                if gi in fused_bf16 and dt == torch.bfloat16:
+                    continue
+                f[key].copy_(f["p"])       # (outside the steady-state step: first use, load_state_dict, non-bf16 shadows)
             self._pver.update({id(q): q._version for q in f["params"]})
 
     refresh_shadows = _refresh_shadows      # public: call after editing parameters in place outside step()
@@ -151,7 +155,10 @@ class FusedAdam(torch.optim.Optimizer):
         flat_ids = set()
         for f in self._flat.values():
             if f.get("n", 0) > 0:
-                f["g"].zero_()
+                if f["g"].is_cuda:      # own fill kernel (the captured step graph holds kernel nodes only)
+                    check(_lib.lib().mcl_fill_zero(f["g"].data_ptr(), 4 * f["g"].numel(), ops._stream()), "mcl_fill_zero")
+                else:
+                    f["g"].zero_()
                 flat_ids.update(id(p) for p in f["params"])
         for group in self.param_groups:
             for p in group["params"]:
@@ -211,7 +218,16 @@ class FusedAdam(torch.optim.Optimizer):
                                           self._dev_state(gi, p.device)["consts"].data_ptr(), st), "mcl_adam_step_dev")
         for h in (wait or []):
             h.wait()
+        fused_shadow = []
         for gi, f in deferred:
+            sh = f.get("shadow_" + str(torch.bfloat16))
+            if sh is not None:
+                # the update also writes the bf16 shadow the backbone kernels read: no cast pass after the step
+                check(L.mcl_adam_step_dev_shadow(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
+                                                 f["n"], self._dev_state(gi, f["p"].device)["consts"].data_ptr(),
+                                                 sh.data_ptr(), st), "mcl_adam_step_dev_shadow")
+                fused_shadow.append(gi)
+                continue
             check(L.mcl_adam_step_dev(f["p"].data_ptr(), f["g"].data_ptr(), f["m"].data_ptr(), f["v"].data_ptr(),
                                       f["n"], self._dev_state(gi, f["p"].device)["consts"].data_ptr(), st),
                   "mcl_adam_step_dev")
@@ -227,7 +243,7 @@ class FusedAdam(torch.optim.Optimizer):
                     self._sink["hook"] = hook
         self._began = False
         self._step_count += 1
-        self._refresh_shadows()
+        self._refresh_shadows(fused_bf16=fused_shadow)
         return loss
 
     # ------------------------------------------------------------------ device-resident step state

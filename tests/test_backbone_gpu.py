@@ -694,6 +694,59 @@ def test_dense_conv3x3_bwd_fused(B, H, W, lddy):
     assert_close_scaled((db + 0.25).cpu(), br.grad.cpu(), 3e-3, what="dbeta2")
 
 
+@pytest.mark.parametrize("B,H,W,ct,cin", [(16, 14, 14, 1024, 512), (32, 7, 7, 1024, 992), (3, 10, 6, 96, 32), (5, 16, 16, 256, 224),
+                                          (1, 3, 5, 64, 0)])
+def test_dense_conv3x3_bwd_with_folded_bn1_fix(B, H, W, ct, cin):
+    """mcl_dense_conv3x3_bwd_fix == mcl_dense_bn1_fix on the layer's 32 gradient channels followed by mcl_dense_conv3x3_bwd,
+    BIT FOR BIT (dz, dgamma2, dbeta2), and the corrected dy it hands to the weight-gradient kernel equals the in-place
+    corrected slice (maps narrower than 17 pixels only: the flat-tile kernel)."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    L = _lib.lib()
+    S = B * H * W
+    g = torch.Generator().manual_seed(S + cin)
+    buf = ((torch.rand(S, ct, generator=g) - 0.3) * 2).to(torch.bfloat16).to(DEV)          # the concat buffer
+    gbuf = ((torch.rand(S, ct, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)      # the gradient buffer
+    z = ((torch.rand(S, 128, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)
+    W2 = ((torch.rand(32, 3, 3, 128, generator=g) - 0.5) / 6).to(torch.bfloat16).to(DEV)
+    gam = (torch.rand(128, generator=g) + 0.5).to(DEV)
+    bet = (torch.rand(128, generator=g) - 0.5).to(DEV)
+    mu2 = z.float().mean(0).contiguous()
+    rs2 = (1.0 / torch.sqrt(z.float().var(0, unbiased=False) + 1e-5)).contiguous()
+    mean = buf.float().mean(0).contiguous()
+    rstd = (1.0 / torch.sqrt(buf.float().var(0, unbiased=False) + 1e-5)).contiguous()
+    kacc = ((torch.rand(ct, 2, generator=g) - 0.5) * 0.05).to(DEV)
+    st = dn._stream()
+
+    def run(fold):
+        gb = gbuf.clone()
+        dg = torch.full((128,), 0.5, device=DEV)
+        db = torch.full((128,), -0.25, device=DEV)
+        g2 = torch.empty(S, 128, device=DEV, dtype=torch.bfloat16)
+        dz = torch.empty(S, 128, device=DEV, dtype=torch.bfloat16)
+        ws = torch.empty(L.mcl_dense_conv3x3_bwd_workspace_floats(S), device=DEV)
+        dy = gb[:, cin:cin + 32]
+        if fold:
+            dyc = torch.empty(S, 32, device=DEV, dtype=torch.bfloat16)
+            _lib.check(L.mcl_dense_conv3x3_bwd_fix(dy.data_ptr(), ct, S, H, W, W2.data_ptr(), z.data_ptr(), gam.data_ptr(),
+                                                   bet.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), ws.data_ptr(), dg.data_ptr(),
+                                                   db.data_ptr(), 1, g2.data_ptr(), dz.data_ptr(),
+                                                   buf[:, cin:].data_ptr(), ct, mean[cin:].data_ptr(), rstd[cin:].data_ptr(),
+                                                   kacc[cin:].data_ptr(), dyc.data_ptr(), st))
+            assert torch.equal(gb, gbuf), "the folded form must not write the gradient buffer"
+            return dz, dg, db, dyc
+        _lib.check(L.mcl_dense_bn1_fix(buf.data_ptr(), ct, gb.data_ptr(), ct, S, cin, 32, mean.data_ptr(), rstd.data_ptr(),
+                                       kacc.data_ptr(), st))
+        _lib.check(L.mcl_dense_conv3x3_bwd(dy.data_ptr(), ct, S, H, W, W2.data_ptr(), z.data_ptr(), gam.data_ptr(),
+                                           bet.data_ptr(), mu2.data_ptr(), rs2.data_ptr(), ws.data_ptr(), dg.data_ptr(),
+                                           db.data_ptr(), 1, g2.data_ptr(), dz.data_ptr(), st))
+        return dz, dg, db, dy.contiguous()
+
+    a, b = run(False), run(True)
+    for x, y, what in zip(a, b, ("dz", "dgamma2", "dbeta2", "corrected dy")):
+        assert torch.equal(x, y), f"{what}: folded fix differs from bn1_fix + conv3x3_bwd"
+    assert not torch.equal(a[3], gbuf[:, cin:cin + 32]), "the correction must change dy in this test"
+
+
 @pytest.mark.parametrize("B,C,H,W", [(4, 64, 112, 112), (3, 64, 17, 9), (2, 128, 56, 56), (5, 8, 6, 10)])
 def test_pool_kernels(B, C, H, W):
     """csrc/pool.hip vs ATen on the same channels-last bf16 data: MaxPool2d(3,2,1) forward bit-exact and backward

@@ -14,6 +14,12 @@ bottleneck output z, the bf16 incoming gradient) and each output is bounded indi
     dz  (conv2 backward-data + norm2 / relu2 backward), bf16            2e-2 of max|dz|     (g2 and dz both rounded)
     dgamma2, dbeta2, dW2, dW1, dgamma1, dbeta1    fp32                  5e-3 of the tensor's max
 
+Round 4: ALL 58 dense layers; the gradient each layer's kernels CONSUMED (the block's bf16 gradient buffer
+with every earlier layer's BatchNorm-1 backward accumulated into it, including the one-pass-late mean terms of the
+single-pass form and the correction folded into the 3x3 backward-data staging) against an fp64 accumulation of the same
+terms, and the block-input gradient that leaves each block (1e-2 of max); the three transitions forward and backward; the
+stem (conv0, norm0 statistics, norm0 -> relu0 -> pool0) and the tail (norm5 + global average pool).
+
 The deviation of the stock bf16 autocast ops (what PyTorch-ROCm computes for the same layer from the same inputs) is
 printed beside each forward result.  Oracle here = fp64 torch of the layer's defining formulas (torchvision _DenseLayer:
 norm1 -> relu1 -> conv1 -> norm2 -> relu2 -> conv2, /root/reference/model.py:75-76 via torchvision); the backbone's parity
@@ -45,6 +51,13 @@ def _rows(t):            # NHWC-stored (B, C, H, W) view -> (S, C) strided view
     return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
 
 
+def _q(a, b, q=0.999):
+    """|a - b| at quantile q, relative to max|b| (for tensors where a handful of elements legitimately differ: max-pool ties)."""
+    d = (a.double() - b.double()).abs().flatten()
+    k = max(1, int(d.numel() * q))
+    return float(d.kthvalue(k).values / (b.double().abs().max() + 1e-30))
+
+
 @pytest.mark.parametrize("B,HW", [(128, 224)])
 def test_dense_layers_teacher_forced_at_benched_shapes(B, HW):
     from mclstexp_amd import backbones, densenet_fused as dn
@@ -54,14 +67,14 @@ def test_dense_layers_teacher_forced_at_benched_shapes(B, HW):
     x = torch.rand((B, 3, HW, HW), device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
     dy_feat = (torch.rand((B, 1024), device=DEV, generator=g) - 0.5)
     dn.reset_fallbacks()
-    dn.CAPTURE_BLOCKS = []
+    dn.CAPTURE_BLOCKS, dn.CAPTURE_MISC = [], []
     try:
         y = enc.forward_fused(x, torch.bfloat16)
         y.backward(dy_feat)
         torch.cuda.synchronize()
-        blocks = dn.CAPTURE_BLOCKS
+        blocks, misc = dn.CAPTURE_BLOCKS, dn.CAPTURE_MISC
     finally:
-        dn.CAPTURE_BLOCKS = None
+        dn.CAPTURE_BLOCKS = dn.CAPTURE_MISC = None
     assert dn.fallback_counts() == {}, dn.fallback_counts()
     assert len(blocks) == 4
     feats = enc.model[0]
@@ -71,13 +84,19 @@ def test_dense_layers_teacher_forced_at_benched_shapes(B, HW):
         worst[key] = max(worst.get(key, 0.0), v)
         assert v <= tol, (key, v, tol)
 
+    n_layers = 0
     for bi, cap in enumerate(blocks):
         blk = getattr(feats, f"denseblock{bi + 1}")
         layers = list(blk.values())
         L, C0, buf, gbuf = len(layers), cap["C0"], cap["buf"], cap["gbuf"]
-        Bn, _, H, W = buf.shape
+        Bn, Ct, H, W = buf.shape
         S = Bn * H * W
-        for l in sorted({0, L // 2, L - 1}):
+        # fp64 accumulation of the block's gradient buffer: the incoming gradient plus, layer by layer in backward order, the
+        # BatchNorm-1 backward dx of every layer computed in fp64 from the dz its kernels produced
+        G64 = _rows(cap["gin"]).double()
+        dycs = cap.get("dyc") or [None] * L
+        for l in range(L - 1, -1, -1):
+            n_layers += 1
             ly = layers[l]
             cin = C0 + 32 * l
             tag = f"block{bi + 1}.layer{l + 1} ({H}x{W}, C_in {cin})"
@@ -98,9 +117,10 @@ def test_dense_layers_teacher_forced_at_benched_shapes(B, HW):
             z64 = a1.double() @ w1.double().t()
             z = _rows(cap["z"][l])
             note("z", _rel(z, z64), 1e-2)
+            sample = l in (0, L // 2, L - 1)
             e_stock_z = _stock(lambda: _rows(F.conv2d(F.relu(F.batch_norm(
                 buf[:, :cin].contiguous(memory_format=torch.channels_last), None, None, ly.norm1.weight, ly.norm1.bias, True, 0.0,
-                ly.norm1.eps)), ly.conv1.weight)), z64)
+                ly.norm1.eps)), ly.conv1.weight)), z64) if sample else float("nan")
             # ---- norm2 statistics of the bf16 z, then y = conv2(relu(norm2(z)))
             m2, v2, r2 = cap["bn2"][l]
             zd = z.double()
@@ -117,9 +137,13 @@ def test_dense_layers_teacher_forced_at_benched_shapes(B, HW):
             yo = buf[:, cin:cin + 32]
             note("y", _rel(yo, y64), 1e-2)
             e_stock_y = _stock(lambda: F.conv2d(F.relu(F.batch_norm(cap["z"][l], None, None, ly.norm2.weight, ly.norm2.bias,
-                                                                    True, 0.0, ly.norm2.eps)), ly.conv2.weight, padding=1), y64)
-            # ---- backward of the layer tail from the gradient the kernels read: dy = final gradient of the layer's 32 channels
-            dy = gbuf[:, cin:cin + 32]
+                                                                    True, 0.0, ly.norm2.eps)), ly.conv2.weight, padding=1),
+                               y64) if sample else float("nan")
+            # ---- the gradient the layer's kernels consumed: its 32 channels of the gradient buffer as they stood when the 3x3
+            # backward kernels ran (the corrected copy when bn1_fix is folded into the backward-data staging), against the fp64
+            # accumulation of everything that flowed into those channels
+            dy = dycs[l] if dycs[l] is not None else gbuf[:, cin:cin + 32]
+            note("dy consumed", _rel(_rows(dy), G64[:, cin:cin + 32]), 1e-2)
             dyd = dy.double()
             da2 = F.conv_transpose2d(dyd, w2d, padding=1)                       # backward-data of conv2
             mask = (a2n > 0)
@@ -129,21 +153,119 @@ def test_dense_layers_teacher_forced_at_benched_shapes(B, HW):
             dgamma2 = (g2 * zhat).sum((0, 2, 3))
             dz64 = (ly.norm2.weight.detach().double() * r2.double()).view(1, -1, 1, 1) * (
                 g2 - (dbeta2 / S).view(1, -1, 1, 1) - zhat * (dgamma2 / S).view(1, -1, 1, 1))
+            assert cap["dz"][l] is not None
             note("dz", _rel(cap["dz"][l], dz64), 2e-2)
             note("dgamma2", _rel(ly.norm2.weight.grad, dgamma2), 5e-3)
             note("dbeta2", _rel(ly.norm2.bias.grad, dbeta2), 5e-3)
             dw2 = torch.nn.grad.conv2d_weight(a2n, w2d.shape, dyd, padding=1)
             note("dW2", _rel(ly.conv2.weight.grad, dw2), 5e-3)
-            # ---- head backward from the dz the kernels produced (bf16): dW1, dgamma1, dbeta1
+            # ---- head backward from the dz the kernels produced (bf16): dW1, dgamma1, dbeta1, and dx into the fp64 buffer
             dzo = _rows(cap["dz"][l]).double()
             dw1 = dzo.t() @ a1.double()
             note("dW1", _rel(ly.conv1.weight.grad.reshape(128, cin), dw1), 5e-3)
             g1 = (dzo @ w1.double()) * (a1 > 0)
             xhat = (x64 - mean.double()) * rstd.double()
-            note("dbeta1", _rel(ly.norm1.bias.grad, g1.sum(0)), 5e-3)
-            note("dgamma1", _rel(ly.norm1.weight.grad, (g1 * xhat).sum(0)), 5e-3)
-            print(f"{tag}: z {_rel(z, z64):.2e} (stock bf16 ops {e_stock_z:.2e})  y {_rel(yo, y64):.2e} (stock {e_stock_y:.2e})  "
-                  f"dz {_rel(cap['dz'][l], dz64):.2e}  dW2 {_rel(ly.conv2.weight.grad, dw2):.2e}  "
-                  f"dW1 {_rel(ly.conv1.weight.grad.reshape(128, cin), dw1):.2e}")
+            db1, dg1 = g1.sum(0), (g1 * xhat).sum(0)
+            note("dbeta1", _rel(ly.norm1.bias.grad, db1), 5e-3)
+            note("dgamma1", _rel(ly.norm1.weight.grad, dg1), 5e-3)
+            G64[:, :cin] += (ly.norm1.weight.detach().double() * rstd.double()) * (g1 - db1 / S - xhat * (dg1 / S))
+            if sample:
+                print(f"{tag}: z {_rel(z, z64):.2e} (stock bf16 ops {e_stock_z:.2e})  y {_rel(yo, y64):.2e} (stock {e_stock_y:.2e})  "
+                      f"dz {_rel(cap['dz'][l], dz64):.2e}  dW2 {_rel(ly.conv2.weight.grad, dw2):.2e}  "
+                      f"dW1 {_rel(ly.conv1.weight.grad.reshape(128, cin), dw1):.2e}  "
+                      f"dy consumed {_rel(_rows(dy), G64[:, cin:cin + 32]):.2e}")
             del x64, z64, zd, a2n, y64, da2, g2, zhat, dz64, dzo, g1, xhat
-    print("worst over the sampled layers:", {k: f"{v:.2e}" for k, v in worst.items()})
+        # what leaves the block: the gradient of its input, every layer's late mean terms included
+        e_in = _rel(_rows(gbuf[:, :C0]), G64[:, :C0])
+        note("block input gradient", e_in, 1e-2)
+        print(f"block{bi + 1}: input gradient (all {L} layers' BatchNorm-1 backward accumulated in bf16) {e_in:.2e} of max")
+        del G64
+    assert n_layers == 58
+
+    # ------------------------------------------------------------------------------------------------ transitions
+    trs = [c for c in misc if c["kind"] == "transition"]
+    assert len(trs) == 3
+    for ti, c in enumerate(trs):
+        buf, p, w16, yv, st, nst = c["buf"], c["p"], c["w16"], c["y"], c["stats"], c["next_stats"]
+        gamma, beta, w = c["params"]
+        Bn, C, H, W = buf.shape
+        Co = w16.shape[0]
+        S = Bn * H * W
+        x64 = buf.double()
+        mean, rstd = st.mean.double().view(1, -1, 1, 1), st.rstd.double().view(1, -1, 1, 1)
+        xhat = (x64 - mean) * rstd
+        a64 = torch.relu(xhat * gamma.detach().double().view(1, -1, 1, 1) + beta.detach().double().view(1, -1, 1, 1))
+        note("transition p", _rel(p, F.avg_pool2d(a64, 2, 2)), 1e-2)
+        wd = w16.double().reshape(Co, C)
+        y64 = _rows(p).double() @ wd.t()
+        yr = _rows(yv)
+        note("transition y", _rel(yr, y64), 1e-2)
+        yd = yr.double()
+        ym, yvv = yd.mean(0), yd.var(0, unbiased=False)
+        note("transition stats mean", float(((nst.mean[:Co].double() - ym).abs() / (yvv.sqrt() + 1e-12)).max()), 1e-4)
+        note("transition stats rstd", _rel(nst.rstd[:Co], 1.0 / torch.sqrt(yvv + c["eps_next"])), 1e-4)
+        # backward from the gradient the kernels read (the [:Co] slice of the next block's gradient buffer)
+        dy = _rows(c["dy"]).double()
+        note("transition dp", _rel(_rows(c["dp"]), dy @ wd), 1e-2)
+        note("transition dW", _rel(w.grad.reshape(Co, C), dy.t() @ _rows(p).double()), 5e-3)
+        da = F.interpolate(c["dp"].double(), scale_factor=2, mode="nearest") / 4.0          # AvgPool2d(2, 2) backward
+        if da.shape[2] != H or da.shape[3] != W:
+            da = F.pad(da, (0, W - da.shape[3], 0, H - da.shape[2]))
+        g1 = da * (a64 > 0)
+        db, dg = g1.sum((0, 2, 3)), (g1 * xhat).sum((0, 2, 3))
+        note("transition dbeta", _rel(beta.grad, db), 5e-3)
+        note("transition dgamma", _rel(gamma.grad, dg), 5e-3)
+        dx64 = (gamma.detach().double().view(1, -1, 1, 1) * rstd) * (g1 - (db / S).view(1, -1, 1, 1) - xhat * (dg / S).view(1, -1, 1, 1))
+        note("transition dx", _rel(c["dx"], dx64), 2e-2)
+        print(f"transition{ti + 1} ({H}x{W}, {C} -> {Co}): p {_rel(p, F.avg_pool2d(a64, 2, 2)):.2e}  y {_rel(yr, y64):.2e}  "
+              f"dp {_rel(_rows(c['dp']), dy @ wd):.2e}  dx {_rel(c['dx'], dx64):.2e}  dW {_rel(w.grad.reshape(Co, C), dy.t() @ _rows(p).double()):.2e}")
+        del x64, xhat, a64, da, g1, dx64
+
+    # ------------------------------------------------------------------------------------------------ stem
+    c0 = next(c for c in misc if c["kind"] == "conv0")
+    x0, w0 = c0["x"].double(), c0["w16"].double()
+    y0_64 = F.conv2d(x0, w0, stride=2, padding=3)
+    note("conv0 y", _rel(c0["y"], y0_64), 1e-2)
+    y0 = _rows(c0["y"]).double()
+    m0, v0 = y0.mean(0), y0.var(0, unbiased=False)
+    note("conv0 stats mean", float(((c0["stats"][0].double() - m0).abs() / (v0.sqrt() + 1e-12)).max()), 1e-4)
+    note("conv0 stats rstd", _rel(c0["stats"][2], 1.0 / torch.sqrt(v0 + feats.norm0.eps)), 1e-4)
+    dw0 = torch.nn.grad.conv2d_weight(x0, w0.shape, c0["dy"].double(), stride=2, padding=3)
+    note("conv0 dW", _rel(c0["w"].grad, dw0), 5e-3)
+    del y0_64, x0
+    ct = next(c for c in misc if c["kind"] == "stem_tail")
+    gam0, bet0 = ct["params"]
+    xs = ct["x"].double().requires_grad_(True)
+    gr, br = gam0.detach().double().requires_grad_(True), bet0.detach().double().requires_grad_(True)
+    # (the kernel's statistics ARE the fp64 statistics to 1e-7: autograd of train-mode batch_norm is the reference)
+    pooled = F.max_pool2d(torch.relu(F.batch_norm(xs, None, None, gr, br, True, 0.0, feats.norm0.eps)), 3, 2, 1)
+    note("stem pool y", _rel(ct["y"], pooled.detach()), 1e-2)
+    pooled.backward(ct["dy"].double())
+    # max-pool ties (ReLU zeros) and near-ties route a gradient to a neighbouring pixel: bound the 99.9 % quantile
+    note("stem dx (q99.9)", _q(ct["dx"], xs.grad), 2e-2)
+    # (norm0's weight has an exactly zero true gradient -- every consumer of a pooled channel normalises it again -- so its
+    # teacher-forced value is a cancellation residue: bounded against the scale of dbeta0, a sum of the same terms)
+    note("stem dbeta0", float((bet0.grad.double() - br.grad).abs().max() / (br.grad.abs().max() + 1e-30)), 2e-2)
+    note("stem dgamma0 (vs max|dbeta0|)", float((gam0.grad.double() - gr.grad).abs().max() / (br.grad.abs().max() + 1e-30)), 2e-2)
+    print(f"stem: conv0 y {worst['conv0 y']:.2e}  dW0 {worst['conv0 dW']:.2e}  pool y {worst['stem pool y']:.2e}  "
+          f"dx q99.9 {worst['stem dx (q99.9)']:.2e}")
+    del xs, pooled
+
+    # ------------------------------------------------------------------------------------------------ norm5 + global pool
+    c5 = next(c for c in misc if c["kind"] == "norm5_pool")
+    g5, b5 = c5["params"]
+    x5 = c5["x"].double()
+    Bn, C, H, W = x5.shape
+    S = Bn * H * W
+    mean, rstd = c5["mean"].double().view(1, -1, 1, 1), c5["rstd"].double().view(1, -1, 1, 1)
+    xhat = (x5 - mean) * rstd
+    out64 = (xhat * g5.detach().double().view(1, -1, 1, 1) + b5.detach().double().view(1, -1, 1, 1)).mean((2, 3))
+    note("norm5+pool out", _rel(c5["out"], out64), 1e-5)
+    dyv = (c5["g"].double() / (H * W)).view(Bn, C, 1, 1).expand(Bn, C, H, W)
+    db, dg = dyv.sum((0, 2, 3)), (dyv * xhat).sum((0, 2, 3))
+    note("norm5 dbeta", _rel(b5.grad, db), 1e-4)
+    note("norm5 dgamma", _rel(g5.grad, dg), 1e-4)
+    dx64 = (g5.detach().double().view(1, -1, 1, 1) * rstd) * (dyv - (db / S).view(1, -1, 1, 1) - xhat * (dg / S).view(1, -1, 1, 1))
+    note("norm5+pool dx", _rel(c5["dx"], dx64), 1e-2)
+    print(f"norm5 + global pool: out {worst['norm5+pool out']:.2e}  dx {worst['norm5+pool dx']:.2e}")
+    print("worst over all 58 layers / 3 transitions / stem / tail:", {k: f"{v:.2e}" for k, v in worst.items()})

@@ -1,0 +1,200 @@
+"""The benched training step runs on this library's kernels only: the kernel list comes from the GPU's
+own activity records (torch.profiler), not from ``densenet_fused.fallback_counts()``.  Plus the kernels that replaced the
+last library pieces (csrc/step_misc.hip, the Adam shadow write, the one-launch InfoNCE scalar), each against torch."""
+import pytest
+import torch
+
+from helpers import assert_close, assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g)
+
+
+def _step_model(B=16, G=171, HW=64, infonce="fused"):
+    from mclstexp_amd import synth
+    from mclstexp_amd.model import mclSTExp_Attention
+    from mclstexp_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    model = mclSTExp_Attention("densenet121", 1.0, 1024, G, 256, 8, 64, 2, backbone_dtype=torch.bfloat16,
+                               embedding_grad="rowsparse", infonce=infonce).to(DEV)
+    model.to(memory_format=torch.channels_last).train()
+    opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(model)
+    b = {k: v.to(DEV) for k, v in synth.make_batch(B, G, image_hw=HW, seed=0).items()}
+    return model, opt, b
+
+
+@pytest.mark.parametrize("mode", ["reference_loop", "captured_sequence"])
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
+def test_step_launches_only_own_kernels(mode, layout):
+    """Every GPU kernel of a steady-state training step (forward, InfoNCE, backward, Adam incl. the position tables) is
+    one of csrc/*.hip's: no hipBLASLt / Tensile ``Cijk_*``, no ``at::native::*``, no MIOpen.  ``reference_loop`` =
+    train.py:36-39's order through autograd (model(batch); zero_grad; backward; step); ``captured_sequence`` = exactly the
+    calls engine.TrainStep records into its single step graph (``TrainStep._sequence`` + step), issued eagerly because the
+    kernels of a replayed graph are not individually visible to the profiler here."""
+    from mclstexp_amd import densenet_fused as dn, kernel_audit
+    from mclstexp_amd.engine import TrainStep
+    model, opt, b = _step_model()
+    if layout == "channels_last":
+        b["image"] = b["image"].contiguous(memory_format=torch.channels_last)
+    tr = TrainStep(model, opt, None, graphs=False)
+    fn = (lambda: tr(b)) if mode == "reference_loop" else (lambda: tr.run_sequence_eager(b))
+    for _ in range(4):
+        fn()
+    dn.reset_fallbacks()
+    ks = kernel_audit.step_kernels(fn)
+    assert sum(ks.values()) > 300, f"the profiler recorded only {sum(ks.values())} kernels: {sorted(ks)[:5]}"
+    assert any("conv1x1_fwd_kernel" in n for n in ks), "the backbone's own kernels are missing from the record"
+    bad = kernel_audit.foreign(ks)
+    assert not bad, "library kernels inside the step:\n" + "\n".join(f"{ks[n]:4d} x {n[:160]}" for n in bad)
+    assert dn.fallback_counts() == {}
+
+
+def test_graph_replay_equals_eager_sequence():
+    """The replayed step graph and the eager issue of the same sequence produce bit-identical parameters (so the audit of
+    the eager sequence speaks for the graph)."""
+    import copy
+    from mclstexp_amd.engine import TrainStep
+    from mclstexp_amd.optim import FusedAdam
+    model, opt, b = _step_model(B=8, HW=32)
+    model2 = copy.deepcopy(model)
+    opt2 = FusedAdam(model2.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(model2)
+    tg = TrainStep(model, opt, None, graphs=True, warmup=2)
+    te = TrainStep(model2, opt2, None, graphs=False)
+    for i in range(5):
+        lg = tg(b)
+        le = te(b) if i < 2 else te.run_sequence_eager(b)      # (the graph's first two calls are eager reference-loop steps)
+    torch.cuda.synchronize()
+    assert float(lg) == float(le)
+    for (n, p), (_, q) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+@pytest.mark.parametrize("B,H,W,C", [(4, 7, 7, 1024), (3, 3, 3, 64), (2, 8, 8, 520), (5, 1, 1, 8)])
+def test_bn_gap_fwd_bwd_vs_torch(B, H, W, C):
+    """norm5 -> adaptive_avg_pool2d -> flatten (model.py:81-85) and its train-mode backward against fp64 autograd."""
+    from mclstexp_amd import densenet_fused as dn
+    x = ((_rand(B, H, W, C, seed=1) * 3 - 1) + torch.arange(C) * 0.01).bfloat16()
+    xd = x.to(DEV).permute(0, 3, 1, 2)
+    gamma = (1 + 0.3 * _rand(C, seed=2)).to(DEV).requires_grad_(True)
+    beta = (0.2 * _rand(C, seed=3) - 0.1).to(DEV).requires_grad_(True)
+    mean, var, rstd = (torch.empty(C, device=DEV) for _ in range(3))
+    dn.bn_stats(xd, mean, var, rstd, 1e-5)
+    xin = xd.detach().clone(memory_format=torch.channels_last).requires_grad_(True)
+    out = dn.BNGlobalPoolFn.apply(xin, gamma, beta, mean, rstd)
+    g = (_rand(B, C, seed=4) - 0.5).to(DEV)
+    out.backward(g)
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr, br = gamma.detach().double().cpu().requires_grad_(True), beta.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    outr = torch.nn.functional.adaptive_avg_pool2d(yr, (1, 1)).flatten(1)
+    outr.backward(g.double().cpu())
+    assert_close(out.detach().cpu().double(), outr.detach(), 2e-5, 2e-5, what="pooled features")
+    assert_close_scaled(gamma.grad.cpu().double(), gr.grad, 2e-4, what="dgamma")
+    assert_close_scaled(beta.grad.cpu().double(), br.grad, 2e-4, what="dbeta")
+    if B * H * W > 1:
+        assert_close_scaled(xin.grad.float().cpu().double(), xr.grad, 1.2e-2, floor=1e-7, what="dx (bf16)")
+    # direct accumulation into existing .grad tensors (the FusedAdam bucket): += semantics
+    before = gamma.grad.clone()
+    xin2 = xd.detach().clone(memory_format=torch.channels_last).requires_grad_(True)
+    dn.BNGlobalPoolFn.apply(xin2, gamma, beta, mean, rstd).backward(g)
+    assert_close_scaled(gamma.grad.cpu(), 2 * before.cpu(), 1e-6, what="dgamma accumulated")
+
+
+def test_bn_running_update_matches_batchnorm_module():
+    """mcl_bn_running_update == what nn.BatchNorm2d.forward does to running_mean / running_var / num_batches_tracked, for
+    more layers than one launch holds (121 in DenseNet-121; 64 per launch)."""
+    from mclstexp_amd import densenet_fused as dn
+    rec = dn._RunningStats()
+    mods, refs, xs = [], [], []
+    for i in range(70):
+        C = 8 * (1 + i % 9)
+        bn = torch.nn.BatchNorm2d(C, momentum=(0.1 if i % 3 else 0.3)).to(DEV).train()
+        ref = torch.nn.BatchNorm2d(C, momentum=bn.momentum).to(DEV).train()
+        with torch.no_grad():
+            bn.running_mean.copy_(_rand(C, seed=i)); ref.running_mean.copy_(bn.running_mean)
+            bn.running_var.copy_(_rand(C, seed=100 + i) + 0.5); ref.running_var.copy_(bn.running_var)
+        x = (_rand(3, C, 5, 4, seed=200 + i) * 2 - 0.7).to(DEV)
+        mods.append(bn); refs.append(ref); xs.append(x)
+        mean = x.mean(dim=(0, 2, 3)).contiguous()
+        var = x.var(dim=(0, 2, 3), unbiased=False).contiguous()
+        rec.add(bn, mean, var, x.numel() // C)
+    rec.flush()
+    for bn, ref, x in zip(mods, refs, xs):
+        ref(x)
+        assert_close(bn.running_mean.cpu(), ref.running_mean.cpu(), 1e-6, 1e-6, what="running_mean")
+        assert_close(bn.running_var.cpu(), ref.running_var.cpu(), 1e-6, 1e-6, what="running_var")
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 16, 24), (1, 3, 7, 5), (3, 4, 8, 8)])
+def test_image_to_bf16_nhwc(shape):
+    """Bit-identical to ``x.to(bfloat16).contiguous(channels_last)`` for NCHW, channels-last and sliced inputs."""
+    from mclstexp_amd import densenet_fused as dn
+    x = (_rand(*shape, seed=5) * 2 - 1).to(DEV)
+    big = (_rand(shape[0], shape[1], shape[2] + 3, shape[3] + 2, seed=6)).to(DEV)
+    for inp in (x, x.contiguous(memory_format=torch.channels_last), big[:, :, 1:1 + shape[2], 2:2 + shape[3]]):
+        got = dn.image_to_act(inp, torch.bfloat16)
+        want = inp.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        assert got.is_contiguous(memory_format=torch.channels_last) and got.dtype == torch.bfloat16
+        assert torch.equal(got, want)
+
+
+def test_adam_shadow_equals_cast_of_updated_params():
+    """mcl_adam_step_dev_shadow: same parameter update bit for bit as mcl_adam_step_dev, shadow == bf16(p)."""
+    from mclstexp_amd import _lib
+    L = _lib.lib()
+    n = 4 * 1000 + 4
+    st = torch.cuda.current_stream().cuda_stream
+    p0 = (_rand(n, seed=1) - 0.5).to(DEV)
+    g = (_rand(n, seed=2) - 0.5).to(DEV)
+    m0, v0 = (0.1 * _rand(n, seed=3)).to(DEV), (0.01 * _rand(n, seed=4)).to(DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    consts = torch.zeros(8, device=DEV)
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1e-3], dtype=torch.float64, device=DEV)
+    _lib.check(L.mcl_adam_consts_update(step.data_ptr(), consts.data_ptr(), hyper.data_ptr(), st))
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.mcl_adam_step_dev(pa.data_ptr(), g.data_ptr(), ma.data_ptr(), va.data_ptr(), n, consts.data_ptr(), st))
+    _lib.check(L.mcl_adam_step_dev_shadow(pb.data_ptr(), g.data_ptr(), mb.data_ptr(), vb.data_ptr(), n, consts.data_ptr(),
+                                          sh.data_ptr(), st))
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert torch.equal(sh, pb.to(torch.bfloat16))
+
+
+def test_fused_adam_shadow_tracks_parameters_over_steps():
+    """After every FusedAdam.step() the bf16 shadow views the backbone kernels read equal bf16(parameter) -- now written by
+    the Adam kernel itself -- and zero_grad() (mcl_fill_zero) leaves an all-zero bucket."""
+    model, opt, b = _step_model(B=4, G=171, HW=32)
+    for _ in range(3):
+        loss = model(b)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    w = model.image_encoder.model[0].denseblock2.denselayer3.conv1.weight
+    v = opt.shadow(w, torch.bfloat16)
+    assert v is not None and torch.equal(v, w.detach().to(torch.bfloat16))
+    opt.zero_grad()
+    for g in opt.flat_grads():
+        assert int(torch.count_nonzero(g)) == 0
+
+
+def test_infonce_loss_mean_matches_two_sum_form():
+    from mclstexp_amd import _lib
+    L = _lib.lib()
+    B = 130
+    st = torch.cuda.current_stream().cuda_stream
+    S = (_rand(B, B, seed=7) * 8 - 4).to(DEV)
+    rl, cl = torch.logsumexp(S, 1).contiguous(), torch.logsumexp(S, 0).contiguous()
+    sums = torch.zeros(2, device=DEV)
+    _lib.check(L.mcl_infonce_loss(S.data_ptr(), B, rl.data_ptr(), cl.data_ptr(), 0, 0, B, 1, 1, sums.data_ptr(), st))
+    out = torch.empty((), device=DEV)
+    _lib.check(L.mcl_infonce_loss_mean(S.data_ptr(), B, rl.data_ptr(), cl.data_ptr(), B, 2.0 * B, out.data_ptr(), st))
+    assert float(out) == float((sums[0] + sums[1]) / (2.0 * B))
+    ref = 0.5 * ((rl - S.diag()).double().mean() + (cl - S.diag()).double().mean())
+    assert abs(float(out) - float(ref)) < 1e-5
