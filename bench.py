@@ -386,6 +386,7 @@ def main():
                        "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
                        "dp_semantics": "spot-encoder attention and BatchNorm statistics are per shard (per GPU); "
                                        "InfoNCE is global over the all-gathered embeddings",
+                       "dp_backward_segments": (len(trainer.seg_graphs) + 1 if (dist_on and trainer.seg_graphs) else None),
                        "fallbacks": densenet_fused.fallback_counts(),
                        "step_kernel_audit": foreign_kernels,
                        "final_loss": round(final_loss, 4),

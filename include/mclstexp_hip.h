@@ -457,6 +457,34 @@ int mcl_fill_zero(void* p, int64_t bytes, mcl_stream_t stream);
 int mcl_scale2_f32(const float* a, int64_t na, const float* b, int64_t nb, const float* s, float* ya, float* yb,
                    mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- generic convolution lowering + pooling, fp32 AND bf16
+ * (csrc/im2col.hip, csrc/pool_generic.hip; dtype 0 = fp32, 1 = bf16).  For the shapes the specialised DenseNet kernels do not
+ * cover: fp32 activations (the reference-numerics mode of the backbone, /root/reference/model.py:72-85) and the ResNet
+ * encoders (/root/reference/model.py:88-148).  A convolution is im2col + this library's GEMM (mcl_gemm / mcl_gemm_bf16):
+ *   mcl_im2col_nhwc: cols[(n,oy,ox)][(ky,kx,c)] = x[n][oy*stride-pad+ky][ox*stride-pad+kx][c] (0 outside); x rows of stride
+ *     ldx (a channel slice is read in place); cols (N*OH*OW, KH*KW*C) contiguous; the column order is the storage order of a
+ *     channels-last weight (C_out, kh, kw, C_in).
+ *   mcl_col2im_nhwc: the transpose (backward-data): dx[n][y][x][c] (+)= the sum of the columns that reference the pixel, as a
+ *     gather in fixed tap order (deterministic); dx rows of stride lddx.
+ *   mcl_maxpool3s2_nhwc_{fwd,bwd}_any: MaxPool2d(3, 2, 1) with ATen's first-maximum tie rule, idx = one byte per element.
+ *   mcl_avgpool2_nhwc_any: AvgPool2d(2, 2) (floor on odd maps) forward / backward.
+ *   mcl_gap_nhwc_{fwd,bwd}: adaptive_avg_pool2d((1,1)) + flatten -> (B, C) fp32, and its backward g/HW broadcast.
+ *   mcl_add_relu: y = relu(a + b) (backward != 0: y = a * [b > 0] with a = dy, b = the forward output).                 */
+int mcl_im2col_nhwc(const void* x, int64_t ldx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW,
+                    int32_t stride, int32_t pad, int32_t dtype, void* cols, mcl_stream_t stream);
+int mcl_col2im_nhwc(const void* dcols, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH, int32_t KW, int32_t stride,
+                    int32_t pad, int32_t dtype, void* dx, int64_t lddx, int32_t accumulate, mcl_stream_t stream);
+int mcl_maxpool3s2_nhwc_fwd_any(const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                mcl_stream_t stream);
+int mcl_maxpool3s2_nhwc_bwd_any(const void* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t dtype, mcl_stream_t stream);
+int mcl_avgpool2_nhwc_any(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t backward, int32_t dtype,
+                          mcl_stream_t stream);
+int mcl_gap_nhwc_fwd(const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t C, int32_t dtype, float* out,
+                     mcl_stream_t stream);
+int mcl_gap_nhwc_bwd(const float* g, int32_t B, int32_t HW, int32_t C, int32_t dtype, void* dx, mcl_stream_t stream);
+int mcl_add_relu(const void* a, const void* b, void* y, int64_t n, int32_t backward, int32_t dtype, mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;

@@ -79,6 +79,14 @@ PROTOTYPES = {
     "mcl_bn_running_update": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_image_to_bf16_nhwc": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_fill_zero": [c_p, c_l, c_p],
+    "mcl_im2col_nhwc": [c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_col2im_nhwc": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p],
+    "mcl_maxpool3s2_nhwc_fwd_any": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "mcl_maxpool3s2_nhwc_bwd_any": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "mcl_avgpool2_nhwc_any": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "mcl_gap_nhwc_fwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_gap_nhwc_bwd": [c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_add_relu": [c_p, c_p, c_p, c_l, c_i, c_i, c_p],
     "mcl_scale2_f32": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p],
     "mcl_maxpool3s2_nhwc_bf16_bwd_ld": [c_p, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_gemm_bf16_workspace_floats": [c_i, c_l, c_i],

@@ -179,9 +179,9 @@ class ImageEncoder(_PooledSequential):
     def __init__(self):
         super().__init__([densenet121_features_module()])
 
-    def forward_fused(self, x, act_dtype=torch.bfloat16):
+    def forward_fused(self, x, act_dtype=torch.bfloat16, cuts=None, cut_blocks=()):
         from .densenet_fused import densenet_features_fused
-        return densenet_features_fused(self.model[0], x, act_dtype, pooled=True)
+        return densenet_features_fused(self.model[0], x, act_dtype, pooled=True, cuts=cuts, cut_blocks=cut_blocks)
 
     def forward_eval_fused(self, x, act_dtype=torch.bfloat16):
         """Eval-mode (running statistics) forward on the fused kernels: the inference path of evel_her2st.py:50."""

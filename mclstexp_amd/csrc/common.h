@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/mclstexp_hip.h"
 
 #define MCL_WAVE 64
@@ -17,6 +18,36 @@
   } while (0)
 
 static inline hipStream_t mcl_stream(mcl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// One-time PER-DEVICE setup (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device attribute: a process-wide flag
+// would leave a second GPU of the same process without it), safe against the autograd worker thread racing the main thread.
+#include <atomic>
+struct mcl_device_once {
+  std::atomic<unsigned long long> done{0};
+  struct guard {
+    mcl_device_once* o;
+    unsigned long long bit;
+    bool need;
+    explicit operator bool() const { return need; }
+    ~guard() {
+      if (need) o->done.fetch_or(bit, std::memory_order_release);    // set AFTER the guarded block has run
+    }
+  };
+  // usage: if (auto g = flag.first()) { ...hipFuncSetAttribute... }   -- two racing threads may both run the (idempotent)
+  // block; none launches before the attribute of its device is set
+  guard first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    return guard{this, bit, !(done.load(std::memory_order_acquire) & bit)};
+  }
+};
+// environment overrides of grid sizes: never below 1 (atoi of garbage / "0" / a negative value would launch a zero-size grid)
+static inline int mcl_env_grid(const char* value, int dflt) {
+  if (!value) return dflt;
+  const int v = atoi(value);
+  return v < 1 ? 1 : v;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

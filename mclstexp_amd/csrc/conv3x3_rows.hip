@@ -487,11 +487,10 @@ int mcl_launch_conv3x3_fwd_rows(const void* z, long long S, int H, int W, const 
                                 float* workspace, float eps, float* ymean, float* yvar, float* yrstd, hipStream_t st) {
   const RowsPlan p = rows_plan(S, H, W);
   const size_t lds_bytes = WF_BYTES + NWAVE * SLAB_BYTES + CI * 8 + NWAVE * 32 * SROW;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_fwd_rows_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
   }
   float2* part = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(conv3x3_fwd_rows_kernel, dim3(p.grid), dim3(64 * NWAVE), lds_bytes, st, (const bf16_t*)z, p.nimg, H, W,

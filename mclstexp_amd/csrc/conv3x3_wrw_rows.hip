@@ -238,7 +238,7 @@ inline WrwRowsPlan wrw_rows_plan(long long S, int H, int W) {
   // critical chain's kernels off the CUs (bench.py: 12.93-12.97 ms/step at 256 workgroups, 12.78-12.84 at 128-160, 12.84-12.90
   // with the kernel-row form although this kernel alone is twice as fast; MCL_WRW_ROWS_GRID for A/B runs)
   static const char* e_g = getenv("MCL_WRW_ROWS_GRID");
-  const int gcap = e_g ? atoi(e_g) : 160;
+  const int gcap = mcl_env_grid(e_g, 160);
   long long rc = ((long long)H * p.nimg + 511) / 512;
   if (rc < 1) rc = 1;
   if (rc > H) rc = H;

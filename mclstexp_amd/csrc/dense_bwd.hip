@@ -909,7 +909,7 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   // in the step, 13.84-13.95 either way; MCL_MAIN_GRID_SMALL)
   static const char* e_gx = getenv("MCL_MAIN_GRID");
   static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
+  const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
@@ -949,7 +949,7 @@ extern "C" int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, 
   hipStream_t st = mcl_stream(stream);
   static const char* e_gx = getenv("MCL_MAIN_GRID");
   static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
+  const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<2, 64>), dim3(gx, nct), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,
@@ -992,7 +992,7 @@ extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const
   const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
   static const char* e_gx = getenv("MCL_MAIN_GRID");
   static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
+  const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<1, 64>), dim3(gx, nct), dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
@@ -1034,11 +1034,10 @@ int conv3x3_bwd_impl(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t
   if (bwd_rows_applicable(S, H, W)) {                 // the large maps: thin row-walking waves
     const BwdRowsPlan p = bwd_rows_plan(S, H, W);
     coef = workspace + (int64_t)p.nsu * 2 * C3I;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static mcl_device_once attr_once;
+    if (auto attr_guard = attr_once.first()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bwd_rows_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
     }
     hipLaunchKernelGGL(conv3x3_bwd_rows_kernel, dim3(p.grid), dim3(64 * BR_NWAVE), (size_t)BR_NWAVE * BR_RING + 1024, st,
                        (const bf16_t*)dy, (long long)lddy, p.nimg, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta,
@@ -1051,7 +1050,7 @@ int conv3x3_bwd_impl(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t
     const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
     static const char* e_gx = getenv("MCL_MAIN_GRID");
     static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-    const int gcap = S >= 50000 ? (e_gx ? atoi(e_gx) : 512) : (e_gs ? atoi(e_gs) : 768);
+    const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
     hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
                        (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
                        (bf16_t*)g2, part, ntile, (const bf16_t*)xfix, (long long)ldxf, fmean, frstd, fk, (bf16_t*)dyc);

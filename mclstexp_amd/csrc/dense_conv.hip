@@ -651,11 +651,10 @@ extern "C" int mcl_dense_conv3x3_fwd(const void* z, int64_t S, int32_t H, int32_
   size_t lds_bytes = (size_t)(T3 + 2 * W + 2) * 256 + 256;
   if (lds_bytes < 4 * T3 * C3_OUT * 4) lds_bytes = 4 * T3 * C3_OUT * 4;
   hipStream_t st = mcl_stream(stream);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_fwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-    attr_set = true;
   }
   float2* part = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(ntile < 512 ? ntile : 512), dim3(256), lds_bytes, st, (const bf16_t*)z, (long long)S, H, W,
@@ -855,7 +854,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __
 // pixel groups (= partials) of the kernel-row form: three workgroups each, two workgroups per CU
 static inline int wrw3k_groups(int ntile) {
   static const char* e = getenv("MCL_W3K_GROUPS");             // 88 x 3 workgroups: 14.08 ms/step at 176, 13.99 at 88 (32-88 alike)
-  const int g = e ? atoi(e) : 88;
+  const int g = mcl_env_grid(e, 88);
   return ntile < g ? ntile : g;
 }
 
@@ -1154,11 +1153,10 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
   const int ntile = N * (OH / 2);
   const int PW = (W + 6) * 3 + 8;
   const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + 256 * 128 + 4 * 64 * 2 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_fwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
   }
   hipStream_t st = mcl_stream(stream);
   float2* part = reinterpret_cast<float2*>(workspace);
@@ -1180,7 +1178,7 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
 // single workgroup per CU -- the former grid of 256 -- overlaps none of them.  MCL_C0W_GRID for A/B.
 inline int conv0_wrw_grid(int ntile) {
   static const char* e = getenv("MCL_C0W_GRID");
-  const int cap = e ? atoi(e) : 768;
+  const int cap = mcl_env_grid(e, 768);
   return ntile < cap ? ntile : cap;
 }
 extern "C" int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W) {
@@ -1199,11 +1197,10 @@ extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, con
   const int ntile = N * (OH / 2);
   const int PW = (W + 6) * 3 + 8;
   const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + (size_t)C0_OUT * (2 * OWp + 8) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wrw_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
   }
   hipStream_t st = mcl_stream(stream);
   const int grid = conv0_wrw_grid(ntile);

@@ -396,14 +396,13 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   const int per_batch = (g.tm >= 8 ? ((g.tm + 7) / 8) * 8 : g.tm) * g.tn * g.ksplit;
   const dim3 grid((unsigned)(per_batch * batch));
   const size_t lds_bytes = (size_t)4 * subs * SUB_B;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
 #define MCL_ATTR(AK, BKM, SB) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<AK, BKM, SB>), \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * SB * SUB_B)
     MCL_ATTR(false, false, 1); MCL_ATTR(false, true, 1); MCL_ATTR(true, false, 1); MCL_ATTR(true, true, 1);
     MCL_ATTR(false, false, 2); MCL_ATTR(false, true, 2); MCL_ATTR(true, false, 2); MCL_ATTR(true, true, 2);
 #undef MCL_ATTR
-    attr_set = true;
   }
 #define MCL_LAUNCH(AK, BKM)                                                                                          \
   do {                                                                                                               \

@@ -286,11 +286,10 @@ extern "C" int mcl_infonce_fp8_lse(const void* a8, int64_t lda, const void* scal
   if (ws_bytes < (int64_t)p.nsplit * R * (int64_t)sizeof(float2)) return MCL_EWORKSPACE;
   hipStream_t st = mcl_stream(stream);
   constexpr size_t lds_bytes = 2 * TC * P + 2 * TC * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fp8_lse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
-    attr_set = true;
   }
   hipLaunchKernelGGL(fp8_lse_kernel, dim3(p.rt * p.nsplit), dim3(256), lds_bytes, st, (const unsigned char*)a8, (long long)lda,
                      (const unsigned char*)scale_a, (long long)ld_sa, (const unsigned char*)b8, (long long)ldb,

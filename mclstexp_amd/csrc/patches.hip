@@ -234,11 +234,10 @@ extern "C" int mcl_her2st_train_patches(const void* image_u8, int32_t Hs, int32_
   const size_t lds_bytes = ((size_t)4 * r * r * 3 + 15) & ~(size_t)15;
   if (lds_bytes > 160 * 1024 - 256) return MCL_EUNSUPPORTED;
   MCL_CLEAR_ERROR();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static mcl_device_once attr_once;
+  if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(her2st_train_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    attr_set = true;
   }
   hipLaunchKernelGGL(her2st_train_kernel, dim3(N), dim3(1024), lds_bytes, mcl_stream(stream),
                      (const unsigned char*)image_u8, Hs, Ws, centers_rc, r, (const AugParams*)params, divisor,

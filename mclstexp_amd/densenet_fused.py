@@ -15,9 +15,10 @@ kernels.  Here:
     dx pass that ACCUMULATES in place into the block's gradient buffer, replacing autograd's per-layer
     slice gradients and their add chain;
   * in bf16 every convolution, its data gradient and its weight gradient run on the hand-written kernels of
-    csrc/dense_conv.hip, conv3x3_rows.hip, dense_bwd.hip and wrw_fused.hip (a bf16 tensor reaching a library path raises,
-    see ``_fallback``); with fp32 activations (``backbone_dtype=None``, the reference-numerics mode) the convolutions are
-    ``aten.convolution`` / ``aten.convolution_backward`` calls between the same BatchNorm kernels.
+    csrc/dense_conv.hip, conv3x3_rows.hip, dense_bwd.hip and wrw_fused.hip; with fp32 activations (``backbone_dtype=None``,
+    the reference-numerics mode) and for any shape the specialised kernels do not cover, a convolution is im2col + this
+    library's own GEMM (conv_generic.py: exact fp32 MFMA for fp32 activations) between the same BatchNorm kernels, and the
+    pools are csrc/pool_generic.hip -- no MIOpen / ATen convolution or pooling call exists in this file (round 4).
 
 Train-mode semantics of nn.BatchNorm2d are kept: batch statistics, running_mean / running_var (unbiased)
 / num_batches_tracked updates with momentum 0.1 (batched with torch._foreach ops at the end of forward).
@@ -38,23 +39,10 @@ Tensor = torch.Tensor
 CL = torch.channels_last
 _ws_cache = {}
 
-# Every place where this file leaves the hand-written kernels for a library path (MIOpen through aten.convolution*,
-# ATen pooling) counts itself here: a shape regression that silently puts MIOpen back on the hot path shows up in
-# ``fallback_counts()`` (asserted empty by the bf16 tests, printed in bench.py's JSON line).
+# Round 1-3 counted here every place where this file left the hand-written kernels for a library path (MIOpen through
+# aten.convolution*, ATen pooling).  No such place remains: shapes outside the specialised kernels run on the generic
+# im2col + own-GEMM path (conv_generic.py).  The counter API stays for its callers (tests, bench.py's JSON line): always empty.
 _fallbacks: dict = {}
-
-
-ALLOW_LIBRARY_FALLBACK = os.environ.get("MCL_ALLOW_LIBRARY_FALLBACK", "0") == "1"
-
-
-def _fallback(site: str, t: Optional[Tensor] = None) -> None:
-    """A bf16 tensor reaching a library path means a shape / layout the hand-written kernels do not cover: that is an error
-    (a drop-in that silently changes backend is a dual path), unless MCL_ALLOW_LIBRARY_FALLBACK=1.  fp32 activations
-    (``backbone_dtype=None``: the reference-numerics mode) run their convolutions on the library by design."""
-    if t is not None and t.dtype == torch.bfloat16 and not ALLOW_LIBRARY_FALLBACK:
-        raise RuntimeError(f"densenet_fused: '{site}' would leave the HIP kernels for a library call on the bf16 path "
-                           f"(tensor {tuple(t.shape)}); set MCL_ALLOW_LIBRARY_FALLBACK=1 to permit it")
-    _fallbacks[site] = _fallbacks.get(site, 0) + 1
 
 
 def fallback_counts() -> dict:
@@ -124,17 +112,42 @@ def bn_act_fwd(x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tenso
                                     rstd.data_ptr(), int(relu), po, ldo, _stream()), "mcl_bn_act_fwd")
 
 
-def _direct_grad_ok(p: Tensor) -> bool:
-    """True when the backward kernels may add this parameter's gradient straight into ``p.grad``.  A parameter whose
-    .grad is None -- the state torch.optim.*.zero_grad() (set_to_none) leaves behind, /root/reference/train.py:37 -- gets a
-    zero-filled dense fp32 .grad here, so the reference's own ``Adam`` + ``zero_grad()`` + ``backward()`` loop stays on the
-    HIP weight-gradient kernels (they accumulate; nothing is handed back to autograd)."""
+def _has_grad_hooks(p: Tensor) -> bool:
+    """Tensor hooks / post-accumulate-grad hooks registered on a parameter: they fire from autograd's AccumulateGrad node, which
+    a gradient added straight into ``.grad`` by a kernel never reaches -- such a parameter takes the autograd hand-over."""
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
+def _direct_grad_possible(p: Tensor) -> bool:
+    """PURE predicate: may the backward kernels add this parameter's gradient straight into ``p.grad``?  True when it owns a
+    dense fp32 .grad of its own layout (FusedAdam's flat bucket) -- or when it could be given one (``_ensure_dense_grad``)."""
+    if _has_grad_hooks(p):
+        return False
     g = getattr(p, "grad", None)
-    if (g is None and DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_cuda
-            and p.dtype == torch.float32):
-        p.grad = g = torch.zeros_like(p)              # preserve_format: same strides as the parameter
-    return (g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape
-            and g.stride() == p.stride() and not g.requires_grad)
+    if g is None:
+        return (DIRECT_PARAM_GRADS and isinstance(p, torch.nn.Parameter) and p.requires_grad and p.is_cuda
+                and p.dtype == torch.float32)
+    return (g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape and g.stride() == p.stride()
+            and not g.requires_grad)
+
+
+def _ensure_dense_grad(p: Tensor) -> None:
+    """A parameter whose .grad is None -- the state torch.optim.*.zero_grad() (set_to_none) leaves behind,
+    /root/reference/train.py:37 -- gets a zero-filled dense fp32 .grad, so the reference's own ``Adam`` + ``zero_grad()`` +
+    ``backward()`` loop stays on the HIP weight-gradient kernels (they accumulate; nothing is handed back to autograd)."""
+    if getattr(p, "grad", None) is None:
+        p.grad = torch.zeros_like(p)                  # preserve_format: same strides as the parameter
+
+
+def _direct_grad_ok(p: Tensor) -> bool:
+    """``_direct_grad_possible`` + ``_ensure_dense_grad``: called where a kernel that accumulates into ``p.grad`` is about to
+    be launched.  Consequences of the direct path (documented): the backward returns None for such a parameter,
+    so ``torch.autograd.grad(loss, params)`` is NOT supported for them (use ``.backward()`` and read ``.grad``), and a
+    parameter with tensor / post-accumulate-grad hooks is excluded (its gradient goes through autograd as usual)."""
+    if not _direct_grad_possible(p):
+        return False
+    _ensure_dense_grad(p)
+    return True
 
 
 def bn_act_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor, rstd: Tensor, relu: bool,
@@ -251,9 +264,9 @@ def _as2d(t: Tensor) -> Tensor:
 
 
 def _conv1x1_fwd(a: Tensor, w: Tensor) -> Tensor:
-    """fp32 activations only (library convolution)."""
-    _fallback("conv1x1_fwd:miopen", a)
-    return F.conv2d(a, w).contiguous(memory_format=CL)
+    """1x1 convolution outside the fused kernel's shapes (fp32 activations): the activation IS the GEMM operand."""
+    from . import conv_generic as cg
+    return cg.conv_fwd(a, w, 1, 0)
 
 
 # norm1 + relu1 + conv1 + norm2-statistics of a dense layer as ONE kernel (csrc/dense_conv.hip): the normalised
@@ -529,19 +542,9 @@ def conv1x1_wrw(dz: Tensor, a: Tensor, w_param: Tensor, bn=None) -> Optional[Ten
     return ret
 
 
-def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Optional[Tensor] = None, bn=None):
-    """(da, dw) -- dw is None when it was added straight into ``w_param.grad``.  With ``bn`` the tensor ``a`` is
-    the un-normalised layer input (fused forward) and only the HIP weight-gradient kernel can consume it."""
-    if bn is not None:
-        assert dz.dtype == torch.bfloat16 and w_param is not None
-        # the data gradient needs only dz and w: a transposed convolution IS the backward-data kernel and, unlike
-        # aten.convolution_backward, does not make a contiguous copy of the (channel-sliced) layer input first
-        _fallback("conv1x1_bwd_data:miopen", dz)
-        da = F.conv_transpose2d(dz, w)
-        return da.contiguous(memory_format=CL), ("direct", conv1x1_wrw(dz, a, w_param, bn=bn))
-    _fallback("conv1x1_bwd:miopen", dz)                   # fp32 activations: library convolution backward
-    da, dw, _ = _conv_bwd(dz, a, w, 0)
-    return da.contiguous(memory_format=CL), dw
+def _conv1x1_bwd(dz: Tensor, a: Tensor, w: Tensor, w_param: Tensor):
+    """(da, dw) of a 1x1 convolution on the generic path; dw is None when it was added straight into ``w_param.grad``."""
+    return _conv_bwd(dz, a, w, w_param, 0)
 
 
 def _same_order(a: Tensor, b: Tensor) -> bool:
@@ -586,10 +589,14 @@ def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
     return w.to(dtype=dt, memory_format=CL)
 
 
-def _conv_bwd(dy, x, w, padding):
-    _fallback("conv_bwd:miopen", dy)
-    return torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [padding, padding], [1, 1], False, [0, 0], 1,
-                                               [True, True, False])
+def _conv_bwd(dy: Tensor, x: Tensor, w: Tensor, w_param: Tensor, padding: int):
+    """(dx, dw) of a stride-1 convolution on the generic path (conv_generic.py: GEMM + col2im, split-K weight gradient);
+    dw is None when it was accumulated straight into ``w_param.grad``, else an fp32 tensor shaped like the parameter."""
+    from . import conv_generic as cg
+    dy = dy if dy.is_contiguous(memory_format=CL) else dy.contiguous(memory_format=CL)
+    dw = cg.conv_bwd_weight(dy, x, w_param, 1, padding)
+    dx = cg.conv_bwd_data(dy, w, x.shape, 1, padding)
+    return dx, dw
 
 
 # The two weight-gradient kernels of a layer are independent of its data-gradient chain (they only add into .grad):
@@ -648,7 +655,10 @@ class DenseBlockFn(torch.autograd.Function):
     def forward(ctx, x0, meta, *params):
         stats, eps1, eps2, growth, bn2_stats = meta[:5]
         prefilled = len(meta) > 5 and meta[5]       # stats[:C0] already hold x0's statistics (TransitionFn)
-        ctx.first_block = not prefilled             # no transition in front of it: the network's first dense block
+        # no transition in front of it (the network's first dense block), or a backward segment ends with this block (its input
+        # is cut: the segment's gradient range must be final, and under capture every forked stream joined, when its graph
+        # ends): the block joins the weight-gradient side stream at the end of its backward
+        ctx.first_block = (not prefilled) or (len(meta) > 6 and bool(meta[6]))
         L = len(params) // 6
         B, C0, H, W = x0.shape
         Ct = C0 + L * growth
@@ -692,12 +702,11 @@ class DenseBlockFn(torch.autograd.Function):
                 dense_conv3x3_fwd(z, g2, b2, m2, r2, w2c, buf[:, cin:c1], eps1[min(l + 1, L - 1)],
                                   stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1])
             else:
+                from . import conv_generic as cg
                 a2 = torch.empty_like(z, memory_format=CL)
                 bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-                _fallback("conv3x3_fwd:miopen", z)
-                y = F.conv2d(a2, w2c, padding=1).contiguous(memory_format=CL)
-                bn_stats(y, stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)],
-                         copy_out=buf[:, cin:c1])
+                cg.conv_fwd(a2, w2c, 1, 1, out=buf[:, cin:c1])            # written straight into the concat buffer
+                bn_stats(buf[:, cin:c1], stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)])
             saved += [a if a is not None else buf.new_empty(0), z, a2 if a2 is not None else buf.new_empty(0)]
             wcast += [w1c, w2c]
         ctx.save_for_backward(buf, *saved, *wcast)
@@ -833,7 +842,7 @@ class DenseBlockFn(torch.autograd.Function):
                 if a2.numel() == 0:
                     a2 = torch.empty_like(z, memory_format=CL)
                     bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-                da2, dw2, _ = _conv_bwd(dy, a2, w2c, 1)
+                da2, dw2 = _conv_bwd(dy, a2, w2c, w2, 1)
                 dz = torch.empty_like(z, memory_format=CL)
                 dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
                                       into_param_grads=d2)
@@ -848,7 +857,7 @@ class DenseBlockFn(torch.autograd.Function):
                                                 gbuf[:, :cin], w1, into_param_grads=d1)
                     if side is not None:
                         main.wait_stream(side)
-                    grads[6 * l: 6 * l + 6] = [dg1, db1, None, dg2, db2, None if dw2_done else _wgrad(w2, dw2)]
+                    grads[6 * l: 6 * l + 6] = [dg1, db1, None, dg2, db2, None if (dw2_done or dw2 is None) else _wgrad(w2, dw2)]
                     continue
                 if side is not None and dw2_done:
                     side.wait_stream(main)                      # dz is ready
@@ -868,15 +877,11 @@ class DenseBlockFn(torch.autograd.Function):
                 if side is not None:
                     main.wait_stream(side)                      # join: dz / dy may be released or overwritten now
             else:
-                if a.numel() == 0:
-                    da, dw1 = _conv1x1_bwd(dz, buf[:, :cin], w1c, w1,
-                                           bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
-                else:
-                    da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
+                da, dw1 = _conv1x1_bwd(dz, a, w1c, w1)
                 dg1, db1 = bn_act_bwd(da, buf[:, :cin], g1, b1, stats.mean[:cin],
                                       stats.rstd[:cin], True, gbuf[:, :cin], True, into_param_grads=d1)
-            gw1 = dw1[1] if isinstance(dw1, tuple) else _wgrad(w1, dw1)
-            grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None if dw2_done else _wgrad(w2, dw2)]
+            gw1 = dw1[1] if isinstance(dw1, tuple) else (None if dw1 is None else _wgrad(w1, dw1))
+            grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None if (dw2_done or dw2 is None) else _wgrad(w2, dw2)]
         # The tensors the side stream still reads stay parked (referenced) until a join.  Joining after every block makes
         # the main chain wait whenever the side stream runs behind; the small maps can afford to keep their tensors alive
         # (tens of MB) until a later block joins: 14.58 -> 14.28 ms/step on configs[1].  The network's first block is the
@@ -899,8 +904,8 @@ def _bn_train(x: Tensor, bn: nn.BatchNorm2d, relu: bool, rec: _RunningStats) -> 
     return BNActFn.apply(x, bn.weight, bn.bias, mean, rstd, relu)
 
 
-def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats, stats: Optional[_BlockStats] = None
-                ) -> Tuple[Tensor, _BlockStats]:
+def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats, stats: Optional[_BlockStats] = None,
+                force_join: bool = False) -> Tuple[Tensor, _BlockStats]:
     """``stats``: a _BlockStats whose first C0 entries already hold the statistics of ``x`` (produced by the
     transition's convolution epilogue) -- the block then only copies x into its buffer."""
     layers = list(blk.values())
@@ -915,7 +920,7 @@ def dense_block(blk: nn.Module, x: Tensor, rec: _RunningStats, stats: Optional[_
     params = []
     for ly in layers:
         params += [ly.norm1.weight, ly.norm1.bias, ly.conv1.weight, ly.norm2.weight, ly.norm2.bias, ly.conv2.weight]
-    meta = (stats, [ly.norm1.eps for ly in layers], [ly.norm2.eps for ly in layers], growth, bn2, prefilled)
+    meta = (stats, [ly.norm1.eps for ly in layers], [ly.norm2.eps for ly in layers], growth, bn2, prefilled, force_join)
     buf = DenseBlockFn.apply(x, meta, *params)
     n = x.shape[0] * x.shape[2] * x.shape[3]
     for i, ly in enumerate(layers):
@@ -981,10 +986,9 @@ class Conv0Fn(torch.autograd.Function):
                                   _stream()), "mcl_conv0_wrw")                          # straight into the fp32 .grad
             _grad_finish_khwc(w, tgt, in_place)
             return None, None, None
-        _fallback("conv0_wrw:miopen", dy)
-        dw = torch.ops.aten.convolution_backward(dy, x, w16, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                                 [False, True, False])[1]
-        return None, _wgrad(ctx.w, dw), None
+        from . import conv_generic as cg
+        dw = cg.conv_bwd_weight(dy, x, ctx.w, 2, 3)          # (parameter without a dense fp32 .grad: generic path)
+        return None, (None if dw is None else dw.to(ctx.w.dtype)), None
 
 
 # --------------------------------------------------------------------------- pooling (csrc/pool.hip)
@@ -1089,15 +1093,15 @@ def _stem_tail_ok(x: Tensor) -> bool:
 def max_pool_3s2(x: Tensor) -> Tensor:
     if _pool_ok(x, False):
         return MaxPool3s2Fn.apply(x)
-    _fallback("maxpool:aten", x)
-    return F.max_pool2d(x, 3, 2, 1)
+    from . import conv_generic as cg
+    return cg.max_pool_3s2(x)                       # fp32 activations (csrc/pool_generic.hip)
 
 
 def avg_pool_2(x: Tensor) -> Tensor:
     if _pool_ok(x, True):
         return AvgPool2Fn.apply(x)
-    _fallback("avgpool:aten", x)
-    return F.avg_pool2d(x, 2, 2)
+    from . import conv_generic as cg
+    return cg.avg_pool_2(x)                         # fp32 activations / odd maps
 
 
 # --------------------------------------------------------------------------- transitions
@@ -1295,15 +1299,44 @@ def image_to_act(x: Tensor, act_dtype: torch.dtype) -> Tensor:
     return x.to(dtype=act_dtype).contiguous(memory_format=CL)
 
 
+# ---- backward in SEGMENTS (data parallel: engine.TrainStep captures one HIP graph per segment and issues the all-reduce of
+# a segment's gradient range while the next segment replays).  A cut sits at every dense block's input behind a transition:
+# the forward passes the tensor through unchanged; the backward stops there, leaving the incoming gradient in ``slot["grad"]``;
+# the next segment is ``torch.autograd.backward((upstream,), (slot["grad"],))``.
+_cut_anchors = {}
+
+
+def _cut_anchor(device) -> Tensor:
+    a = _cut_anchors.get(device.index)
+    if a is None:
+        a = torch.zeros(1, device=device, requires_grad=True)     # makes the cut's output require grad; never receives one
+        _cut_anchors[device.index] = a
+    return a
+
+
+class _CutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.slot["grad"] = g
+        return None, None, None
+
+
 # dense block index -> callable invoked on the main stream right after that block's forward has been enqueued
 FORWARD_BLOCK_HOOKS: dict = {}
 
 
 def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16,
-                            pooled: bool = False) -> Tensor:
+                            pooled: bool = False, cuts: Optional[list] = None, cut_blocks=()) -> Tensor:
     """Train-mode forward of torchvision-layout DenseNet ``features`` (conv0 ... norm5), returning the
     (B, C, h, w) norm5 output (no ReLU: model.py:82-84 pools it directly) or, ``pooled``, the (B, C) fp32 features
-    after model.py:83-84's adaptive_avg_pool2d + flatten (norm5 and the pool as one kernel on the bf16 path)."""
+    after model.py:83-84's adaptive_avg_pool2d + flatten (norm5 and the pool as one kernel on the bf16 path).
+    ``cuts`` (a list) + ``cut_blocks`` (dense block indices, 2..): the backward is cut at the input of those blocks (behind
+    their transition); (upstream tensor, slot) pairs are appended to ``cuts`` in forward order (see ``_CutFn``)."""
     if not x.is_cuda:
         raise RuntimeError("densenet_features_fused: input is on the CPU; the fused backbone path is GPU-only")
     rec = _RunningStats()
@@ -1313,9 +1346,8 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
         mean0, var0, rstd0 = (torch.empty(64, device=x.device, dtype=torch.float32) for _ in range(3))
         x = Conv0Fn.apply(x, features.conv0.weight, (features.norm0.eps, (mean0, var0, rstd0)))
     else:
-        _fallback("conv0_fwd:miopen", x)
-        x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
-                     padding=features.conv0.padding)
+        from . import conv_generic as cg
+        x = cg.conv2d(x, features.conv0.weight, features.conv0.stride[0], features.conv0.padding[0])
     x = x.contiguous(memory_format=CL)
     if _stem_tail_ok(x):
         C0 = x.shape[1]
@@ -1330,8 +1362,9 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     i = 1
     out = None
     next_stats = None
+    cut_here = False
     while hasattr(features, f"denseblock{i}"):
-        buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec, next_stats)
+        buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec, next_stats, force_join=cut_here)
         hook = FORWARD_BLOCK_HOOKS.get(i)
         if hook is not None:
             hook()                                            # e.g. an event other streams wait for (model.embed)
@@ -1349,11 +1382,15 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
                                              device=buf.device, dtype=buf.dtype, memory_format=CL)
                 x = TransitionFn.apply(buf, tr.norm.weight, tr.norm.bias, tr.conv.weight,
                                        (stats, next_stats, nxt[0].norm1.eps))
+                cut_here = cuts is not None and (i + 1) in cut_blocks and x.requires_grad
+                if cut_here:
+                    slot = {}
+                    cuts.append((x, slot))
+                    x = _CutFn.apply(x.detach(), _cut_anchor(x.device), slot)
             else:
+                from . import conv_generic as cg
                 a = BNActFn.apply(buf, tr.norm.weight, tr.norm.bias, stats.mean, stats.rstd, True)
-                _fallback("transition:miopen", buf)
-                x = F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL))
-                x = avg_pool_2(x.contiguous(memory_format=CL))
+                x = avg_pool_2(cg.conv2d(a, tr.conv.weight, 1, 0))
         else:
             if pooled and _gap_ok(buf):
                 out = BNGlobalPoolFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd)
@@ -1396,9 +1433,8 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
     if _conv0_ok(x, features.conv0):
         x = conv0_fwd(x, _weight(features.conv0.weight, act_dtype), features.norm0.eps, None)
     else:
-        _fallback("eval.conv0_fwd:miopen", x)
-        x = F.conv2d(x, features.conv0.weight.to(dtype=act_dtype, memory_format=CL), stride=features.conv0.stride,
-                     padding=features.conv0.padding)
+        from . import conv_generic as cg
+        x = cg.conv_fwd(x, _weight(features.conv0.weight, act_dtype), features.conv0.stride[0], features.conv0.padding[0])
     x = x.contiguous(memory_format=CL)
     if _stem_tail_ok(x):
         x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, features.norm0.running_mean,
@@ -1422,19 +1458,19 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                 dense_conv3x3_fwd(z, ly.norm2.weight, ly.norm2.bias, ly.norm2.running_mean, rs[id(ly.norm2)], w2c,
                                   buf[:, cin:cin + growth], ly.norm1.eps, None, None, None)
             else:
-                _fallback("eval.dense_layer:miopen", buf)
+                from . import conv_generic as cg
                 a = affine(buf[:, :cin], ly.norm1, True)
                 z = affine(_conv1x1_fwd(a, w1c), ly.norm2, True)
-                buf[:, cin:cin + growth].copy_(F.conv2d(z, w2c, padding=1))
+                cg.conv_fwd(z, w2c, 1, 1, out=buf[:, cin:cin + growth])
         if hasattr(features, f"transition{i}"):
             tr = getattr(features, f"transition{i}")
             if _transition_ok(buf, tr.conv.weight):
                 p = bn_act_avgpool_fwd(buf, tr.norm.weight, tr.norm.bias, tr.norm.running_mean, rs[id(tr.norm)])
                 x = pooled_conv1x1_fwd(p, _weight(tr.conv.weight, act_dtype), tr.norm.eps, None)
             else:
-                _fallback("eval.transition:miopen", buf)
+                from . import conv_generic as cg
                 a = affine(buf, tr.norm, True)
-                x = avg_pool_2(F.conv2d(a, tr.conv.weight.to(dtype=act_dtype, memory_format=CL)).contiguous(memory_format=CL))
+                x = avg_pool_2(cg.conv_fwd(a, _weight(tr.conv.weight, act_dtype), 1, 0))
         elif pooled and _gap_ok(buf):
             bn = features.norm5
             B, C, H, W = buf.shape

@@ -399,12 +399,36 @@ class GradReducer:
         step = ((n + self.buckets - 1) // self.buckets + 3) // 4 * 4          # 16-byte aligned chunk starts
         return [g[o:min(n, o + step)] for o in range(0, n, step)]
 
-    def reduce(self, optimizer, async_flat: bool = False):
+    def _reduce_chunk(self, c: Tensor, async_flat: bool, handles: list) -> None:
+        if self.wire == "bf16":
+            w = c.to(torch.bfloat16)
+            if async_flat and not _host_staged(w, self.pg):
+                handles.append(_WireHandle(td.all_reduce(w, op=td.ReduceOp.SUM, group=self.pg, async_op=True), c, w))
+            else:
+                _all_reduce_sum(w, self.pg)
+                c.copy_(w)
+        elif async_flat and not _host_staged(c, self.pg):
+            handles.append(td.all_reduce(c, op=td.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            _all_reduce_sum(c, self.pg)
+
+    def reduce_range(self, g: Tensor, lo: int, hi: int, async_flat: bool = True) -> list:
+        """All-reduce (SUM) of the element range [lo, hi) of a flat gradient bucket as ONE collective -- issued by
+        engine.TrainStep as soon as the backward segment that produces the range has been enqueued, so that it runs on the
+        communicator's stream beside the next segment's kernels.  Returns the work handles (empty when it ran synchronously).
+        Every element is summed once over the same ranks, whatever the partition into ranges."""
+        handles: list = []
+        if hi > lo:
+            self._reduce_chunk(g[lo:hi], async_flat, handles)
+        return handles
+
+    def reduce(self, optimizer, async_flat: bool = False, skip_flat=()):
         """Sums gradients over ranks.  ``async_flat``: the (large) flat-bucket all-reduce is only ENQUEUED and its
         work handles are returned -- the caller overlaps it with independent work (the position-table update, which
         needs no flat gradient) and waits before the flat Adam step: ``optimizer.step(wait=handles)``.  The small
         table-row all-gather is issued first so that it does not queue behind the big all-reduce on the
-        communicator's stream."""
+        communicator's stream.  ``skip_flat``: data pointers of flat buckets that were already reduced range by range
+        (``reduce_range``)."""
         if hasattr(optimizer, "ensure_flat"):
             optimizer.ensure_flat()
         if async_flat and hasattr(optimizer, "prefetch_table_rows"):
@@ -413,18 +437,10 @@ class GradReducer:
         handles = []
         if hasattr(optimizer, "flat_grads"):
             for g in optimizer.flat_grads():
+                if g.data_ptr() in skip_flat:
+                    continue
                 for c in self._chunks(g):
-                    if self.wire == "bf16":
-                        w = c.to(torch.bfloat16)
-                        if async_flat and not _host_staged(w, self.pg):
-                            handles.append(_WireHandle(td.all_reduce(w, op=td.ReduceOp.SUM, group=self.pg, async_op=True), c, w))
-                        else:
-                            _all_reduce_sum(w, self.pg)
-                            c.copy_(w)
-                    elif async_flat and not _host_staged(c, self.pg):
-                        handles.append(td.all_reduce(c, op=td.ReduceOp.SUM, group=self.pg, async_op=True))
-                    else:
-                        _all_reduce_sum(c, self.pg)
+                    self._reduce_chunk(c, async_flat, handles)
             flat_ids = optimizer.flat_param_ids()
         for group in optimizer.param_groups:
             for p in group["params"]:

@@ -50,6 +50,9 @@ class TrainStep:
         self._all_regular = True
         self.opt_in_graph = False
         self._one = None
+        self._first_size = None
+        self.seg_graphs, self.seg_ranges = [], []
+        self._tables_stream = None
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
@@ -148,17 +151,121 @@ class TrainStep:
         # advances the device step counter) would be replayed by graph B AND repeated by the eager step() -> off here
         if getattr(m, "sparse_grads", None) is not None:
             m.sparse_grads.pop("hook", None)
-        with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
-            self.es, self.ei = m.embed(self.static_in)
+        # Segmented backward (data parallel, DenseNet on the fused kernels): the backbone's backward is cut at dense-block
+        # inputs and captured as one graph PER SEGMENT; after each segment's replay the all-reduce of exactly the gradient
+        # range that segment finished is enqueued on the communicator's stream, where it runs beside the next segment's
+        # kernels (what DDP's bucketed overlap does for /root/reference/baselines/Bleep/BLEEP_main.py:76-78,147 -- here with
+        # ranges that follow the flat bucket's layout, no packing copies), and the position tables are updated beside the
+        # remaining segments as soon as segment 0 has produced their gradient rows.  MCL_DP_SEGMENTS = number of segments
+        # (default 2: [heads, spot branch, norm5, last dense block] = 70 % of the gradient bytes | the rest; up to one per
+        # dense block; 1 = one backward graph and one all-reduce after it, the round-3 form).  Every cut adds a join of the
+        # weight-gradient side stream at its block's end and a graph launch: measured on ONE GPU (size-1 RCCL group, nothing
+        # to overlap) 2 segments cost +0.27 ms/step, 4 segments +0.35 (profiles/r04_dp_segments_size1.txt).
+        # (a group of ONE rank -- MCL_FORCE_DIST=1 on a single GPU -- has nothing to overlap: one backward graph by default)
+        try:
+            world = torch.distributed.get_world_size(self.reducer.pg) if self.reducer is not None else 1
+        except Exception:
+            world = 1
+        n_seg = int(os.environ.get("MCL_DP_SEGMENTS", "2" if world > 1 else "1"))
+        n_blocks = 0
+        enc = getattr(m, "image_encoder", None)
+        feats = enc.model[0] if enc is not None and hasattr(enc, "model") and hasattr(enc, "forward_fused") else None
+        while feats is not None and hasattr(feats, f"denseblock{n_blocks + 1}"):
+            n_blocks += 1
+        n_seg = max(1, min(n_seg, n_blocks)) if n_blocks else 1
+        want_seg = (self.reducer is not None and n_seg > 1 and hasattr(m, "segment_backward")
+                    and hasattr(self.opt, "flat_location"))
+        m.segment_backward = tuple(range(n_blocks - n_seg + 2, n_blocks + 1)) if want_seg else ()
+        try:
+            with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
+                self.es, self.ei = m.embed(self.static_in)
+        finally:
+            m.segment_backward = ()
+        cuts = list(getattr(m, "backward_cuts", None) or []) if want_seg else []
+        m.backward_cuts = None
         self.d_es = torch.zeros_like(self.es)
         self.d_ei = torch.zeros_like(self.ei)
         self.gb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode="thread_local"):
             self.opt.zero_grad()
             torch.autograd.backward((self.es, self.ei), (self.d_es, self.d_ei))
+        self.seg_graphs, self.seg_ranges = [], []
+        if cuts:
+            for up, slot in reversed(cuts):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.ga.pool(), capture_error_mode="thread_local"):
+                    torch.autograd.backward((up,), (slot["grad"],))
+                self.seg_graphs.append(g)
+            self.seg_ranges = self._segment_ranges(n_blocks - len(cuts) + 1, n_blocks)
+            if self.seg_ranges is None:                  # parameters not laid out as expected: one all-reduce at the end
+                self.seg_ranges = []
         if getattr(m, "embedding_grad", "dense") == "rowsparse":
             m.sparse_grads["static"] = True
         torch.cuda.synchronize()
+
+    def _segment_ranges(self, first_cut_block: int, last_block: int):
+        """[(flat bucket, lo, hi)] per backward segment, in backward order: segment 0 (heads, spot branch, norm5, last
+        dense block) owns the tail of the image encoder's flat range and everything behind it, segment k the range from
+        the first parameter of the k-th cut block (counted from the end) up to the next cut block's.  None if the layout
+        does not allow it."""
+        enc = getattr(self.model, "image_encoder", None)
+        feats = enc.model[0] if enc is not None and hasattr(enc, "model") else None
+        if feats is None:
+            return None
+        starts, gi = [], None
+        for i in range(first_cut_block, last_block + 1):
+            blk = getattr(feats, f"denseblock{i}", None)
+            if blk is None:
+                return None
+            loc = self.opt.flat_location(next(blk.parameters()))
+            if loc is None or (gi is not None and loc[0] != gi):
+                return None
+            gi = loc[0]
+            starts.append(loc[1])
+        bucket = self.opt.flat_bucket(gi)
+        if bucket is None or starts != sorted(starts) or len(set(starts)) != len(starts):
+            return None
+        bounds = [0] + starts + [bucket.numel()]
+        return [(bucket, bounds[k], bounds[k + 1]) for k in range(len(bounds) - 2, -1, -1)]
+
+    def _replay_backward_dp(self) -> None:
+        """Graph B (and its segments) + the gradient exchange + the optimizer, data parallel."""
+        if not self.seg_graphs or not self.seg_ranges:
+            self.gb.replay()
+            self._reduce_and_step()
+            return
+        red, handles = self.reducer, []
+        main = torch.cuda.current_stream()
+        self.gb.replay()                                   # heads, spot branch, norm5, last dense block
+        # the position tables: their gradient rows exist now (the spot branch's backward is in segment 0).  Row exchange
+        # (a small all-gather, first on the communicator) + the HBM-streaming table Adam run on a side stream beside the
+        # remaining, latency-bound segments -- what the single-process step graph does from inside its backward
+        tables_side = None
+        if hasattr(self.opt, "_early_tables") and getattr(self.model, "embedding_grad", "dense") == "rowsparse" \
+                and os.environ.get("MCL_EARLY_TABLES", "1") != "0":
+            if self._tables_stream is None:
+                self._tables_stream = torch.cuda.Stream(device=main.device)
+            tables_side = self._tables_stream
+            tables_side.wait_stream(main)
+            with torch.cuda.stream(tables_side):
+                self.opt._early_tables()
+        elif hasattr(self.opt, "prefetch_table_rows"):
+            self.opt.prefetch_table_rows()
+        bucket, lo, hi = self.seg_ranges[0]
+        handles += red.reduce_range(bucket, lo, hi, async_flat=True)
+        for g, (bucket, lo, hi) in zip(self.seg_graphs, self.seg_ranges[1:]):
+            g.replay()
+            handles += red.reduce_range(bucket, lo, hi, async_flat=True)
+        # whatever lives outside the segmented bucket (other param groups, parameters that are not flat-managed)
+        handles += red.reduce(self.opt, async_flat=True, skip_flat={self.seg_ranges[0][0].data_ptr()})
+        if tables_side is not None:
+            main.wait_stream(tables_side)
+        if hasattr(self.opt, "prefetch_table_rows"):
+            self.opt.step(wait=handles)
+        else:
+            for h in handles:
+                h.wait()
+            self.opt.step()
 
     def opt_will_be_in_graph(self) -> bool:
         return hasattr(self.opt, "_begin_step") and os.environ.get("MCL_OPT_IN_GRAPH", "1") != "0"
@@ -198,6 +305,15 @@ class TrainStep:
         if self.reducer is None:
             return True
         if self.equal_shards:
+            # the caller promised equal per-rank batches: a different size on ONE rank would send the ranks down different
+            # paths (replay vs eager) with mismatched collective shapes -- a hang or silently wrong gathered embeddings.
+            # It cannot be detected across ranks without the exchange that equal_shards switches off, so it is an error here.
+            n = int(batch["expression"].shape[0])
+            if self._first_size is None:
+                self._first_size = n
+            elif n != self._first_size:
+                raise RuntimeError(f"TrainStep(equal_shards=True): this step's per-rank batch has {n} pairs, the first one had "
+                                   f"{self._first_size}; use drop_last / equal shards, or equal_shards=False (host size exchange)")
             self._all_regular = (self.static_in is not None
                                  and batch["expression"].shape[0] == self.static_in["expression"].shape[0])
             return True
@@ -240,6 +356,9 @@ class TrainStep:
         loss, d_es, d_ei = self.model.loss_and_grads(self.es, self.ei)
         self.d_es.copy_(d_es)
         self.d_ei.copy_(d_ei)
-        self.gb.replay()
-        self._reduce_and_step()
+        if self.reducer is not None:
+            self._replay_backward_dp()
+        else:
+            self.gb.replay()
+            self._reduce_and_step()
         return loss

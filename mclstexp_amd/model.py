@@ -208,6 +208,8 @@ class _ContrastiveBase(nn.Module):
         self.embedding_grad = embedding_grad
         self.process_group = process_group
         self.fused_backbone = True      # DenseNet-121: concat-free BN+ReLU kernels (densenet_fused.py)
+        self.segment_backward = ()      # dense blocks whose input cuts the backbone's backward (data-parallel overlap, engine.py)
+        self.backward_cuts = None
         self.capture = False
         self.last: Dict[str, Tensor] = {}
         self.sparse_grads: Dict[str, ops.RowSparseGrad] = {}
@@ -242,7 +244,12 @@ class _ContrastiveBase(nn.Module):
             return image
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and encoder.training
                 and image.is_cuda and torch.is_grad_enabled()):
-            return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
+            # segment_backward (set by engine.TrainStep while it captures the data-parallel step): the backbone's backward is
+            # cut at the dense-block inputs; the (upstream tensor, slot) pairs are left in self.backward_cuts
+            seg = self.segment_backward if self.backbone_dtype == torch.bfloat16 else ()
+            self.backward_cuts = [] if seg else None
+            return encoder.forward_fused(image, self.backbone_dtype or torch.float32, cuts=self.backward_cuts,
+                                         cut_blocks=tuple(seg) if seg else ())
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and not encoder.training
                 and image.is_cuda and self.backbone_dtype == torch.bfloat16 and not torch.is_grad_enabled()):
             return encoder.forward_eval_fused(image, torch.bfloat16)      # inference: running statistics

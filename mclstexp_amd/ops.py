@@ -130,7 +130,11 @@ DIRECT_PARAM_GRADS = os.environ.get("MCL_DIRECT_GRADS", "1") != "0"
 
 
 def _direct_grad_ok(p) -> bool:
+    """Pure predicate (this path never creates a .grad).  A parameter with tensor / post-accumulate-grad hooks is excluded:
+    the hooks fire from autograd's AccumulateGrad node, which a kernel-side accumulation never reaches."""
     g = getattr(p, "grad", None)
+    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        return False
     return (DIRECT_PARAM_GRADS and g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape
             and g.is_contiguous() and p.is_contiguous() and not g.requires_grad)
 

@@ -105,6 +105,15 @@ class FusedAdam(torch.optim.Optimizer):
             if gi not in self._flat:
                 self._build_flat(gi, group)
 
+    def flat_location(self, p: Tensor):
+        """(group index, element offset) of a flat-managed parameter inside its group's flat buffers, or None."""
+        return self._where.get(id(p))
+
+    def flat_bucket(self, gi: int) -> Optional[Tensor]:
+        """The flat gradient bucket of param group ``gi`` (None when the group has no flat-managed parameter)."""
+        f = self._flat.get(gi)
+        return f["g"] if f and f.get("n", 0) > 0 else None
+
     def flat_param_ids(self) -> set:
         return {id(p) for f in self._flat.values() for p in f["params"]}
 
@@ -274,7 +283,24 @@ class FusedAdam(torch.optim.Optimizer):
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("FusedAdam: hyper-parameters changed inside a graph capture; call "
                                        "optimizer.sync_hyper() before capturing")
-                d["hyper"].copy_(torch.tensor(cur, dtype=torch.float64))
+                # pinned staging ring + asynchronous copy: a per-iteration LR schedule must not put a host-synchronising
+                # pageable copy in front of every replay (stream order ahead of the replay guarantees visibility); a slot is
+                # reused only after the copy that read it has completed
+                ring = d.setdefault("hyper_ring", [])
+                if not ring:
+                    for _ in range(4):
+                        ring.append([torch.empty(5, dtype=torch.float64, pin_memory=True), None])
+                    d["hyper_slot"] = 0
+                slot = ring[d["hyper_slot"]]
+                d["hyper_slot"] = (d["hyper_slot"] + 1) % len(ring)
+                if slot[1] is not None:
+                    slot[1].synchronize()
+                for i, v in enumerate(cur):
+                    slot[0][i] = v
+                d["hyper"].copy_(slot[0], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(d["hyper"].device))
+                slot[1] = ev
                 d["hyper_host"] = cur
 
     def _begin_step(self) -> None:

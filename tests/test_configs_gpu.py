@@ -106,9 +106,14 @@ def test_cfg1_as_benched_vs_oracle():
         128 x 256 elements (measured: rms 0.14, max 0.57 -- a random-init 121-layer BatchNorm net amplifies bf16
         rounding chaotically; the stock bf16-autocast module path deviates from fp64 just as much, which is what
         test_cfg4_backbone_256px_accuracy_vs_fp64 and test_fused_densenet_as_accurate_as_module_path pin); spot side 2e-3
-        at step 1 (fp32 kernels; measured 1.7e-6).  Later steps inherit Adam's +-lr sign noise, which grows with the number
-        of updates behind the step: 0.06 per update (measured 0.055 / 0.066 / 0.106 at steps 2 / 3 / 4 -- a 1000-term
-        fan-in of weights that each moved by up to 2 lr the other way);
+        at step 1 (fp32 kernels; measured 1.8e-6).  Later steps inherit the bf16 noise of the IMAGE embeddings through the
+        loss gradient: Adam's first updates are +-lr * sign(g), so a spot-path weight whose tiny gradient changes sign moves
+        the other way, and a 1000-term fan-in of such weights shows up in the spot embeddings.  Measured (round 4,
+        tools/diag_cfg1_spot_noise.py, one box, same seeds) 0.054 / 0.070 / 0.109 at steps 2 / 3 / 4; with the two-pass
+        BatchNorm-1 backward instead of the single-pass one 0.054 / 0.071 / 0.103 (the r03 kernel change is NOT the source:
+        ADVICE r03), and with an fp32 backbone (no bf16 kernel anywhere, exact InfoNCE) 2.5e-5 / 9.4e-4 / 1.5e-3 -- the
+        deviation is the bf16 backbone's 0.14-rms image-embedding noise amplified by Adam, not a spot-path kernel error.
+        Bounds = 1.3 x the measured values per step;
       * loss: 3 % of max(1, |loss|) -- logits reach +-85 and the bf16 image embeddings move them by ~0.5;
       * non-backbone parameters after 4 Adam steps: 8.5e-4 absolute = 4 steps x 2 lr (Adam's first updates are
         ~ +-lr * sign(g): an element whose tiny gradient flips sign under bf16 noise moves the other way, so two
@@ -136,7 +141,7 @@ def test_cfg1_as_benched_vs_oracle():
               f"dE_img max {de_i:.3e} rms {rms_i:.3e}; max|dE_spot| {de_s:.3e}")
         assert abs(l - lr_) <= 3e-2 * max(1.0, abs(lr_)), (s, l, lr_)
         assert de_i <= 1.5 and rms_i <= 0.25, (s, de_i, rms_i)
-        assert de_s <= (2e-3 if s == 0 else 0.06 * s), (s, de_s)
+        assert de_s <= (2e-3, 0.071, 0.092, 0.142)[s], (s, de_s)
     worst, name = _worst_param_diff(m, params)
     print(f"cfg1: worst non-backbone parameter deviation after {steps} Adam steps {worst:.3e} ({name}); "
           f"oracle {t_cpu / steps:.1f} s/step")

@@ -305,6 +305,33 @@ def test_grad_reducer_buckets_equal_monolithic_and_bf16_wire():
     assert torch.equal(o0["mono"], o1["mono"]) and torch.equal(o0["bf16"], o1["bf16"])          # replicas identical
 
 
+def _range_case(rank, world):
+    from mclstexp_amd import dist as mdist
+    g = torch.Generator().manual_seed(300 + rank)
+    base = torch.randn(50007, generator=g)
+    red = mdist.GradReducer(td.group.WORLD)
+    mono = base.clone()
+    for h in red.reduce_range(mono, 0, mono.numel(), async_flat=True):
+        h.wait()
+    parts = base.clone()
+    handles = []
+    bounds = [50007, 41000, 20004, 8, 0]                  # tail first, like the backward segments of engine.TrainStep
+    for hi, lo in zip(bounds, bounds[1:]):
+        handles += red.reduce_range(parts, lo, hi, async_flat=True)
+    handles += red.reduce_range(parts, 5, 5)              # an empty range is a no-op
+    for h in handles:
+        h.wait()
+    return mono, parts, base
+
+
+def test_grad_reducer_ranges_equal_monolithic():
+    """One all-reduce per gradient range (the segmented data-parallel backward) == one all-reduce of the whole bucket, bit
+    for bit, and the replicas agree."""
+    (m0, p0, b0), (m1, p1, b1) = _spawn(_range_case, 2)
+    assert torch.equal(m0, b0 + b1) and torch.equal(p0, m0)
+    assert torch.equal(m1, m0) and torch.equal(p1, p0)
+
+
 def test_init_from_env_single_process(monkeypatch):
     from mclstexp_amd import dist as mdist
     monkeypatch.setenv("WORLD_SIZE", "1")

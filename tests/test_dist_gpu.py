@@ -181,6 +181,31 @@ def _rccl_worker(_index, port, ret):
                 batch = {k: v.cuda() for k, v in synth.make_batch(B, G, image_dim=D, seed=s % 2).items()}
                 losses.append(float(step(batch).item()))
             out[mode] = (losses, {n: p.detach().double().sum().item() for n, p in m.named_parameters()})
+        # DenseNet-121 on the fused kernels, data-parallel form: backward captured in SEGMENTS with one all-reduce per gradient
+        # range and the position tables updated beside the later segments (MCL_DP_SEGMENTS = 4: one per dense block, 2: the
+        # default) against ONE backward graph + one all-reduce (= 1): same kernels, same sums -> bit-identical parameters
+        import hashlib
+        seg = {}
+        for flag in ("4", "2", "1"):
+            os.environ["MCL_DP_SEGMENTS"] = flag
+            torch.manual_seed(0)
+            m = mclSTExp_Attention("densenet121", 1.0, 1024, G, 256, 8, 64, 2, embedding_grad="rowsparse",
+                                   process_group=pg, infonce="fused", backbone_dtype=torch.bfloat16)
+            m.cuda().to(memory_format=torch.channels_last).train()
+            opt = FusedAdam(m.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(m)
+            step = TrainStep(m, opt, mdist.GradReducer(pg), graphs=True, warmup=2, equal_shards=True)
+            losses = []
+            for s in range(5):
+                batch = {k: v.cuda() for k, v in synth.make_batch(8, G, image_hw=64, seed=s % 2).items()}
+                losses.append(float(step(batch).item()))
+            torch.cuda.synchronize()
+            h = hashlib.sha256()
+            for n, p in m.named_parameters():
+                h.update(p.detach().float().cpu().numpy().tobytes())
+            seg[flag] = {"losses": losses, "sha": h.hexdigest(), "n_seg_graphs": len(step.seg_graphs),
+                         "ranges": [(lo, hi) for _, lo, hi in step.seg_ranges]}
+        os.environ.pop("MCL_DP_SEGMENTS", None)
+        out["segments"] = seg
         ret["out"] = out
     finally:
         mdist.shutdown()
@@ -193,7 +218,7 @@ def test_rccl_size1_group_matches_single_process():
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl1", str(_free_port())], capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=600)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL1 ")]
     assert r.returncode == 0 and line, r.stderr[-2000:]
     out = json.loads(line[-1][6:])
@@ -202,6 +227,14 @@ def test_rccl_size1_group_matches_single_process():
         assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (l_d, l_s)
     for n in c_s:
         assert abs(c_d[n] - c_s[n]) <= 1e-5 * max(1.0, abs(c_s[n])), n
+    # per-block backward segments with one all-reduce per gradient range == one backward graph + one all-reduce, bit for bit
+    seg = out["segments"]
+    assert [seg[f]["n_seg_graphs"] for f in ("4", "2", "1")] == [3, 1, 0], seg
+    rg = seg["4"]["ranges"]
+    assert len(rg) == 4 and rg[-1][0] == 0 and all(rg[k][0] == rg[k + 1][1] for k in range(3)), rg   # a partition, tail first
+    assert [list(r) for r in seg["2"]["ranges"]] == [list(rg[0]), [0, rg[0][0]]], seg
+    for f in ("4", "2"):
+        assert seg[f]["losses"] == seg["1"]["losses"] and seg[f]["sha"] == seg["1"]["sha"], (f, seg)
 
 
 if __name__ == "__main__" and len(os.sys.argv) == 3 and os.sys.argv[1] == "--rccl1":
