@@ -452,6 +452,8 @@ int mcl_bn_running_update(int32_t n, float* const* running_mean, float* const* r
 int mcl_image_to_bf16_nhwc(const float* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t C, int32_t H,
                            int32_t W, void* y, mcl_stream_t stream);
 int mcl_fill_zero(void* p, int64_t bytes, mcl_stream_t stream);
+/* debug: buf[idx] (uint64) = the GPU wall clock (100 MHz) when the stream reaches this point (MCL_STAMPS=1 timelines). */
+int mcl_stamp(void* buf, int32_t idx, mcl_stream_t stream);
 /* ya[i] = a[i] * s[0] (i < na), yb[i] = b[i] * s[0] (i < nb): a loss gradient scaled by autograd's upstream scalar (a
  * DEVICE value: no host read) for both embedding gradients in one launch.                                             */
 int mcl_scale2_f32(const float* a, int64_t na, const float* b, int64_t nb, const float* s, float* ya, float* yb,

@@ -1,7 +1,8 @@
 """Image backbones (kernel K10): module trees + parameter names only.  EXECUTION: DenseNet-121 in bf16
 runs entirely on the hand-written kernels scheduled by densenet_fused.py (``ImageEncoder.forward_fused`` /
-``forward_eval_fused``), the ViT on vit_fused.py; the modules' own ``forward`` (plain torch.nn on PyTorch-ROCm) is what fp32
-activations, the ResNet selector values (a12) and the A/B flag ``fused_backbone=False`` use.
+``forward_eval_fused``), the ViT on vit_fused.py, the ResNets (a12) on resnet_fused.py (generic im2col + own-GEMM convolutions,
+fp32 or bf16); the modules' own ``forward`` (plain torch.nn on PyTorch-ROCm) is what the A/B flag ``fused_backbone=False``
+and CPU-side tooling use.
 
 torchvision and timm are absent from the image, so the architectures are restated here in plain
 ``torch.nn`` with torchvision-/timm-compatible parameter names, which keeps reference checkpoints
@@ -166,6 +167,12 @@ class _PooledSequential(nn.Module):
         x = self.model(x)
         x = F.adaptive_avg_pool2d(x, (1, 1))
         return x.view(x.size(0), -1)
+
+    def forward_fused(self, x, act_dtype=torch.bfloat16):
+        """ResNet encoders on this library's kernels (resnet_fused.py): train-mode BatchNorm when ``self.training``, the
+        running statistics otherwise.  (ImageEncoder overrides this with the DenseNet execution.)"""
+        from .resnet_fused import resnet_features
+        return resnet_features(self.model, x, act_dtype, training=self.training)
 
 
 class ImageEncoder(_PooledSequential):

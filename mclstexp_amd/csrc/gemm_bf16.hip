@@ -385,11 +385,12 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   long long kps = (K + ksplit - 1) / ksplit;
   kps = (kps + BK - 1) / BK * BK;
   g.k_per_split = kps;
-  g.ksplit = (int)((K + kps - 1) / kps);
+  const bool via_slabs = ksplit > 1;       // requested: partial slabs + fixed-order merge, which is what honours `accumulate`
+  g.ksplit = (int)((K + kps - 1) / kps);   // (a short reduction may collapse to ONE slab: still merged, so that += holds)
   g.slab_stride = 0;
   hipStream_t st = mcl_stream(stream);
   float* final_c = (float*)C;
-  if (g.ksplit > 1) {
+  if (via_slabs) {
     g.slab_stride = (long long)M * ldc + 64;          // (+64: never a power-of-two stride, see csrc/wrw_fused.hip)
     g.C = workspace;
   }
@@ -414,7 +415,7 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   else if (akm && !bkm) MCL_LAUNCH(true, false);
   else MCL_LAUNCH(true, true);
 #undef MCL_LAUNCH
-  if (g.ksplit > 1) {
+  if (via_slabs) {
     // slabs are [M][ldc] fp32 at stride slab_stride; merge adds them in fixed order (+= when accumulate)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

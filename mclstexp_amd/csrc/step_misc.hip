@@ -255,7 +255,21 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float* __restrict__ a
   }
 }
 
+// debug: the GPU's wall clock (s_memrealtime, 100 MHz) when the stream reaches this point -- an UNTRACED timeline of a replayed
+// step graph (a kernel trace inflates launches and changes how the two hardware queues interleave)
+__global__ void stamp_kernel(unsigned long long* __restrict__ buf, int idx) {
+  if (threadIdx.x == 0) buf[idx] = wall_clock64();
+}
+
 }  // namespace
+
+extern "C" int mcl_stamp(void* buf, int32_t idx, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!buf || idx < 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, mcl_stream(stream), (unsigned long long*)buf, idx);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
 
 extern "C" int mcl_scale2_f32(const float* a, int64_t na, const float* b, int64_t nb, const float* s, float* ya, float* yb,
                               mcl_stream_t stream) {

@@ -57,6 +57,39 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- MCL_STAMPS=1: GPU wall-clock stamps at labelled points of the step (a one-thread kernel on the CURRENT stream, captured
+# into the step graph like any other launch): the untraced timeline of a replayed step (tools/step_stamps.py).
+STAMPS = os.environ.get("MCL_STAMPS", "0") == "1"
+_stamp_labels: list = []
+_stamp_buf = {}
+
+
+def stamp(label: str) -> None:
+    if not STAMPS:
+        return
+    dev = torch.cuda.current_device()
+    buf = _stamp_buf.get(dev)
+    if buf is None:
+        buf = torch.zeros(4096, device=f"cuda:{dev}", dtype=torch.int64)
+        _stamp_buf[dev] = buf
+    if label in _stamp_labels:
+        idx = _stamp_labels.index(label)
+    else:
+        _stamp_labels.append(label)
+        idx = len(_stamp_labels) - 1
+    check(_lib.lib().mcl_stamp(buf.data_ptr(), idx, _stream()), "mcl_stamp")
+
+
+def read_stamps() -> dict:
+    """{label: GPU wall clock in microseconds} of the last execution of every stamp."""
+    torch.cuda.synchronize()
+    buf = _stamp_buf.get(torch.cuda.current_device())
+    if buf is None:
+        return {}
+    v = buf[:len(_stamp_labels)].cpu().tolist()
+    return {lab: t / 100.0 for lab, t in zip(_stamp_labels, v)}
+
+
 def _dt(t: Tensor) -> int:
     if t.dtype == torch.bfloat16:
         return 1
@@ -736,6 +769,7 @@ class DenseBlockFn(torch.autograd.Function):
             ctx.cap["dz"] = [None] * L
             ctx.cap["gbuf"] = gbuf
         grads = [None] * (6 * L)
+        stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} start (main)")
         kacc = None             # single-pass BatchNorm-1 backward: the previous pass's mean terms, [C_total][2]
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
@@ -888,8 +922,14 @@ class DenseBlockFn(torch.autograd.Function):
         # last one of the backward: it always joins, so nothing is left running when the backward returns.
         if kacc is not None:
             dense_bn1_fix(buf, gbuf, 0, C0, stats.mean, stats.rstd, kacc)     # the block input: the mean terms of layer 0
+        if STAMPS:
+            stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} end (main)")
+            if USE_SIDE_STREAM:
+                with torch.cuda.stream(_side_stream(buf.device)):
+                    stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} weight gradients done (side)")
         if buf.shape[0] * buf.shape[2] * buf.shape[3] >= JOIN_MIN_PIXELS or ctx.first_block:
             _side_join(buf.device)
+            stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} after join (main)")
         return (gbuf[:, :C0], None, *grads)
 
 
@@ -1365,6 +1405,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     cut_here = False
     while hasattr(features, f"denseblock{i}"):
         buf, stats = dense_block(getattr(features, f"denseblock{i}"), x, rec, next_stats, force_join=cut_here)
+        stamp(f"fwd block {i} done (main)")
         hook = FORWARD_BLOCK_HOOKS.get(i)
         if hook is not None:
             hook()                                            # e.g. an event other streams wait for (model.embed)

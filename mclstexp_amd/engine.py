@@ -68,11 +68,16 @@ class TrainStep:
     def _sequence(self, inp):
         """The launch sequence of the single step graph up to the optimizer, shared by the capture and by
         ``run_sequence_eager``: forward, closed-form InfoNCE forward + backward, zero_grad, backward from the embeddings."""
+        from . import densenet_fused as dn
         m = self.model
+        dn.stamp("step start (main)")
         es, ei = m.embed(inp)
+        dn.stamp("forward done (main)")
         loss, d_es, d_ei = m.loss_and_grads(es, ei)
         self.opt.zero_grad()
+        dn.stamp("backward start (main)")
         torch.autograd.backward((es, ei), (d_es, d_ei))
+        dn.stamp("backward done (main)")
         return es, ei, loss
 
     def run_sequence_eager(self, batch) -> Tensor:

@@ -253,6 +253,10 @@ class _ContrastiveBase(nn.Module):
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and not encoder.training
                 and image.is_cuda and self.backbone_dtype == torch.bfloat16 and not torch.is_grad_enabled()):
             return encoder.forward_eval_fused(image, torch.bfloat16)      # inference: running statistics
+        if (self.fused_backbone and image.is_cuda and image.dim() == 4 and isinstance(
+                encoder, (backbones.ImageEncoder_Resnet, backbones.ImageEncdoer_res18, backbones.ImageEncdoer_res101))):
+            # ResNet selector values (model.py:88-148) on the generic own-kernel path, bf16 or fp32 activations
+            return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder_VIT) and image.is_cuda
                 and self.backbone_dtype == torch.bfloat16):
             from .vit_fused import vit_features_fused           # ViT on the hand-written bf16 kernels (csrc/gemm_bf16.hip)

@@ -469,9 +469,12 @@ class PosEmbedAddFn(torch.autograd.Function):
             # both tables share the same upstream gradient; the optimizer (or its data-parallel
             # exchange) reduces it to touched rows
             ctx.sink["dout"], ctx.sink["ix"], ctx.sink["iy"] = _rowmajor(dout, "dout"), ix, iy
+            from . import densenet_fused as _dn
+            _dn.stamp("spot backward done (its stream)")
             hook = ctx.sink.get("hook")
             if hook is not None:
                 hook()          # FusedAdam._early_tables: update both tables now, on this (spot-branch) stream
+                _dn.stamp("position tables updated (spot stream)")
             return d_expr, None, None, None, None
         gx = embed_rowgrad(dout, ix)
         gy = embed_rowgrad(dout, iy)

@@ -152,8 +152,9 @@ def test_cfg1_as_benched_vs_oracle():
 @pytest.mark.parametrize("mode", ["fp32_exact", "bf16_fused_graph"])
 def test_cfg0_her2st_shape_with_densenet(mode):
     """her2st config: B = 8, 112x112 patches, G = 785, full DenseNet-121, 3 steps vs the oracle.
-    fp32_exact: fp32 backbone (MIOpen fp32 convolutions + own BN kernels), exact InfoNCE -- 5e-3 on the loss (two
-    fp32 executions of this 121-layer random-init net differ by that much between summation orders);
+    fp32_exact: fp32 backbone (round 4: im2col + exact-fp32 MFMA GEMM convolutions, own BN / pooling kernels -- no library call),
+    exact InfoNCE -- 1e-4 on the loss at step 1 (north_star), 5e-3 afterwards (Adam's sign-like first updates amplify the
+    summation-order noise of two fp32 executions of this 121-layer random-init net);
     bf16_fused_graph: the benched mode at this shape -- 10 % on the loss (measured 5 %: with 8 patches the last block's
     BatchNorm layers normalise over 8 x 3 x 3 = 72 values, which amplifies bf16 rounding far more than at batch 128)."""
     from mclstexp_amd import synth
@@ -176,6 +177,11 @@ def test_cfg0_her2st_shape_with_densenet(mode):
         print(f"cfg0 {mode} step {s + 1}: loss {l:.5f} oracle {lr_:.5f}; dE_img max {de_i:.3e} rms {rms_i:.3e}")
         assert abs(l - lr_) <= tol * max(1.0, abs(lr_)), (mode, s, l, lr_)
         assert de_i <= (1.5 if bf16 else 0.1) and rms_i <= (0.25 if bf16 else 0.02), (mode, s, de_i, rms_i)
+        if not bf16 and s == 0:
+            # round 4: the fp32 mode runs im2col + the exact-fp32 MFMA GEMM (no MIOpen): same weights, same batch, before any
+            # optimizer step -- the north-star bound (1e-4 on the loss) holds end to end through the 121-layer backbone
+            # (measured 1e-5 on the loss, image embeddings 3.0e-5 max / 7.6e-6 rms)
+            assert abs(l - lr_) <= 1e-4 and de_i <= 2e-4 and rms_i <= 5e-5, (l, lr_, de_i, rms_i)
     worst, name = _worst_param_diff(m, params)
     print(f"cfg0 {mode}: worst non-backbone parameter deviation {worst:.3e} ({name})")
     assert worst <= 6.5e-4, (worst, name)          # 3 steps x 2 lr (see test_cfg1_as_benched_vs_oracle)
