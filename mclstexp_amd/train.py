@@ -48,9 +48,10 @@ def generate_args(argv=None):
     parser.add_argument('--compute', type=str, default='f32', choices=['f32', 'bf16'],
                         help='MFMA operand type of the hand kernels (f32 = reference numerics)')
     parser.add_argument('--backbone_dtype', type=str, default='bf16', choices=['f32', 'bf16'],
-                        help='autocast dtype of the delegated image backbone')
-    parser.add_argument('--infonce', type=str, default='exact', choices=['exact', 'fused'],
-                        help='exact = fp32 logits (reference numerics); fused = flash-style bf16 MFMA kernel')
+                        help='activation type of the image backbone kernels (f32 = reference numerics: exact-fp32 MFMA)')
+    parser.add_argument('--infonce', type=str, default='exact', choices=['exact', 'fused', 'fp8'],
+                        help='exact = fp32 logits (reference numerics); fused = flash-style bf16 MFMA kernel; fp8 = the '
+                             'similarity contraction on e4m3 operands with hardware block scales (BASELINE configs[4])')
     parser.add_argument('--hip_graphs', action='store_true',
                         help='replay forward / backward from HIP graphs (engine.TrainStep) instead of eager launches')
     parser.add_argument('--save_dir', type=str, default='', help='if set: torch.save(state_dict) per fold (train.py:87-95)')

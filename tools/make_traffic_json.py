@@ -24,6 +24,7 @@ UNITS = {   # ABI unit -> [(kernel substring, launches of it per unit call)]
     "mcl_dense_conv3x3_wrw_det": [("conv3x3_wrw_k", 1)],
     "mcl_adam_table_step_dev": [("adam_table_kernel", 1)],
     "mcl_adam_step_dev": [("adam_kernel(", 1)],
+    "mcl_adam_step_dev_shadow": [("adam_kernel<true>", 1)],
 }
 
 

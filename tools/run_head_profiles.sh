@@ -1,4 +1,4 @@
-# Profiles of the shipped configuration at HEAD -> gpurun_out/head_* (copied into profiles/r03_* afterwards)
+# Profiles of the shipped configuration at HEAD -> gpurun_out/head_* (copied into profiles/rNN_* afterwards)
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
 cd /tmp
 B="python3 $R/bench.py --no_cpu_baseline --profile_steps 0"
