@@ -452,6 +452,14 @@ int mcl_bn_running_update(int32_t n, float* const* running_mean, float* const* r
 int mcl_image_to_bf16_nhwc(const float* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t C, int32_t H,
                            int32_t W, void* y, mcl_stream_t stream);
 int mcl_fill_zero(void* p, int64_t bytes, mcl_stream_t stream);
+/* nn.Dropout(p) / nn.GELU() / the residual add of the dropout > 0 path (model.py:25-29,156,164-165; never active in the
+ * reference, model.py:217) as own elementwise kernels on contiguous fp32.  mcl_dropout_fwd: mask byte = 1 where kept (a
+ * counter-based generator of (seed, element index): reproducible per seed), y = kept ? x / (1 - p) : 0; mcl_dropout_bwd:
+ * dx = mask ? dy / (1 - p) : 0.  mcl_gelu_f32: out = dy ? dy * gelu'(x) : gelu(x) (exact erf form).                       */
+int mcl_dropout_fwd(const float* x, float* y, void* mask, int64_t n, float p, uint64_t seed, mcl_stream_t stream);
+int mcl_dropout_bwd(const float* dy, const void* mask, float* dx, int64_t n, float p, mcl_stream_t stream);
+int mcl_gelu_f32(const float* x, const float* dy, float* out, int64_t n, mcl_stream_t stream);
+int mcl_add_f32(const float* a, const float* b, float* y, int64_t n, mcl_stream_t stream);
 /* debug: buf[idx] (uint64) = the GPU wall clock (100 MHz) when the stream reaches this point (MCL_STAMPS=1 timelines). */
 int mcl_stamp(void* buf, int32_t idx, mcl_stream_t stream);
 /* ya[i] = a[i] * s[0] (i < na), yb[i] = b[i] * s[0] (i < nb): a loss gradient scaled by autograd's upstream scalar (a

@@ -80,6 +80,10 @@ PROTOTYPES = {
     "mcl_image_to_bf16_nhwc": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_fill_zero": [c_p, c_l, c_p],
     "mcl_stamp": [c_p, c_i, c_p],
+    "mcl_dropout_fwd": [c_p, c_p, c_p, c_l, c_f, C.c_uint64, c_p],
+    "mcl_dropout_bwd": [c_p, c_p, c_p, c_l, c_f, c_p],
+    "mcl_gelu_f32": [c_p, c_p, c_p, c_l, c_p],
+    "mcl_add_f32": [c_p, c_p, c_p, c_l, c_p],
     "mcl_im2col_nhwc": [c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_col2im_nhwc": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p],
     "mcl_maxpool3s2_nhwc_fwd_any": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],

@@ -255,6 +255,43 @@ __global__ __launch_bounds__(256) void scale2_kernel(const float* __restrict__ a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// nn.Dropout(p) and nn.GELU() as own elementwise kernels for the dropout > 0 path of FeedForward / ProjectionHead
+// (/root/reference/model.py:25-29,156,164; the reference never activates it: model.py:217 hard-codes 0.).  The mask comes
+// from a counter-based generator (one 64-bit mix of (seed, element index) per element: reproducible for a given seed, no
+// state), is kept as one byte per element for the backward, and kept elements are scaled by 1 / (1 - p).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          unsigned char* __restrict__ mask, long long n, float p, float scale,
+                                                          unsigned long long seed) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const unsigned long long r = mix64(seed ^ mix64((unsigned long long)i));
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);          // 24 random bits -> [0, 1)
+    const unsigned char keep = u >= p ? 1 : 0;
+    mask[i] = keep;
+    y[i] = keep ? x[i] * scale : 0.0f;
+  }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                          float* __restrict__ dx, long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    dx[i] = mask[i] ? dy[i] * scale : 0.0f;
+}
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                   float* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = dy ? dy[i] * gelu_erf_grad(x[i]) : gelu_erf(x[i]);
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
 // debug: the GPU's wall clock (s_memrealtime, 100 MHz) when the stream reaches this point -- an UNTRACED timeline of a replayed
 // step graph (a kernel trace inflates launches and changes how the two hardware queues interleave)
 __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int idx) {
@@ -262,6 +299,47 @@ __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int idx) {
 }
 
 }  // namespace
+
+namespace {
+inline unsigned ew_grid(long long n) {
+  long long b = (n + 255) / 256;
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+}  // namespace
+
+extern "C" int mcl_dropout_fwd(const float* x, float* y, void* mask, int64_t n, float p, uint64_t seed, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!x || !y || !mask || n <= 0 || !(p >= 0.0f && p < 1.0f)) return MCL_EINVAL;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, mcl_stream(stream), x, y, (unsigned char*)mask,
+                     (long long)n, p, 1.0f / (1.0f - p), (unsigned long long)seed);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_dropout_bwd(const float* dy, const void* mask, float* dx, int64_t n, float p, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dy || !dx || !mask || n <= 0 || !(p >= 0.0f && p < 1.0f)) return MCL_EINVAL;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, mcl_stream(stream), dy, (const unsigned char*)mask,
+                     dx, (long long)n, 1.0f / (1.0f - p));
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_gelu_f32(const float* x, const float* dy, float* out, int64_t n, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!x || !out || n <= 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(gelu_kernel, dim3(ew_grid(n)), dim3(256), 0, mcl_stream(stream), x, dy, out, (long long)n);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_add_f32(const float* a, const float* b, float* y, int64_t n, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!a || !b || !y || n <= 0) return MCL_EINVAL;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n)), dim3(256), 0, mcl_stream(stream), a, b, y, (long long)n);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
 
 extern "C" int mcl_stamp(void* buf, int32_t idx, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();

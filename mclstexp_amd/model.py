@@ -51,15 +51,18 @@ class _LinearFn(torch.autograd.Function):
         x2, W, pre = ctx.saved_tensors
         dy2 = dy.reshape(-1, W.shape[0])
         if pre is not None:
-            dy2 = dy2 * _gelu_grad(pre)
+            dy2 = ops.gelu_bwd(dy2, pre)
         dW = ops.linear_bwd_weight(dy2, x2)
         db = ops.colsum(dy2) if ctx.has_bias else None
         dx = ops.linear_bwd_data(dy2, W).view(ctx.shp) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None
 
 
-def _gelu_grad(x: Tensor) -> Tensor:
-    return 0.5 * (1.0 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327
+def _dropout(mod: nn.Dropout, x: Tensor) -> Tensor:
+    """nn.Dropout as an own kernel when it is active (training, p > 0; never in the reference: model.py:217), else identity."""
+    if mod.training and mod.p > 0:
+        return ops.DropoutFn.apply(x, mod.p)
+    return x
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -105,8 +108,8 @@ class FeedForward(nn.Module):
                                  nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
 
     def forward(self, x):
-        h = self.net[2](_linear(self.net[0], x, gelu=True))
-        return self.net[4](_linear(self.net[3], h))
+        h = _dropout(self.net[2], _linear(self.net[0], x, gelu=True))
+        return _dropout(self.net[4], _linear(self.net[3], h))
 
 
 class Attention(nn.Module):
@@ -132,7 +135,7 @@ class Attention(nn.Module):
         out = _AttnCoreFn.apply(qkv, self.heads, self.dim_head)
         if isinstance(self.to_out, nn.Identity):
             return out.view(*shp[:-1], -1)
-        out = self.to_out[1](_linear(self.to_out[0], out))
+        out = _dropout(self.to_out[1], _linear(self.to_out[0], out))
         return out.view(*shp[:-1], -1)
 
 
@@ -150,9 +153,9 @@ class attn_block(nn.Module):
     def forward(self, x):
         a, f = self.attn.fn, self.ff.fn
         fused_ok = (not (self.training and self._p > 0)) and not isinstance(a.to_out, nn.Identity)
-        if not fused_ok:
-            x = self.attn(x) + x
-            return self.ff(x) + x
+        if not fused_ok:                                 # dropout > 0: the unfused sequence, every op an own kernel
+            x = ops.AddFn.apply(self.attn(x), x)
+            return ops.AddFn.apply(self.ff(x), x)
         shp = x.shape
         if x.dim() == 3 and shp[0] != 1:
             return torch.cat([self.forward(xi.unsqueeze(0)) for xi in x], 0)
@@ -180,16 +183,12 @@ class ProjectionHead(nn.Module):
         x2 = x.reshape(-1, shp[-1])
         if self.training and self.dropout.p > 0:
             projected = _linear(self.projection, x2)
-            y = self.dropout(_linear(self.fc, ops_gelu(projected))) + projected
+            y = ops.AddFn.apply(_dropout(self.dropout, _linear(self.fc, ops.GeluFn.apply(projected))), projected)
             y = _layer_norm(self.layer_norm, y)
         else:
             y = ops.ProjectionHeadFn.apply(x2, self.projection.weight, self.projection.bias, self.fc.weight,
                                            self.fc.bias, self.layer_norm.weight, self.layer_norm.bias)
         return y.view(*shp[:-1], -1)
-
-
-def ops_gelu(x: Tensor) -> Tensor:
-    return F.gelu(x)  # only on the dropout>0 path, which the reference never takes
 
 
 class _ContrastiveBase(nn.Module):

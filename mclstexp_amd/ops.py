@@ -707,6 +707,80 @@ class InfoNCEFn(torch.autograd.Function):
         return d_es * gl, d_ei * gl, None, None, None
 
 
+# --------------------------------------------------------------------------- dropout > 0 path (model.py:25-29,156,164-165)
+_dropout_calls = 0
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout(p) in training mode on an own kernel (csrc/step_misc.hip): mask from a counter-based generator seeded by
+    torch's seed and a per-call counter (reproducible under torch.manual_seed), one byte per element kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        global _dropout_calls
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mclstexp_amd: dropout > 0 inside a HIP-graph capture would replay ONE frozen mask; run the "
+                               "dropout > 0 configuration eagerly (engine.TrainStep(graphs=False))")
+        x = _chk(x, "dropout input").contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        _dropout_calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        check(_lib.lib().mcl_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), seed, _stream()),
+              "mcl_dropout_fwd")
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(_lib.lib().mcl_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, _stream()),
+              "mcl_dropout_bwd")
+        return dx, None
+
+
+def gelu_bwd(dy: Tensor, pre: Tensor) -> Tensor:
+    """dy * gelu'(pre) (exact erf form) in one own launch."""
+    dy, pre = dy.contiguous(), pre.contiguous()
+    out = torch.empty_like(dy)
+    check(_lib.lib().mcl_gelu_f32(pre.data_ptr(), dy.data_ptr(), out.data_ptr(), dy.numel(), _stream()), "mcl_gelu_f32")
+    return out
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x, "gelu input").contiguous()
+        y = torch.empty_like(x)
+        check(_lib.lib().mcl_gelu_f32(x.data_ptr(), None, y.data_ptr(), x.numel(), _stream()), "mcl_gelu_f32")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return gelu_bwd(dy, x)
+
+
+class AddFn(torch.autograd.Function):
+    """a + b (a residual join) as an own launch; the gradient passes through to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "a").contiguous(), _chk(b, "b").contiguous()
+        assert a.shape == b.shape
+        y = torch.empty_like(a)
+        check(_lib.lib().mcl_add_f32(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "mcl_add_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
 # --------------------------------------------------------------------------- BLEEP soft-target CLIP loss (§8 f4)
 def soft_clip_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, targets_times_temperature: bool = False
                       ) -> Tuple[Tensor, Tensor, Tensor]:

@@ -198,3 +198,50 @@ def test_infonce_loss_mean_matches_two_sum_form():
     assert float(out) == float((sums[0] + sums[1]) / (2.0 * B))
     ref = 0.5 * ((rl - S.diag()).double().mean() + (cl - S.diag()).double().mean())
     assert abs(float(out) - float(ref)) < 1e-5
+
+
+def test_dropout_path_runs_on_own_kernels():
+    """dropout > 0 (model.py:25-29,156,164; never active in the reference, model.py:217): nn.Dropout / nn.GELU / the residual
+    adds of the unfused sequence are own kernels too; mask statistics, scaling, reproducibility under torch.manual_seed, and the
+    exact-erf GELU and its derivative against torch."""
+    from mclstexp_amd import kernel_audit, ops, synth
+    from mclstexp_amd.model import FeedForward, ProjectionHead, attn_block
+    x = (_rand(400, 256, seed=20) - 0.5).to(DEV).requires_grad_(True)
+    torch.manual_seed(7)
+    y1 = ops.DropoutFn.apply(x, 0.3)
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    kept = (y1 != 0).detach()
+    assert_close(y1.detach()[kept].cpu(), (x.detach() / 0.7)[kept].cpu(), 1e-6, 1e-6, what="kept elements scaled by 1/(1-p)")
+    g = (_rand(400, 256, seed=21) - 0.5).to(DEV)
+    y1.backward(g)
+    assert_close(x.grad.cpu(), torch.where(kept, g / 0.7, torch.zeros_like(g)).cpu(), 1e-6, 1e-6, what="dropout backward")
+    ops._dropout_calls = 0
+    torch.manual_seed(7)
+    a = ops.DropoutFn.apply(x.detach(), 0.3)
+    ops._dropout_calls = 0
+    torch.manual_seed(7)
+    b = ops.DropoutFn.apply(x.detach(), 0.3)
+    assert torch.equal(a, b) and not torch.equal(a, ops.DropoutFn.apply(x.detach(), 0.3))   # same seed + call index: same mask
+    xg = (4 * _rand(1000, seed=22) - 2).to(DEV).requires_grad_(True)
+    yg = ops.GeluFn.apply(xg)
+    yg.backward(torch.ones_like(yg))
+    xr = xg.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(xr)
+    yr.backward(torch.ones_like(yr))
+    assert_close(yg.detach().cpu(), yr.detach().cpu(), 2e-6, 2e-6, what="gelu")
+    assert_close(xg.grad.cpu(), xr.grad.cpu(), 2e-6, 2e-6, what="gelu'")
+    # the p > 0 modules end to end: forward + backward launch no ATen elementwise / dropout kernel
+    torch.manual_seed(0)
+    blk = attn_block(256, heads=8, dim_head=64, mlp_dim=256, dropout=0.2).to(DEV).train()
+    head = ProjectionHead(256, 256, dropout=0.2).to(DEV).train()
+    inp = (_rand(1, 64, 256, seed=23) - 0.5).to(DEV)
+
+    def run():
+        out = head(blk(inp))
+        torch.autograd.backward((out,), (torch.ones_like(out),))
+    run()
+    ks = kernel_audit.step_kernels(run)
+    bad = [n for n in kernel_audit.foreign(ks) if "FillFunctor" not in n]       # (ones_like of this test itself)
+    assert not bad, bad
+    assert any("dropout_fwd_kernel" in n for n in ks) and any("gelu_kernel" in n for n in ks)
