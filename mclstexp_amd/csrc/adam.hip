@@ -3,6 +3,7 @@
 // form reads no dense gradient (24 B/element) and adds the row-sparse data gradient through a
 // row->slot map.  16-byte accesses per lane, grid-stride, ~8 workgroups per CU.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -196,7 +197,11 @@ int launch_adam_table(float* p, float* m, float* v, int32_t n_rows, int32_t cols
                       const float* row_grad, int64_t ld_rg, const AdamC& c, const AdamC* c_dev, hipStream_t st) {
   // one 4-row group per workgroup (no grid-stride loop): the hardware dispatcher balances 16 K short workgroups
   // better than 4 K persistent ones -- measured in bench.py on one box: 6.00 vs 5.33 TB/s
-  const int blocks = (n_rows + 3) / 4;
+  // MCL_TABLE_GRID (experiment): a persistent grid of that many workgroups instead -- the update then takes
+  // longer but leaves HBM bandwidth to the backbone's backward it runs beside
+  static const char* e_tg = getenv("MCL_TABLE_GRID");
+  int blocks = (n_rows + 3) / 4;
+  if (e_tg && atoi(e_tg) > 0 && atoi(e_tg) < blocks) blocks = atoi(e_tg);
   const bool vec = (cols % 4 == 0) && (ld_rg % 4 == 0) && al16(p) && al16(m) && al16(v) && al16(row_grad);
   if (vec)
     hipLaunchKernelGGL((adam_table_kernel<true>), dim3(blocks), dim3(256), 0, st, p, m, v, n_rows, cols, row_slot,
