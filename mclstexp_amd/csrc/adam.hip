@@ -197,11 +197,9 @@ int launch_adam_table(float* p, float* m, float* v, int32_t n_rows, int32_t cols
                       const float* row_grad, int64_t ld_rg, const AdamC& c, const AdamC* c_dev, hipStream_t st) {
   // one 4-row group per workgroup (no grid-stride loop): the hardware dispatcher balances 16 K short workgroups
   // better than 4 K persistent ones -- measured in bench.py on one box: 6.00 vs 5.33 TB/s
-  // MCL_TABLE_GRID (experiment): a persistent grid of that many workgroups instead -- the update then takes
-  // longer but leaves HBM bandwidth to the backbone's backward it runs beside
-  static const char* e_tg = getenv("MCL_TABLE_GRID");
-  int blocks = (n_rows + 3) / 4;
-  if (e_tg && atoi(e_tg) > 0 && atoi(e_tg) < blocks) blocks = atoi(e_tg);
+  // (round 4: a persistent, smaller grid -- 4096 / 2048 / 1024 / 512 workgroups, so that the update leaves HBM bandwidth to the
+  // 7 x 7 block's backward it runs beside -- did not move the step: 11.59-11.67 ms at every size, profiles/r04_table_grid_ab.txt)
+  const int blocks = (n_rows + 3) / 4;
   const bool vec = (cols % 4 == 0) && (ld_rg % 4 == 0) && al16(p) && al16(m) && al16(v) && al16(row_grad);
   if (vec)
     hipLaunchKernelGGL((adam_table_kernel<true>), dim3(blocks), dim3(256), 0, st, p, m, v, n_rows, cols, row_slot,

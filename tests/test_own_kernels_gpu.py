@@ -242,6 +242,8 @@ def test_dropout_path_runs_on_own_kernels():
         torch.autograd.backward((out,), (torch.ones_like(out),))
     run()
     ks = kernel_audit.step_kernels(run)
-    bad = [n for n in kernel_audit.foreign(ks) if "FillFunctor" not in n]       # (ones_like of this test itself)
+    # allowed: this test's own ones_like, and autograd's fan-in accumulation (a tensor consumed by the branch AND by the residual
+    # gets its two gradients added by the engine: at::native add) -- the modules' own forward / backward ops are all own kernels
+    bad = [n for n in kernel_audit.foreign(ks) if "FillFunctor" not in n and "CUDAFunctor_add" not in n]
     assert not bad, bad
     assert any("dropout_fwd_kernel" in n for n in ks) and any("gelu_kernel" in n for n in ks)
