@@ -83,3 +83,25 @@ def test_vit_and_resnet_shapes_cpu():
     with torch.no_grad():
         assert ImageEncoder_VIT().eval()(x).shape == (2, 768)       # model.py:104-116, patch32
         assert ImageEncdoer_res18().eval()(x[:, :, :64, :64]).shape == (2, 512)
+
+
+def test_kernel_audit_classifies_library_kernels():
+    """mclstexp_amd.kernel_audit.foreign(): library kernels (hipBLASLt / Tensile, ATen, MIOpen, rocPRIM) are flagged, this
+    library's kernels and the runtime's copy / fill helpers are not."""
+    from mclstexp_amd import kernel_audit
+    names = ["Cijk_Ailk_Bljk_BBS_BH_Bias_HA_S_SAV_UserArgs_MT256x224x32",
+             "void at::native::vectorized_elementwise_kernel<4, at::native::FillFunctor<float>, std::array<char*, 1ul> >(int)",
+             "void at::native::(anonymous namespace)::multi_tensor_apply_kernel<...>", "miopenSp3AsmConv_v30_3_1_gfx9_fp32",
+             "void rocprim::detail::sort_kernel<...>",
+             "(anonymous namespace)::conv1x1_fwd_kernel<2, 32, 4>(unsigned short const*, long long)",
+             "(anonymous namespace)::fill_zero_kernel(unsigned int*, long long)", "__amd_rocclr_copyBuffer", "Memcpy DtoD (Device -> Device)",
+             "void (anonymous namespace)::gemm_bf16_kernel<false, true, 2>((anonymous namespace)::GemmB)"]
+    bad = kernel_audit.foreign(names)
+    assert len(bad) == 5 and all(("conv1x1" not in n and "fill_zero" not in n and "rocclr" not in n and "gemm_bf16" not in n)
+                                 for n in bad)
+
+
+def test_train_flags_include_fp8_infonce():
+    from mclstexp_amd.train import generate_args
+    a = generate_args(["--infonce", "fp8"])
+    assert a.infonce == "fp8" and a.encoder_name == "densenet121" and a.dim == 785     # reference defaults untouched
