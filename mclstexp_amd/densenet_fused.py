@@ -1325,18 +1325,27 @@ def _gap_ok(buf: Tensor) -> bool:
             and buf.is_contiguous(memory_format=CL))
 
 
-def image_to_act(x: Tensor, act_dtype: torch.dtype) -> Tensor:
+def image_to_act(x: Tensor, act_dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
     """``x.to(act_dtype).contiguous(memory_format=channels_last)`` of the input image; fp32 -> bf16 as one launch of
-    mcl_image_to_bf16_nhwc for any input strides (NCHW from a DataLoader, channels-last from bench.py)."""
+    mcl_image_to_bf16_nhwc for any input strides (NCHW from a DataLoader, channels-last from bench.py).  ``out``: a bf16
+    channels-last tensor that receives the result (engine.TrainStep's static graph input: the per-step input copy IS the cast)."""
     if (act_dtype == torch.bfloat16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad
             and x.numel() > 0):
         B, C, H, W = x.shape
-        y = torch.empty((B, C, H, W), device=x.device, dtype=torch.bfloat16, memory_format=CL)
+        if out is not None:
+            assert out.shape == x.shape and out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=CL)
+            y = out
+        else:
+            y = torch.empty((B, C, H, W), device=x.device, dtype=torch.bfloat16, memory_format=CL)
         sb, sc, sy, sx = x.stride()
         check(_lib.lib().mcl_image_to_bf16_nhwc(x.data_ptr(), sb, sc, sy, sx, B, C, H, W, y.data_ptr(), _stream()),
               "mcl_image_to_bf16_nhwc")
         return y
-    return x.to(dtype=act_dtype).contiguous(memory_format=CL)
+    y = x.to(dtype=act_dtype).contiguous(memory_format=CL)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 # ---- backward in SEGMENTS (data parallel: engine.TrainStep captures one HIP graph per segment and issues the all-reduce of

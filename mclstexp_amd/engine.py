@@ -53,6 +53,8 @@ class TrainStep:
         self._first_size = None
         self.seg_graphs, self.seg_ranges = [], []
         self._tables_stream = None
+        self._img_bf16 = False
+        self._in_sig = {}
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
@@ -117,9 +119,37 @@ class TrainStep:
             self.opt.step()
 
     # ------------------------------------------------------------------ capture
+    def _image_staged_bf16(self, batch) -> bool:
+        """The static image input of the step graph can hold the bf16 channels-last activation directly when the image
+        encoder's first kernel consumes exactly that (DenseNet / ResNet on the fused bf16 path): the per-step copy of the fp32
+        image into the graph's input buffer and the cast kernel inside the graph become ONE launch outside it."""
+        from . import backbones
+        m = self.model
+        enc = getattr(m, "image_encoder", None)
+        img = batch.get("image")
+        return (os.environ.get("MCL_STAGE_IMAGE_BF16", "1") != "0" and getattr(m, "fused_backbone", False)
+                and getattr(m, "backbone_dtype", None) == torch.bfloat16
+                and isinstance(enc, (backbones.ImageEncoder, backbones.ImageEncoder_Resnet, backbones.ImageEncdoer_res18,
+                                     backbones.ImageEncdoer_res101))
+                and img is not None and img.is_cuda and img.dtype == torch.float32 and img.dim() == 4
+                and not img.requires_grad)
+
+    def _stage_inputs(self, batch) -> None:
+        for k, v in self.static_in.items():
+            if k == "image" and self._img_bf16:
+                from . import densenet_fused as dn
+                dn.image_to_act(batch[k], torch.bfloat16, out=v)
+            else:
+                v.copy_(batch[k], non_blocking=True)
+
     def _capture(self, batch) -> None:
         m = self.model
         self.static_in = {k: v.clone(memory_format=torch.preserve_format) for k, v in batch.items()}
+        self._img_bf16 = self._image_staged_bf16(batch)
+        if self._img_bf16:
+            from . import densenet_fused as dn
+            self.static_in["image"] = dn.image_to_act(batch["image"], torch.bfloat16)
+        self._in_sig = {k: (tuple(v.shape), v.dtype) for k, v in batch.items()}
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                # the captured step reads lr / betas / eps / wd from device memory
         torch.cuda.synchronize()
@@ -298,8 +328,7 @@ class TrainStep:
                 sink["static"] = True
 
     def _same_shapes(self, batch) -> bool:
-        return all(k in batch and batch[k].shape == v.shape and batch[k].dtype == v.dtype
-                   for k, v in self.static_in.items())
+        return all(k in batch and tuple(batch[k].shape) == sh and batch[k].dtype == dt for k, (sh, dt) in self._in_sig.items())
 
     # ------------------------------------------------------------------ call
     def _agree_sizes(self, batch) -> bool:
@@ -347,8 +376,7 @@ class TrainStep:
             self._all_regular = True
         if not self._same_shapes(batch) or (self.reducer is not None and not self._all_regular):
             return self._eager_ragged(batch)
-        for k, v in self.static_in.items():
-            v.copy_(batch[k], non_blocking=True)
+        self._stage_inputs(batch)
         if self.opt_in_graph:
             self.opt.sync_hyper()                # an LR schedule / param_groups edit reaches the replayed optimizer
         self.ga.replay()
