@@ -24,7 +24,11 @@
 // that mcl_launch_wrw_merge adds in fixed order: deterministic, no atomics.
 // Epilogue (through LDS, so that HBM sees 16-byte row chunks): + bias[n], exact-erf GELU (optionally also storing the
 // pre-activation), * gelu'(aux), + residual; bf16 or fp32 output.
+// Round 4: problems made of interior 256 x 256 tiles only (every ViT linear at batch 256: 50432 = 197 x 256 tokens) take
+// gemm_bf16_stag_kernel -- same tile, same fragments, same k order (bit-identical results), but the two wave groups run one
+// barrier apart over a four-slot half-K ring filled three ahead: +6...19 % on the ViT shapes (below).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -70,6 +74,13 @@ __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 
 __device__ __forceinline__ bf16x8 frag_kc(const unsigned char* tile, int row, int kk, int h) {
   const int c = (kk >> 3) + h;
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+// ---- k-contiguous HALF tile of the staggered ring: [128 rows][32 k] bf16 = 64-byte rows, chunk c (0..3) of row r at physical
+// chunk c ^ ((r >> 2) & 3): a ds_read_b128 lane group (16 lanes, rows {0-3, 12-15, 20-27} of one logical chunk) lands on the 16
+// distinct 16-byte slots of the 256-byte bank row (slot = 4 (r & 3) + physical chunk).
+__device__ __forceinline__ bf16x8 frag_kc32(const unsigned char* tile, int row, int kk, int h) {
+  const int c = (kk >> 3) + h;
+  return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
 }
 // ---- reduction-major tile: [64 k][128 cols] bf16 = 256-byte rows, chunk c of row r at c ^ ((r & 3) << 2); fragment =
 // 8 consecutive k of column cbase + (lane & 31) through the transposing read (see csrc/wrw_fused.hip frag_sw)
@@ -341,6 +352,220 @@ __global__ __launch_bounds__(256 * SUBS) void gemm_bf16_kernel(GemmB g) {
   }
 }
 
+// ---- staggered form of the 256 x 256 tile for problems made of interior tiles only (M, N multiples of 256, every K range a
+// multiple of 64): two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so that one group's MFMA
+// segment coincides with the other group's fragment reads + DMA issue.  LDS = ring of four half-K slots (32 k: 16 KB of A + 16 KB
+// of B) filled three ahead with counted waits.  Per half-tile x and wave:
+//     R(x):  vmcnt -> own pieces of x+1 landed | 12 fragment reads of x | 4 DMA pieces of x+3 | s_barrier
+//     M(x):  lgkmcnt(0) | setprio(1) | 16 MFMAs | setprio(0) | s_barrier
+// Group 1 executes one extra barrier up front, group 0 one at the end.  Hazards by barrier count (group 0: R(x) ends at barrier
+// 2x, M(x) at 2x+1; group 1 one later): the slot of x-1 is last read in group 1's R(x-1), which ends at 2x-1, and is refilled
+// (x+3) in R(x) segments, all after 2x-1; every wave's wait for x+1 sits in its R(x), before barrier 2x+1, and x+1 is first
+// read after 2x+1.  Same fragments, same k order as the lockstep kernel: bit-identical results.
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(512) void gemm_bf16_stag_kernel(GemmB g) {
+  constexpr int SUBS = 2;
+  constexpr int BM = 128 * SUBS, BN = 128 * SUBS;
+  constexpr int TILE_B = SUBS * SUB_B, STAGE_B = 2 * TILE_B;
+  constexpr int NI = 2 * SUBS;                 // 32-row blocks per wave
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];      // 2 stages x (A tile + B tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = SUBS == 2 ? wave >> 2 : wave >> 1, wn = SUBS == 2 ? wave & 3 : wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+  int b, ks, tx, ty;
+  if (g.tm >= 8) {
+    // XCD-aware decode (block id % 8 = XCD): row panel = (q / tn) * 8 + xcd, column tile = q % tn
+    const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
+    const int bid = blockIdx.x % per_batch;
+    b = blockIdx.x / per_batch;
+    const int xcd = bid & 7, q = bid >> 3;
+    ks = q % g.ksplit;
+    const int q2 = q / g.ksplit;
+    tx = q2 % g.tn;
+    ty = (q2 / g.tn) * 8 + xcd;
+    if (ty >= g.tm) return;
+  } else {                                     // few row panels (batched small problems): plain decode, no padding
+    const int per_batch = g.tm * g.tn * g.ksplit;
+    const int bid = blockIdx.x % per_batch;
+    b = blockIdx.x / per_batch;
+    ks = bid % g.ksplit;
+    const int q2 = bid / g.ksplit;
+    tx = q2 % g.tn;
+    ty = q2 / g.tn;
+  }
+  const int m0 = ty * BM, n0 = tx * BN;
+  const long long k_begin = (long long)ks * g.k_per_split;
+  const long long k_end = min((long long)g.K, k_begin + g.k_per_split);
+  const int nt = (int)((k_end - k_begin + BK - 1) / BK);
+  const int b1 = b / g.batch2, b2 = b % g.batch2;
+  const bf16_t* A = g.A + (long long)b1 * g.sAb + (long long)b2 * g.sAb2;
+  const bf16_t* B = g.B + (long long)b1 * g.sBb + (long long)b2 * g.sBb2;
+  const long long c_off = (long long)b1 * g.sCb + (long long)b2 * g.sCb2;
+  const unsigned lds_base = (unsigned)(size_t)MCL_LDSP(lds);
+
+
+  constexpr int HK = 32, HSUB = 8192, HOP = 2 * HSUB, SLOT = 2 * HOP;   // half-K, bytes per half sub-tile / operand / slot
+  const int nh = (int)((k_end - k_begin) / HK);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int grp = wave_s >> 2;
+  // DMA: a half sub-tile is 8 pieces of 1 KB; wave w moves piece (w & 7) of sub-tile 0 and of sub-tile 1 of both operands
+  const int pp = wave_s;
+  unsigned vA[2], vB[2];
+  {
+    const unsigned a0 = !A_KMAJOR ? (unsigned)((lane >> 2) * g.lda * 2) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3))) << 4)
+                                  : (unsigned)((lane >> 4) * g.lda * 2) + (unsigned)(((lane & 15) ^ (((lane >> 4) & 3) << 2)) << 4);
+    const unsigned b0 = !B_KMAJOR ? (unsigned)((lane >> 2) * g.ldb * 2) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3))) << 4)
+                                  : (unsigned)((lane >> 4) * g.ldb * 2) + (unsigned)(((lane & 15) ^ (((lane >> 4) & 3) << 2)) << 4);
+    vA[0] = a0; vA[1] = a0 + (unsigned)(!A_KMAJOR ? 256ll * g.lda : 256);
+    vB[0] = b0; vB[1] = b0 + (unsigned)(!B_KMAJOR ? 256ll * g.ldb : 256);
+  }
+  const unsigned char* baseA = reinterpret_cast<const unsigned char*>(
+      !A_KMAJOR ? A + (long long)(m0 + 16 * pp) * g.lda + k_begin : A + (k_begin + 4 * pp) * g.lda + m0);
+  const unsigned char* baseB = reinterpret_cast<const unsigned char*>(
+      !B_KMAJOR ? B + (long long)(n0 + 16 * pp) * g.ldb + k_begin : B + (k_begin + 4 * pp) * g.ldb + n0);
+  const long long stepA = !A_KMAJOR ? 2ll * HK : 2ll * HK * g.lda, stepB = !B_KMAJOR ? 2ll * HK : 2ll * HK * g.ldb;
+  auto dma_half = [&](int ht) {                       // 4 DMA instructions per wave
+    const unsigned char* pa = baseA + ht * stepA;
+    const unsigned char* pb = baseB + ht * stepB;
+    const unsigned d = lds_base + (ht & 3) * SLOT + pp * 1024;
+    glds16s(pa, vA[0], d);
+    glds16s(pb, vB[0], d + HOP);
+    glds16s(pa, vA[1], d + HSUB);
+    glds16s(pb, vB[1], d + HOP + HSUB);
+  };
+
+  f32x16 acc[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  for (int i = 0; i < 3 && i < nh; ++i) dma_half(i);
+  if (nh >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nh == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();         // the stagger: group 1 runs one barrier behind group 0
+  const int cb = (wn & 1) * 64;
+  for (int ht = 0; ht < nh; ++ht) {
+    // ---- R segment
+    if (ht + 1 < nh) {                                // own pieces of ht + 1 landed (younger ones may stay in flight)
+      if (ht + 2 < nh) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* tA = lds + (ht & 3) * SLOT + wm * HSUB;
+    const unsigned char* tB = lds + (ht & 3) * SLOT + HOP + (wn >> 1) * HSUB;
+    bf16x8 fa[2][NI], fb[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kk = 16 * q;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (!B_KMAJOR) fb[q][j] = frag_kc32(tB, cb + j * 32 + l31, kk, h);
+        else fb[q][j] = frag_km(tB, kk + 8 * h, cb + j * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (!A_KMAJOR) fa[q][i] = frag_kc32(tA, i * 32 + l31, kk, h);
+        else fa[q][i] = frag_km(tA, kk + 8 * h, i * 32, lane);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ht + 3 < nh) dma_half(ht + 3);                // into the slot of ht - 1, whose last reader finished before the last barrier
+    __builtin_amdgcn_sched_barrier(0);                // (the 4 pieces spread among the MFMAs below instead: measured 2-5 % slower)
+    __builtin_amdgcn_s_barrier();
+    // ---- M segment
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();         // group 0 catches up: every wave has executed 2 nh + 2 barriers
+  __syncthreads();                                   // every wave is done with the operand stages: reuse them
+
+  // ---- epilogue through LDS in halves of 64 rows: wave tile half 64 x 64 fp32 (16 KB per wave = the operand stages)
+  constexpr int EP = 64;
+  float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
+  const int cch = lane & 7;                          // 8 chunks of 8 columns per 64-column row
+#pragma unroll 1
+  for (int half = 0; half < SUBS; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          et[row * EP + j * 32 + l31] = (half == 0 ? acc[ii][j][r] : acc[NI - 2 + ii][j][r]) * g.alpha;
+        }
+    // (a wave reads back only what it wrote: no workgroup barrier needed; LDS ops of a wave complete in order)
+    const int mw = m0 + wm * (64 * SUBS) + half * 64, nw = n0 + wn * 64;
+#pragma unroll 2
+    for (int rr = lane >> 3; rr < 64; rr += 8) {
+      const int m = mw + rr, n = nw + cch * 8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < g.N) v[e] += g.bias[n + e];
+      }
+      if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
+        float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
+        if (n + 8 <= g.N) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
+        }
+        continue;
+      }
+      if (g.pre_out) {
+        *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      }
+      if (g.gelu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      }
+      if (g.gelu_bwd) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] *= gelu_g(bf_lo(a[e]));
+          v[2 * e + 1] *= gelu_g(bf_hi(a[e]));
+        }
+      }
+      if (g.resid) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += bf_lo(a[e]);
+          v[2 * e + 1] += bf_hi(a[e]);
+        }
+      }
+      // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
+      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
+          u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    }
+  }
+}
+
+
 }  // namespace
 
 // flags: bit 0 A reduction-major, bit 1 B reduction-major, bit 2 GELU, bit 3 multiply by gelu'(aux), bit 4 fp32 output
@@ -404,10 +629,20 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
     MCL_ATTR(false, false, 1); MCL_ATTR(false, true, 1); MCL_ATTR(true, false, 1); MCL_ATTR(true, true, 1);
     MCL_ATTR(false, false, 2); MCL_ATTR(false, true, 2); MCL_ATTR(true, false, 2); MCL_ATTR(true, true, 2);
 #undef MCL_ATTR
+#define MCL_ATTR_S(AK, BKM) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_stag_kernel<AK, BKM>), \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * SUB_B)
+    MCL_ATTR_S(false, false); MCL_ATTR_S(false, true); MCL_ATTR_S(true, false); MCL_ATTR_S(true, true);
+#undef MCL_ATTR_S
   }
+  // the staggered kernel where every tile is interior (MCL_GEMM_STAG=0: the lockstep kernel; bit-identical results; read per
+  // launch -- tests flip it inside one process)
+  const char* e_stag = getenv("MCL_GEMM_STAG");
+  const bool stag = subs == 2 && !(e_stag && e_stag[0] == '0') && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && kps % 64 == 0 &&
+                    lda * 512 < (1ll << 31) && ldb * 512 < (1ll << 31);
 #define MCL_LAUNCH(AK, BKM)                                                                                          \
   do {                                                                                                               \
-    if (subs == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, 2>), grid, dim3(512), lds_bytes, st, g);           \
+    if (stag) hipLaunchKernelGGL((gemm_bf16_stag_kernel<AK, BKM>), grid, dim3(512), lds_bytes, st, g);              \
+    else if (subs == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, 2>), grid, dim3(512), lds_bytes, st, g);           \
     else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKM, 1>), grid, dim3(256), lds_bytes, st, g);                     \
   } while (0)
   if (!akm && !bkm) MCL_LAUNCH(false, false);

@@ -38,6 +38,70 @@ def test_gemm_bf16_layouts(M, N, K, akm, bkm):
         assert (C[:, (N + 7) // 8 * 8:] == 7.0).all()               # columns beyond the padded row are untouched
 
 
+@pytest.mark.parametrize("M,N,K,akm,bkm,mode", [
+    (1024, 768, 768, 0, 0, "bias"), (1024, 2304, 64, 0, 0, "plain"), (768, 1024, 128, 0, 1, "gelu_bwd"),
+    (1024, 768, 192, 0, 1, "resid"), (2304, 1024, 256, 1, 0, "bias_gelu_pre"), (768, 3072, 8192, 1, 1, "f32_splitk"),
+    (1024, 1024, 4096, 1, 1, "f32")])
+def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monkeypatch):
+    """gemm_bf16_stag_kernel (problems of interior 256 x 256 tiles: two wave groups one barrier apart over a four-slot half-K
+    ring) against the lockstep kernel (MCL_GEMM_STAG=0): same fragments in the same k order and the same epilogue, so equal
+    bit for bit -- all four operand layouts, 1 / 2 / 3 / many half-tiles (shorter than, equal to and longer than the ring),
+    every epilogue form, split-K slabs; and against fp64."""
+    from mclstexp_amd import vit_fused as vf
+    A = _r(K if akm else M, M if akm else K, seed=21).to(BF).to(DEV)
+    B = _r(K if bkm else N, N if bkm else K, seed=22, scale=0.3).to(BF).to(DEV)
+    bias = _r(N, seed=23).to(DEV)
+    res = _r(M, N, seed=24).to(BF).to(DEV)
+    aux = _r(M, N, seed=25, scale=2.0).to(BF).to(DEV)
+    flags = akm * vf.A_KM | bkm * vf.B_KM
+    outs = []
+    for stag in ("1", "0"):
+        monkeypatch.setenv("MCL_GEMM_STAG", stag)
+        f32 = mode.startswith("f32")
+        C = torch.full((M, N), 3.0, device=DEV, dtype=torch.float32 if f32 else BF)
+        pre = torch.zeros((M, N), device=DEV, dtype=BF)
+        kw = dict(flags=flags)
+        if mode == "plain":
+            kw.update(alpha=0.5)
+        elif mode == "bias":
+            kw.update(bias=bias)
+        elif mode == "bias_gelu_pre":
+            kw.update(flags=flags | vf.GELU, bias=bias, pre_out=pre, ldp=N)
+        elif mode == "resid":
+            kw.update(bias=bias, resid=res, ldr=N)
+        elif mode == "gelu_bwd":
+            kw.update(flags=flags | vf.GELU_BWD, aux=aux, ldaux=N)
+        elif mode == "f32":
+            kw.update(flags=flags | vf.OUT_F32)
+        else:
+            kw.update(flags=flags | vf.OUT_F32, ksplit=8, accumulate=True)
+        vf.gemm(A, B, C, M, N, K, A.shape[1], B.shape[1], N, **kw)
+        torch.cuda.synchronize()
+        outs.append((C, pre))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    a = (A.t() if akm else A).double()
+    b = (B if bkm else B.t()).double()
+    ref = a @ b
+    if mode == "plain":
+        ref = 0.5 * ref
+    elif mode == "bias":
+        ref = ref + bias.double()
+    elif mode == "bias_gelu_pre":
+        assert_close(outs[0][1].float().cpu(), (ref + bias.double()).cpu(), 3e-3, 2 ** -7, what="staggered pre-activation")
+        ref = torch.nn.functional.gelu(ref + bias.double())
+    elif mode == "resid":
+        ref = ref + bias.double() + res.double()
+    elif mode == "gelu_bwd":
+        xa = aux.double().requires_grad_(True)
+        torch.nn.functional.gelu(xa).sum().backward()
+        ref = ref * xa.grad
+    elif mode == "f32_splitk":
+        ref = ref + 3.0
+    tol = (2e-4, 2e-3) if mode.startswith("f32") else (4e-3, 2 ** -6)
+    assert_close(outs[0][0].float().cpu(), ref.cpu(), tol[0], tol[1], what=f"staggered gemm {mode}")
+
+
 def test_gemm_bf16_epilogues_and_batch():
     """bias + GELU (+ stored pre-activation), gelu' multiply, residual add, two-level batch with strides, fp32 output,
     split-K with accumulation (deterministic)."""
