@@ -111,10 +111,118 @@ struct GemmB {
   long long k_per_split, slab_stride;
 };
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU (exact-erf form, nn.GELU's default) and its derivative for bf16 outputs.  Phi(x) = 0.5 erfc(-x / sqrt 2) through Abramowitz &
+// Stegun 7.1.26 (erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7 on erf): one
+// v_rcp_f32, one v_exp_f32 and 9 multiply-adds instead of libdevice's erff (~40 instructions with range branches) -- the epilogue of
+// the ViT's fc1 (50 432 x 3072 outputs) spent more time in erff than the tile in its K loop.  The error is 2^-14 of the bf16
+// rounding that follows; the fp32 paths (csrc/gemm.hip, the spot encoder) keep erff.  exp(-z^2) = exp(-x^2 / 2) is shared with
+// the density term of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& ex) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  ex = __expf(-z * z);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float half_erfc = 0.5f * poly * ex;
+  Phi = x < 0.0f ? half_erfc : 1.0f - half_erfc;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float Phi, ex;
+  gelu_parts(x, Phi, ex);
+  return x * Phi;
+}
 __device__ __forceinline__ float gelu_g(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float Phi, ex;
+  gelu_parts(x, Phi, ex);
+  return fmaf(x * 0.39894228040143267794f, ex, Phi);
+}
+
+// ---- epilogue of a wave's (32 NI) x 64 accumulator tile, through LDS in halves of 64 rows (64 x 64 fp32 = 16 KB per wave: the
+// operand stages, free after the K loop's last barrier; a wave reads back only what it wrote, so no workgroup barrier).
+// Loads, stores and LDS-DMA pieces retire in issue order on one counter, so a load waited for after a store drains that store:
+// the bias is loaded once before the first store, and the residual / gelu' operand rows of iteration i + 1 are requested before
+// the stores of iteration i (round 4; the per-iteration loads used to wait out the previous iteration's store acknowledgements).
+template <int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmB& g, f32x16 (&acc)[NI][2], unsigned char* lds, int wave, int lane,
+                                              int mw0, int nw, int ks, long long c_off, int b1) {
+  constexpr int EP = 64;
+  const int h = lane >> 5, l31 = lane & 31;
+  float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
+  const int cch = lane & 7;                          // 8 chunks of 8 columns per 64-column row
+  const int n = nw + cch * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = (g.bias && n + e < g.N) ? g.bias[n + e] : 0.0f;
+  const bool has_x = g.gelu_bwd || g.resid;
+  auto load_x = [&](int m, u32x4& xa, u32x4& xr) {
+    if (m >= g.M || n >= g.N) return;
+    if (g.gelu_bwd) xa = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
+    if (g.resid) xr = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
+  };
+#pragma unroll 1
+  for (int half = 0; half < NI / 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          et[row * EP + j * 32 + l31] = (half == 0 ? acc[ii][j][r] : acc[NI - 2 + ii][j][r]) * g.alpha;
+        }
+    const int mw = mw0 + half * 64;
+    u32x4 xa = {0, 0, 0, 0}, xr = {0, 0, 0, 0}, xa_n = {0, 0, 0, 0}, xr_n = {0, 0, 0, 0};
+    if (has_x) load_x(mw + (lane >> 3), xa, xr);
+#pragma unroll 2
+    for (int rr = lane >> 3; rr < 64; rr += 8) {
+      const int m = mw + rr;
+      if (has_x && rr + 8 < 64) load_x(m + 8, xa_n, xr_n);
+      if (m < g.M && n < g.N) {
+        const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
+        const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (g.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        }
+        if (g.out_f32) {                               // split-K slab / fp32 result: no activation
+          float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
+          if (n + 8 <= g.N) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
+          }
+        } else {
+          if (g.pre_out) {
+            *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+                u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+          }
+          if (g.gelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          }
+          if (g.gelu_bwd) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] *= gelu_g(bf_lo(xa[e]));
+              v[2 * e + 1] *= gelu_g(bf_hi(xa[e]));
+            }
+          }
+          if (g.resid) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] += bf_lo(xr[e]);
+              v[2 * e + 1] += bf_hi(xr[e]);
+            }
+          }
+          // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
+              u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        }
+      }
+      xa = xa_n; xr = xr_n;
+    }
+  }
 }
 
 // SUBS = 2: 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each) -- the large linears.  SUBS = 1: 128 x 128 tile, 4 waves
@@ -282,74 +390,7 @@ __global__ __launch_bounds__(256 * SUBS) void gemm_bf16_kernel(GemmB g) {
   }
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
 
-  // ---- epilogue through LDS in halves of 64 rows: wave tile half 64 x 64 fp32 (16 KB per wave = the operand stages)
-  constexpr int EP = 64;
-  float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
-  const int cch = lane & 7;                          // 8 chunks of 8 columns per 64-column row
-#pragma unroll 1
-  for (int half = 0; half < SUBS; ++half) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          et[row * EP + j * 32 + l31] = (half == 0 ? acc[ii][j][r] : acc[NI - 2 + ii][j][r]) * g.alpha;
-        }
-    // (a wave reads back only what it wrote: no workgroup barrier needed; LDS ops of a wave complete in order)
-    const int mw = m0 + wm * (64 * SUBS) + half * 64, nw = n0 + wn * 64;
-#pragma unroll 2
-    for (int rr = lane >> 3; rr < 64; rr += 8) {
-      const int m = mw + rr, n = nw + cch * 8;
-      if (m >= g.M || n >= g.N) continue;
-      const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (g.bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < g.N) v[e] += g.bias[n + e];
-      }
-      if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
-        float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
-        if (n + 8 <= g.N) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
-        }
-        continue;
-      }
-      if (g.pre_out) {
-        *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
-            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-      }
-      if (g.gelu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-      }
-      if (g.gelu_bwd) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] *= gelu_g(bf_lo(a[e]));
-          v[2 * e + 1] *= gelu_g(bf_hi(a[e]));
-        }
-      }
-      if (g.resid) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] += bf_lo(a[e]);
-          v[2 * e + 1] += bf_hi(a[e]);
-        }
-      }
-      // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
-          u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-    }
-  }
+  gemm_epilogue<NI>(g, acc, lds, wave, lane, m0 + wm * (64 * SUBS), n0 + wn * 64, ks, c_off, b1);
 }
 
 // ---- staggered form of the 256 x 256 tile for problems made of interior tiles only (M, N multiples of 256, every K range a
@@ -357,7 +398,7 @@ __global__ __launch_bounds__(256 * SUBS) void gemm_bf16_kernel(GemmB g) {
 // segment coincides with the other group's fragment reads + DMA issue.  LDS = ring of four half-K slots (32 k: 16 KB of A + 16 KB
 // of B) filled three ahead with counted waits.  Per half-tile x and wave:
 //     R(x):  vmcnt -> own pieces of x+1 landed | 12 fragment reads of x | 4 DMA pieces of x+3 | s_barrier
-//     M(x):  lgkmcnt(0) | setprio(1) | 16 MFMAs | setprio(0) | s_barrier
+//     M(x):  lgkmcnt(0) | 16 MFMAs | s_barrier      (s_setprio around the MFMAs: measured 0-5 % slower; finer phases of 8 MFMAs: no gain)
 // Group 1 executes one extra barrier up front, group 0 one at the end.  Hazards by barrier count (group 0: R(x) ends at barrier
 // 2x, M(x) at 2x+1; group 1 one later): the slot of x-1 is last read in group 1's R(x-1), which ends at 2x-1, and is refilled
 // (x+3) in R(x) segments, all after 2x-1; every wave's wait for x+1 sits in its R(x), before barrier 2x+1, and x+1 is first
@@ -480,7 +521,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_stag_kernel(GemmB g) {
     // ---- M segment
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -488,81 +528,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_stag_kernel(GemmB g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();         // group 0 catches up: every wave has executed 2 nh + 2 barriers
   __syncthreads();                                   // every wave is done with the operand stages: reuse them
 
-  // ---- epilogue through LDS in halves of 64 rows: wave tile half 64 x 64 fp32 (16 KB per wave = the operand stages)
-  constexpr int EP = 64;
-  float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
-  const int cch = lane & 7;                          // 8 chunks of 8 columns per 64-column row
-#pragma unroll 1
-  for (int half = 0; half < SUBS; ++half) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          et[row * EP + j * 32 + l31] = (half == 0 ? acc[ii][j][r] : acc[NI - 2 + ii][j][r]) * g.alpha;
-        }
-    // (a wave reads back only what it wrote: no workgroup barrier needed; LDS ops of a wave complete in order)
-    const int mw = m0 + wm * (64 * SUBS) + half * 64, nw = n0 + wn * 64;
-#pragma unroll 2
-    for (int rr = lane >> 3; rr < 64; rr += 8) {
-      const int m = mw + rr, n = nw + cch * 8;
-      if (m >= g.M || n >= g.N) continue;
-      const float4 v0 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(et + rr * EP + cch * 8 + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (g.bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < g.N) v[e] += g.bias[n + e];
-      }
-      if (g.out_f32) {                                 // split-K slab / fp32 result: no activation
-        float* o = reinterpret_cast<float*>(g.C) + (long long)ks * g.slab_stride + c_off + (long long)m * g.ldc + n;
-        if (n + 8 <= g.N) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
-        }
-        continue;
-      }
-      if (g.pre_out) {
-        *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
-            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-      }
-      if (g.gelu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-      }
-      if (g.gelu_bwd) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] *= gelu_g(bf_lo(a[e]));
-          v[2 * e + 1] *= gelu_g(bf_hi(a[e]));
-        }
-      }
-      if (g.resid) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(g.resid + (long long)b1 * g.sRb + (long long)m * g.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[2 * e] += bf_lo(a[e]);
-          v[2 * e + 1] += bf_hi(a[e]);
-        }
-      }
-      // 16-byte store; columns beyond N inside the chunk fall into the row's padding (ldc >= round_up(N, 8) is required)
-      *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(g.C) + c_off + (long long)m * g.ldc + n) =
-          u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-    }
-  }
+  gemm_epilogue<NI>(g, acc, lds, wave, lane, m0 + wm * (64 * SUBS), n0 + wn * 64, ks, c_off, b1);
 }
 
 
