@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 4
+#define MCL_ABI_VERSION 5
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -216,6 +216,14 @@ int mcl_colsum_bf16(const void* x, int64_t ldx, int64_t rows, int32_t D, float* 
  * backward in place on dP: dS = P * (dP - sum P dP) * scale.                                                        */
 int mcl_softmax_bf16_fwd(void* s, int64_t ld, int64_t rows, int32_t n, mcl_stream_t stream);
 int mcl_softmax_bf16_bwd(const void* P, void* dP, int64_t ld, int64_t rows, int32_t n, float scale, mcl_stream_t stream);
+/* Fused attention core of the ViT encoder (csrc/vit_attention.hip; replaces the reference's timm Attention.forward core,
+ * /root/reference/model.py:104-116 -> timm vision_transformer.Attention: softmax(q k^T scale) v per image and head), bf16,
+ * head dimension 64, T <= 224 tokens, no (B heads, T, T) tensor in HBM.  qkv (B, T, 3 heads 64) bf16 as the qkv linear
+ * writes it; o / dout (B, T, heads 64) bf16; lse, dsum (B heads, T) fp32 (dsum is scratch written by the backward);
+ * dqkv (B, T, 3 heads 64) bf16, every element written.  T > 224 -> MCL_EUNSUPPORTED (callers keep the GEMM + softmax path). */
+int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t T, int32_t heads, float scale, mcl_stream_t stream);
+int mcl_vit_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* dsum, void* dqkv, int32_t B,
+                     int32_t T, int32_t heads, float scale, mcl_stream_t stream);
 /* Patch extraction for the patch-embedding GEMM: out[(b, py, px)][c*p*p + iy*p + ix] (bf16) from an fp32 image
  * addressed by element strides (sb, sc, sy, sx): NCHW or channels-last.                                            */
 int mcl_vit_patchify(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H, int32_t W,

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib: Optional[C.CDLL] = None
 
@@ -104,6 +104,8 @@ PROTOTYPES = {
     "mcl_softmax_bf16_fwd": [c_p, c_l, c_l, c_i, c_p],
     "mcl_softmax_bf16_bwd": [c_p, c_p, c_l, c_l, c_i, c_f, c_p],
     "mcl_vit_patchify": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_vit_attn_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "mcl_vit_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "mcl_quant_e4m3_rows": [c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p],
     "mcl_dequant_e4m3_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_l, c_p],
     "mcl_infonce_fp8_workspace_bytes": [c_i, c_i],

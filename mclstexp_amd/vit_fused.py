@@ -64,6 +64,7 @@ def _w16(w: Tensor) -> Tensor:
     return w.detach().to(BF).contiguous()
 
 
+FUSED_ATTN = os.environ.get("MCL_VIT_FUSED_ATTN", "1") != "0"            # 0: batched GEMMs + softmax launches (A/B, T > 224)
 JOIN_EVERY = int(os.environ.get("MCL_VIT_JOIN_EVERY", "4"))              # encoder blocks between joins of the side stream
 KSPLIT_TARGET = int(os.environ.get("MCL_VIT_KSPLIT_TARGET", "128"))     # workgroups a split-K weight gradient aims for (side lane: 60.5 ms/step at 256, 59.7 at 128)
 
@@ -186,18 +187,25 @@ class ViTFn(torch.autograd.Function):
         x[:, 0] = (vit.cls_token.detach().reshape(D) + vit.pos_embed.detach().reshape(T, D)[0]).to(BF)
         saved = []
         scale = dh ** -0.5
+        fused_attn = FUSED_ATTN and dh == 64 and T <= 224
         for blk in vit.blocks:
             a, m = blk.attn, blk.mlp
             u1, mean1, rstd1 = ln_fwd(x, blk.norm1, M)
             qkv = torch.empty((B, T, 3 * D), device=dev, dtype=BF)
             gemm(u1, _w16(a.qkv.weight), qkv, M, 3 * D, D, D, D, 3 * D, bias=a.qkv.bias)
-            P = torch.empty((B * heads, T, Tp), device=dev, dtype=BF)
-            gemm(qkv, qkv, P, T, T, dh, 3 * D, 3 * D, Tp, b_off=D, batch=B * heads, batch2=heads,
-                 sA=(T * 3 * D, dh), sB=(T * 3 * D, dh), sC=(heads * T * Tp, T * Tp), alpha=scale)
-            check(L.mcl_softmax_bf16_fwd(P.data_ptr(), Tp, B * heads * T, T, _st()), "mcl_softmax_bf16_fwd")
             o = torch.empty((B, T, D), device=dev, dtype=BF)
-            gemm(P, qkv, o, T, dh, T, Tp, 3 * D, D, flags=B_KM, b_off=2 * D, batch=B * heads, batch2=heads,
-                 sA=(heads * T * Tp, T * Tp), sB=(T * 3 * D, dh), sC=(T * D, dh))
+            if fused_attn:
+                # softmax(q k^T scale) v per image and head in ONE launch, no (B heads, T, T) tensor (csrc/vit_attention.hip);
+                # P below is the row log-sum-exp, all the backward needs
+                P = torch.empty((B * heads, T), device=dev, dtype=torch.float32)
+                check(L.mcl_vit_attn_fwd(qkv.data_ptr(), o.data_ptr(), P.data_ptr(), B, T, heads, scale, _st()), "mcl_vit_attn_fwd")
+            else:
+                P = torch.empty((B * heads, T, Tp), device=dev, dtype=BF)
+                gemm(qkv, qkv, P, T, T, dh, 3 * D, 3 * D, Tp, b_off=D, batch=B * heads, batch2=heads,
+                     sA=(T * 3 * D, dh), sB=(T * 3 * D, dh), sC=(heads * T * Tp, T * Tp), alpha=scale)
+                check(L.mcl_softmax_bf16_fwd(P.data_ptr(), Tp, B * heads * T, T, _st()), "mcl_softmax_bf16_fwd")
+                gemm(P, qkv, o, T, dh, T, Tp, 3 * D, D, flags=B_KM, b_off=2 * D, batch=B * heads, batch2=heads,
+                     sA=(heads * T * Tp, T * Tp), sB=(T * 3 * D, dh), sC=(T * D, dh))
             x1 = torch.empty_like(x)
             gemm(o, _w16(a.proj.weight), x1, M, D, D, D, D, D, bias=a.proj.bias, resid=x, ldr=D, sRb=0)
             u2, mean2, rstd2 = ln_fwd(x1, blk.norm2, M)
@@ -213,6 +221,7 @@ class ViTFn(torch.autograd.Function):
         ctx.save_for_backward(patches, *saved)
         ctx.vit = vit
         ctx.dims = (B, T, D, K0, heads, dh, Tp, npatch)
+        ctx.fused_attn = fused_attn
         return feat
 
     @staticmethod
@@ -250,19 +259,25 @@ class ViTFn(torch.autograd.Function):
             # attention core, per (image, head)
             dqkv = torch.empty((B, T, 3 * D), device=dev, dtype=BF)
             nb = B * heads
-            sP = (heads * T * Tp, T * Tp)
-            sQ = (T * 3 * D, dh)
-            sO = (T * D, dh)
-            gemm(P, do, dqkv, T, dh, T, Tp, D, 3 * D, flags=A_KM | B_KM, c_off=2 * D, batch=nb, batch2=heads,
-                 sA=sP, sB=sO, sC=sQ)                                                   # dV = P^T dO
-            dP = torch.empty((B * heads, T, Tp), device=dev, dtype=BF)
-            gemm(do, qkv, dP, T, T, dh, D, 3 * D, Tp, b_off=2 * D, batch=nb, batch2=heads, sA=sO, sB=sQ, sC=sP)   # dO V^T
-            check(L.mcl_softmax_bf16_bwd(P.data_ptr(), dP.data_ptr(), Tp, B * heads * T, T, scale, _st()),
-                  "mcl_softmax_bf16_bwd")
-            gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=B_KM, b_off=D, batch=nb, batch2=heads,
-                 sA=sP, sB=sQ, sC=sQ)                                                   # dQ = dS K
-            gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=A_KM | B_KM, c_off=D, batch=nb, batch2=heads,
-                 sA=sP, sB=sQ, sC=sQ)                                                   # dK = dS^T Q
+            if ctx.fused_attn:
+                # P = the forward's row log-sum-exp: dq, dk, dv in two launches, probabilities recomputed on chip
+                dsum = torch.empty((nb, T), device=dev, dtype=torch.float32)
+                check(L.mcl_vit_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), P.data_ptr(), dsum.data_ptr(),
+                                         dqkv.data_ptr(), B, T, heads, scale, _st()), "mcl_vit_attn_bwd")
+            else:
+                sP = (heads * T * Tp, T * Tp)
+                sQ = (T * 3 * D, dh)
+                sO = (T * D, dh)
+                gemm(P, do, dqkv, T, dh, T, Tp, D, 3 * D, flags=A_KM | B_KM, c_off=2 * D, batch=nb, batch2=heads,
+                     sA=sP, sB=sO, sC=sQ)                                                   # dV = P^T dO
+                dP = torch.empty((B * heads, T, Tp), device=dev, dtype=BF)
+                gemm(do, qkv, dP, T, T, dh, D, 3 * D, Tp, b_off=2 * D, batch=nb, batch2=heads, sA=sO, sB=sQ, sC=sP)   # dO V^T
+                check(L.mcl_softmax_bf16_bwd(P.data_ptr(), dP.data_ptr(), Tp, B * heads * T, T, scale, _st()),
+                      "mcl_softmax_bf16_bwd")
+                gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=B_KM, b_off=D, batch=nb, batch2=heads,
+                     sA=sP, sB=sQ, sC=sQ)                                                   # dQ = dS K
+                gemm(dP, qkv, dqkv, T, dh, T, Tp, 3 * D, 3 * D, flags=A_KM | B_KM, c_off=D, batch=nb, batch2=heads,
+                     sA=sP, sB=sQ, sC=sQ)                                                   # dK = dS^T Q
             _param_grads(dqkv, u1, a.qkv, M, grads)
             du1 = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dqkv, _w16(a.qkv.weight), du1, M, D, 3 * D, 3 * D, D, D, flags=B_KM)

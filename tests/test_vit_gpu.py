@@ -102,6 +102,45 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
     assert_close(outs[0][0].float().cpu(), ref.cpu(), tol[0], tol[1], what=f"staggered gemm {mode}")
 
 
+@pytest.mark.parametrize("B,T,heads", [(2, 197, 12), (3, 50, 2), (2, 33, 1), (1, 224, 2), (2, 7, 3)])
+def test_vit_fused_attention_vs_fp64(B, T, heads):
+    """csrc/vit_attention.hip (softmax(q k^T scale) v per image and head, forward + dq / dk / dv, no probability tensor in HBM)
+    against fp64 autograd on the same bf16 qkv / dout values: o and the row log-sum-exp, and the three gradients -- ragged
+    token counts (197, 50, 33, 7: partial 32-blocks), the 224-token limit, several heads.  bf16 outputs: tolerances are the
+    output rounding (2^-8 relative) plus the bf16 rounding of P / dS inside the second product."""
+    from mclstexp_amd import _lib
+    from mclstexp_amd._lib import check
+    L = _lib.lib()
+    D = heads * 64
+    scale = 64 ** -0.5
+    qkv = _r(B, T, 3 * D, seed=31, scale=2.0).to(BF).to(DEV)
+    dout = _r(B, T, D, seed=32).to(BF).to(DEV)
+    o = torch.zeros((B, T, D), device=DEV, dtype=BF)
+    lse = torch.zeros((B * heads, T), device=DEV, dtype=torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    check(L.mcl_vit_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, T, heads, scale, st), "fwd")
+    dqkv = torch.full((B, T, 3 * D), 7.0, device=DEV, dtype=BF)
+    dsum = torch.zeros((B * heads, T), device=DEV, dtype=torch.float32)
+    check(L.mcl_vit_attn_bwd(qkv.data_ptr(), o.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(), dqkv.data_ptr(),
+                             B, T, heads, scale, st), "bwd")
+    torch.cuda.synchronize()
+    x = qkv.double().cpu().requires_grad_(True)
+    q, k, v = [x[..., i * D:(i + 1) * D].reshape(B, T, heads, 64).permute(0, 2, 1, 3) for i in range(3)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    ref_lse = torch.logsumexp(s, dim=-1)
+    ref_o = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B, T, D)
+    ref_o.backward(dout.double().cpu())
+    om = float(ref_o.detach().abs().max())
+    assert_close(o.float().cpu(), ref_o.detach(), 6e-3 * om, 2 ** -7, what="o")
+    assert_close(lse.cpu(), ref_lse.detach().reshape(B * heads, T), 2e-4, 1e-5, what="lse")
+    g = x.grad
+    for i, name in enumerate(("dq", "dk", "dv")):
+        ref = g[..., i * D:(i + 1) * D]
+        mx = float(ref.abs().max())
+        assert_close(dqkv[..., i * D:(i + 1) * D].float().cpu(), ref, 1.5e-2 * mx, 2 ** -6, what=name)
+    assert torch.isfinite(dqkv.float()).all()
+
+
 def test_gemm_bf16_epilogues_and_batch():
     """bias + GELU (+ stored pre-activation), gelu' multiply, residual add, two-level batch with strides, fp32 output,
     split-K with accumulation (deterministic)."""
