@@ -43,6 +43,20 @@ struct mcl_device_once {
   }
 };
 // environment overrides of grid sizes: never below 1 (atoi of garbage / "0" / a negative value would launch a zero-size grid)
+// compute units of the current device (cached per device id; 256 on MI355X): the grid of persistent kernels
+static inline int mcl_cu_count() {
+  static int cached[64];
+  int d = 0;
+  (void)hipGetDevice(&d);
+  if (d < 0 || d >= 64) d = 0;
+  if (cached[d] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cached[d] = n;
+  }
+  return cached[d];
+}
+
 static inline int mcl_env_grid(const char* value, int dflt) {
   if (!value) return dflt;
   const int v = atoi(value);

@@ -47,28 +47,49 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
-// ---- fill a row-major tile [nrows32][64] from src rows (row stride ld elements, column offset applied by the caller); rows >= T zero
-__device__ __forceinline__ void fill_rows(unsigned char* tile, const bf16_t* __restrict__ src, long long ld, int T, int nrows, int tid,
-                                          int nthreads) {
-  for (int i = tid; i < nrows * 8; i += nthreads) {
-    const int row = i >> 3, c = i & 7;
-    u32x4 v = {0, 0, 0, 0};
-    if (row < T) v = *reinterpret_cast<const u32x4*>(src + (long long)row * ld + 8 * c);
-    *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+// ---- tile fills in two phases so that EVERY global load of a workgroup's prologue is in flight before the first LDS write waits
+// for one: thread t owns the 16-byte chunks t, t + 512, t + 1024, t + 1536 of a [rows][64] source (rows <= 224: 1792 chunks).
+constexpr int FILL_IT = 4;
+struct Chunks { u32x4 v[FILL_IT]; };
+__device__ __forceinline__ void load_chunks(Chunks& ch, const bf16_t* __restrict__ src, long long ld, int T, int tid) {
+#pragma unroll
+  for (int j = 0; j < FILL_IT; ++j) {
+    const int i = tid + 512 * j, row = i >> 3, c = i & 7;
+    ch.v[j] = u32x4{0, 0, 0, 0};
+    if (row < T) ch.v[j] = *reinterpret_cast<const u32x4*>(src + (long long)row * ld + 8 * c);
   }
 }
-// ---- fill a transposed tile [64][TP]: element (d, row) = src[row][d]; columns >= T zero (up to ncols)
-__device__ __forceinline__ void fill_transposed(unsigned char* tile, const bf16_t* __restrict__ src, long long ld, int T, int ncols,
-                                                int tid, int nthreads) {
-  bf16_t* t = reinterpret_cast<bf16_t*>(tile);
-  for (int i = tid; i < ncols * 8; i += nthreads) {
-    const int row = i >> 3, c = i & 7;
-    u32x4 v = {0, 0, 0, 0};
-    if (row < T) v = *reinterpret_cast<const u32x4*>(src + (long long)row * ld + 8 * c);
+// row-major tile [nrows][64]; rows >= T zero
+__device__ __forceinline__ void store_rows(unsigned char* tile, const Chunks& ch, int nrows, int tid) {
+#pragma unroll
+  for (int j = 0; j < FILL_IT; ++j) {
+    const int i = tid + 512 * j, row = i >> 3, c = i & 7;
+    if (row < nrows) *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = ch.v[j];
+  }
+}
+// transposed tile [64][TP]: element (d, row) = src[row][d]; columns T .. ncols - 1 zero.  Lanes l and l ^ 8 hold the same chunk of
+// two adjacent rows (row = chunk index >> 3): they exchange their dwords so that each writes FOUR dwords (row pair packed) for half
+// of the chunk's eight d -- instead of eight 2-byte stores per lane, which collide on banks and on half-dwords.
+__device__ __forceinline__ void store_transposed(unsigned char* tile, const Chunks& ch, int ncols, int tid) {
+  unsigned* t32 = reinterpret_cast<unsigned*>(tile);
+#pragma unroll
+  for (int j = 0; j < FILL_IT; ++j) {
+    const int i = tid + 512 * j, row = i >> 3, c = i & 7, p = row & 1;
+    unsigned mine[4], other[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      t[(8 * c + 2 * e) * TP + row] = (bf16_t)(v[e] & 0xFFFFu);
-      t[(8 * c + 2 * e + 1) * TP + row] = (bf16_t)(v[e] >> 16);
+      mine[e] = ch.v[j][e];
+      other[e] = __shfl_xor(mine[e], 8);
+    }
+    if (row < ncols) {                                // (ncols is a multiple of 32: both rows of a pair exist together)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned ev = p ? other[2 * p + u] : mine[2 * p + u];      // the even row's dword (d = 8c + 4p + 2u, + 1)
+        const unsigned od = p ? mine[2 * p + u] : other[2 * p + u];
+        const int d = 8 * c + 4 * p + 2 * u, r2 = (row & ~1) >> 1;
+        t32[(d * TP) / 2 + r2] = (ev & 0xFFFFu) | (od << 16);
+        t32[((d + 1) * TP) / 2 + r2] = (ev >> 16) | (od & 0xFFFF0000u);
+      }
     }
   }
 }
@@ -124,83 +145,112 @@ __device__ __forceinline__ void store_strip(const f32x16 (&acc)[2], unsigned cha
 }
 
 // ================================================================ forward
+// Persistent over (image, head) items: the next item's K / V chunks and query fragments are requested into registers right after
+// the barrier that publishes the current item's tiles, and land under its MFMAs and softmax (one workgroup per CU: nothing else
+// would cover the prologue's memory latency).
 __global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
-                                                           int T, int heads, float scale) {
+                                                           int T, int heads, float scale, int items) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-  const int bh = blockIdx.x, b = bh / heads, head = bh % heads;
   const int D = heads * DH, nb = (T + 31) / 32;
   const long long ld = 3ll * D;
-  const bf16_t* q = qkv + (long long)b * T * ld + head * DH;
-  const bf16_t* k = q + D;
-  const bf16_t* v = q + 2 * D;
   unsigned char* Ks = lds;                       // [nb*32][64]
   unsigned char* Vt = lds + nb * 32 * 128;       // [64][TP]
-  fill_rows(Ks, k, ld, T, nb * 32, tid, 512);
-  fill_transposed(Vt, v, ld, T, nb * 32, tid, 512);
-  __syncthreads();
-  f32x16 oT[2];
   const int strip = wave;
   const bool active = strip < nb;
-  if (active) {
-    bf16x8 qf[4];
+  auto q_of = [&](int bh) { return qkv + (long long)(bh / heads) * T * ld + (bh % heads) * DH; };
+  bf16x8 qf[4], qn[4];                           // this wave's query fragments of the current / next item
+  Chunks ck, cv, nk, nv;
+  int bh = blockIdx.x;
+  if (bh >= items) return;
+  {
+    const bf16_t* q = q_of(bh);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(q, ld, strip * 32 + l31, T, ks, h);
-    f32x16 s[7];
+    load_chunks(ck, q + D, ld, T, tid);
+    load_chunks(cv, q + 2 * D, ld, T, tid);
+  }
+  for (; bh < items; bh += gridDim.x) {
+    const int b = bh / heads, head = bh % heads;
+    store_rows(Ks, ck, nb * 32, tid);
+    store_transposed(Vt, cv, nb * 32, tid);
+    __syncthreads();
+    const int next = bh + gridDim.x;
+    if (next < items) {                          // in flight under this item's compute
+      const bf16_t* q = q_of(next);
 #pragma unroll
-    for (int kb = 0; kb < 7; ++kb) {
+      for (int ks = 0; ks < 4; ++ks) qn[ks] = frag_global(q, ld, strip * 32 + l31, T, ks, h);
+      load_chunks(nk, q + D, ld, T, tid);
+      load_chunks(nv, q + 2 * D, ld, T, tid);
+    }
+    f32x16 oT[2];
+    if (active) {
+      // Two passes over the key blocks instead of holding the 224-key score row (112 registers) beside the prefetch registers:
+      // pass 1 = scores -> row maximum, pass 2 = scores again -> exp, row sum and P V.  The 28 extra MFMAs are free here (the
+      // kernel is bound by memory latency and the softmax's vector instructions, not by the matrix pipe).
+      auto scores = [&](int kb) {
+        f32x16 s;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
-      if (kb < nb) {
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kb * 32 + l31, ks, h), qf[ks], s[kb], 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kb * 32 + l31, ks, h), qf[ks], s, 0, 0, 0);
+        return s;
+      };
+      // this lane = query strip*32 + l31, registers = keys; the other 16 keys of every block sit in lane ^ 32
+      float m = -INFINITY;
+      for (int kb = 0; kb < nb; ++kb) {
+        const f32x16 s = scores(kb);
+        const int kmax = T - kb * 32;            // keys of this block that exist: only the last block is partial
+        if (kmax >= 32) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, s[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, reg_row(r, h) < kmax ? s[r] : -INFINITY);
+        }
       }
-    }
-    // row softmax: this lane = query strip*32 + l31, registers = keys; the other 16 keys of every block sit in lane ^ 32
-    float m = -INFINITY;
+      m = fmaxf(m, __shfl_xor(m, 32)) * scale;   // (scale > 0)
+      float sum = 0.0f;
 #pragma unroll
-    for (int kb = 0; kb < 7; ++kb)
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = kb < nb && kb * 32 + reg_row(r, h) < T;
-        s[kb][r] = ok ? s[kb][r] * scale : -INFINITY;
-        m = fmaxf(m, s[kb][r]);
-      }
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sum = 0.0f;
+        for (int r = 0; r < 16; ++r) oT[db][r] = 0.0f;
+      for (int kb = 0; kb < nb; ++kb) {
+        f32x16 s = scores(kb);
+        const int kmax = T - kb * 32;
 #pragma unroll
-    for (int kb = 0; kb < 7; ++kb)
+        for (int r = 0; r < 16; ++r) s[r] = __expf(fmaf(s[r], scale, -m));      // unnormalised (<= 1): o is divided instead
+        if (kmax < 32) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[kb][r] = __expf(s[kb][r] - m);
-        sum += s[kb][r];
-      }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    if (h == 0 && strip * 32 + l31 < T) lse[(long long)bh * T + strip * 32 + l31] = m + __logf(sum);
+          for (int r = 0; r < 16; ++r) s[r] = reg_row(r, h) < kmax ? s[r] : 0.0f;
+        }
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oT[db][r] = 0.0f;
-#pragma unroll
-    for (int kb = 0; kb < 7; ++kb) {
-      if (kb < nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] *= inv;
+        for (int r = 0; r < 16; ++r) sum += s[r];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pf = pack_regs(s[kb], s2);
+          const bf16x8 pf = pack_regs(s, s2);
           const int base = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
           for (int db = 0; db < 2; ++db)
             oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Vt, db * 32 + l31, base), pf, oT[db], 0, 0, 0);
         }
       }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+      if (h == 0 && strip * 32 + l31 < T) lse[(long long)bh * T + strip * 32 + l31] = m + __logf(sum);
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oT[db][r] *= inv;   // (lane = query: one factor per lane)
     }
+    __syncthreads();                             // every wave is done with the tiles: the staging rows reuse them
+    if (active) store_strip(oT, lds + wave * 4096, o + (long long)b * T * D + head * DH, D, strip * 32, T, lane);
+    __syncthreads();                             // staging rows read back: the next item's tiles may be written
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+    ck = nk; cv = nv;
   }
-  __syncthreads();                               // every wave is done with the tiles: the staging rows reuse them
-  if (active) store_strip(oT, lds + wave * 4096, o + (long long)b * T * D + head * DH, D, strip * 32, T, lane);
 }
 
 // ================================================================ backward, query strips: dq (and D = rowsum(do .* o) for the dk/dv kernel)
@@ -221,28 +271,37 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
   unsigned char* Ks = lds;
   unsigned char* Vs = Ks + nb * 32 * 128;
   unsigned char* Kt = Vs + nb * 32 * 128;
-  fill_rows(Ks, k, ld, T, nb * 32, tid, 512);
-  fill_rows(Vs, v, ld, T, nb * 32, tid, 512);
-  fill_transposed(Kt, k, ld, T, nb * 32, tid, 512);
-  __syncthreads();
-  f32x16 dqT[2];
   const int strip = wave;
   const bool active = strip < nb;
+  const int qi = strip * 32 + l31;
+  bf16x8 qf[4], dof[4], of[4];                   // this wave's strip operands: requested first
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = frag_global(q, ld, qi, T, ks, h);
+    dof[ks] = frag_global(dO, D, qi, T, ks, h);
+    of[ks] = frag_global(O, D, qi, T, ks, h);
+  }
+  const float l = lse[(long long)bh * T + (qi < T ? qi : T - 1)];
+  {
+    Chunks ck, cv;
+    load_chunks(ck, k, ld, T, tid);
+    load_chunks(cv, v, ld, T, tid);
+    store_rows(Ks, ck, nb * 32, tid);
+    store_transposed(Kt, ck, nb * 32, tid);
+    store_rows(Vs, cv, nb * 32, tid);
+  }
+  __syncthreads();
+  f32x16 dqT[2];
   if (active) {
-    const int qi = strip * 32 + l31;
-    bf16x8 qf[4], dof[4];
     float dsum = 0.0f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = frag_global(q, ld, qi, T, ks, h);
-      dof[ks] = frag_global(dO, D, qi, T, ks, h);
       const u32x4 a = __builtin_bit_cast(u32x4, dof[ks]);
-      const u32x4 c = __builtin_bit_cast(u32x4, frag_global(O, D, qi, T, ks, h));
+      const u32x4 c = __builtin_bit_cast(u32x4, of[ks]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) dsum += bf_lo(a[e]) * bf_lo(c[e]) + bf_hi(a[e]) * bf_hi(c[e]);
     }
     dsum += __shfl_xor(dsum, 32);
-    const float l = lse[(long long)bh * T + (qi < T ? qi : T - 1)];
     if (h == 0 && qi < T) Dsum[(long long)bh * T + qi] = dsum;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -257,11 +316,12 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kb * 32 + l31, ks, h), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, kb * 32 + l31, ks, h), dof[ks], dp, 0, 0, 0);
       }
+      const int kmax = T - kb * 32;                       // only the last key block is partial
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = kb * 32 + reg_row(r, h) < T;
-        const float p = ok ? __expf(s[r] * scale - l) : 0.0f;
-        s[r] = p * (dp[r] - dsum) * scale;              // dS^T
+      for (int r = 0; r < 16; ++r) s[r] = __expf(fmaf(s[r], scale, -l)) * ((dp[r] - dsum) * scale);   // dS^T = P (dP - D) scale
+      if (kmax < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = reg_row(r, h) < kmax ? s[r] : 0.0f;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -296,26 +356,29 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
   unsigned char* dOt = Qt + TT_B;
   float* lseS = reinterpret_cast<float*>(dOt + TT_B);   // [nb*32] lse, then [nb*32] D
   float* DS = lseS + nb * 32;
-  fill_rows(Qs, q, ld, T, nb * 32, tid, 512);
-  fill_rows(dOs, dO, D, T, nb * 32, tid, 512);
-  fill_transposed(Qt, q, ld, T, nb * 32, tid, 512);
-  fill_transposed(dOt, dO, D, T, nb * 32, tid, 512);
-  for (int i = tid; i < nb * 32; i += 512) {
-    lseS[i] = i < T ? lse[(long long)bh * T + i] : 0.0f;
-    DS[i] = i < T ? Dsum[(long long)bh * T + i] : 0.0f;
+  const int strip = wave;
+  const bool active = strip < nb;
+  const int ki = strip * 32 + l31;
+  bf16x8 kf[4], vf[4];                           // this wave's key / value fragments: requested first
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = frag_global(k, ld, ki, T, ks, h);
+    vf[ks] = frag_global(v, ld, ki, T, ks, h);
+  }
+  {
+    Chunks cq, cd;
+    load_chunks(cq, q, ld, T, tid);
+    load_chunks(cd, dO, D, T, tid);
+    const float lv = tid < T ? lse[(long long)bh * T + tid] : 0.0f, dv = tid < T ? Dsum[(long long)bh * T + tid] : 0.0f;
+    store_rows(Qs, cq, nb * 32, tid);
+    store_transposed(Qt, cq, nb * 32, tid);
+    store_rows(dOs, cd, nb * 32, tid);
+    store_transposed(dOt, cd, nb * 32, tid);
+    if (tid < nb * 32) { lseS[tid] = lv; DS[tid] = dv; }
   }
   __syncthreads();
   f32x16 dkT[2], dvT[2];
-  const int strip = wave;
-  const bool active = strip < nb;
   if (active) {
-    const int ki = strip * 32 + l31;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = frag_global(k, ld, ki, T, ks, h);
-      vf[ks] = frag_global(v, ld, ki, T, ks, h);
-    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -330,12 +393,27 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, qb * 32 + l31, ks, h), vf[ks], dp, 0, 0, 0);  // dP[q][key]
       }
       f32x16 ds;
+      const int qmax = T - qb * 32;                        // only the last query block is partial
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = qb * 32 + reg_row(r, h);
-        const float p = qi < T ? __expf(s[r] * scale - lseS[qi]) : 0.0f;
-        s[r] = p;
-        ds[r] = p * (dp[r] - DS[qi]) * scale;
+      for (int g = 0; g < 4; ++g) {                        // registers 4g .. 4g + 3 = queries qb*32 + 8g + 4h + 0..3
+        const float4 lq = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * g + 4 * h);
+        const float4 dq4 = *reinterpret_cast<const float4*>(DS + qb * 32 + 8 * g + 4 * h);
+        const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dv4[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float p = __expf(fmaf(s[r], scale, -lv[e]));
+          s[r] = p;
+          ds[r] = p * ((dp[r] - dv4[e]) * scale);
+        }
+      }
+      if (qmax < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = reg_row(r, h) < qmax;
+          s[r] = ok ? s[r] : 0.0f;
+          ds[r] = ok ? ds[r] : 0.0f;
+        }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -371,8 +449,9 @@ extern "C" int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B,
   static mcl_device_once attr_once;
   if (auto attr_guard = attr_once.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_bytes, mcl_stream(stream),
-                     (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale);
+  const int items = B * heads, grid = items < 2 * mcl_cu_count() ? items : mcl_cu_count();   // persistent from two rounds up
+  hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
+                     (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
