@@ -24,6 +24,7 @@
 // the 32 lanes of a ds_read_b64 group, one row each, cover the 64 banks exactly once).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -449,7 +450,9 @@ extern "C" int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B,
   static mcl_device_once attr_once;
   if (auto attr_guard = attr_once.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const int items = B * heads, grid = items < 2 * mcl_cu_count() ? items : mcl_cu_count();   // persistent from two rounds up
+  const char* e_p = getenv("MCL_VIT_ATTN_PERSIST");     // 0: one workgroup per item (A/B)
+  const int items = B * heads;
+  const int grid = (items < 2 * mcl_cu_count() || (e_p && e_p[0] == '0')) ? items : mcl_cu_count();   // persistent from two rounds up
   hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
                      (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
   MCL_CHECK_LAUNCH();
