@@ -211,7 +211,9 @@ __global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restr
           for (int r = 0; r < 16; ++r) m = fmaxf(m, reg_row(r, h) < kmax ? s[r] : -INFINITY);
         }
       }
+      const float sl2 = scale * 1.44269504088896340736f;                       // exp(x) = exp2(x log2 e): folded into the scale
       m = fmaxf(m, __shfl_xor(m, 32)) * scale;   // (scale > 0)
+      const float ml2 = m * 1.44269504088896340736f;
       float sum = 0.0f;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restr
         f32x16 s = scores(kb);
         const int kmax = T - kb * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = __expf(fmaf(s[r], scale, -m));      // unnormalised (<= 1): o is divided instead
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -ml2));   // unnormalised (<= 1): o is divided instead
         if (kmax < 32) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = reg_row(r, h) < kmax ? s[r] : 0.0f;
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
     }
     dsum += __shfl_xor(dsum, 32);
     if (h == 0 && qi < T) Dsum[(long long)bh * T + qi] = dsum;
+    const float sl2 = scale * 1.44269504088896340736f, ll2 = l * 1.44269504088896340736f;   // exp(x) = exp2(x log2 e)
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
       }
       const int kmax = T - kb * 32;                       // only the last key block is partial
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __expf(fmaf(s[r], scale, -l)) * ((dp[r] - dsum) * scale);   // dS^T = P (dP - D) scale
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -ll2)) * ((dp[r] - dsum) * scale);   // dS^T = P (dP - D) scale
       if (kmax < 32) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = reg_row(r, h) < kmax ? s[r] : 0.0f;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
     store_transposed(Qt, cq, nb * 32, tid);
     store_rows(dOs, cd, nb * 32, tid);
     store_transposed(dOt, cd, nb * 32, tid);
-    if (tid < nb * 32) { lseS[tid] = lv; DS[tid] = dv; }
+    if (tid < nb * 32) { lseS[tid] = lv * 1.44269504088896340736f; DS[tid] = dv; }   // lse in the exp2 domain
   }
   __syncthreads();
   f32x16 dkT[2], dvT[2];
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dkT[db][r] = 0.0f; dvT[db][r] = 0.0f; }
+    const float sl2 = scale * 1.44269504088896340736f;
     for (int qb = 0; qb < nb; ++qb) {
       f32x16 s, dp;
 #pragma unroll
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float p = __expf(fmaf(s[r], scale, -lv[e]));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lv[e]));
           s[r] = p;
           ds[r] = p * ((dp[r] - dv4[e]) * scale);
         }
