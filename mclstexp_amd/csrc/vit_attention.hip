@@ -15,13 +15,13 @@
 // query strip -- so that in the MFMA result layout a LANE is one query and the REGISTERS run over keys: the row softmax is a
 // per-lane loop plus one exchange with lane ^ 32, and P^T (as it sits in the result registers, rounded to bf16) IS the B operand of
 // the next product O^T = V^T P^T once the contraction index is permuted to the register order: MFMA step s2 of key block kb
-// contracts, for lane half h, the keys kb*32 + 16 s2 + 4 h + {0..3, 8..11} -- so the A operand (V^T, rows = head dimension) is two
-// 8-byte LDS reads from a tile stored [d][key].  No probability ever leaves the registers.  The dk / dv kernel is the mirrored
-// problem (lane = key, registers = queries; per-query lse and D are broadcast LDS reads).
+// contracts, for lane half h, the keys kb*32 + 16 s2 + 4 h + {0..3, 8..11} -- and the A operand (V^T: rows = head dimension) for
+// exactly those keys is two transposing LDS reads (ds_read_b64_tr_b16) of the row-major V tile.  No probability ever leaves the
+// registers and no transposed copy of any operand exists.  The dk / dv kernel is the mirrored problem (lane = key, registers =
+// queries; per-query lse and D are broadcast LDS reads).
 //
-// LDS tiles: row-major operand tiles [rows][64] bf16 (128-byte rows, 16-byte chunk c of row r at c ^ ((r >> 1) & 7): conflict-free
-// ds_read_b128 fragments, the layout of csrc/gemm_bf16.hip) and transposed tiles [64][260] bf16 (row pitch 130 dwords = 2 mod 64:
-// the 32 lanes of a ds_read_b64 group, one row each, cover the 64 banks exactly once).
+// LDS tiles: row-major [rows][64] bf16 (128-byte rows) with ONE swizzle (swz below) that is conflict-free both for the row fragments
+// (ds_read_b128) and for the transposing fragments: 56-58 KB per workgroup.
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -38,8 +38,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DH = 64;          // head dimension
-constexpr int TP = 260;         // pitch (elements) of a transposed tile
-constexpr int TT_B = DH * TP * 2;  // bytes of a transposed tile
+
+// 16-byte chunk c of tile row r lives at physical chunk c ^ swz(r): bits 1..3 of r, bit-REVERSED.  Row fragments (ds_read_b128: a
+// lane group = rows {0-3, 12-15, 20-27} of one logical chunk) see eight distinct values per row parity -> 16 distinct 16-byte
+// slots; transposing fragments (ds_read_b64_tr_b16: a 32-lane group = 4 consecutive rows x 64 bytes) see rows r, r + 1 on the two
+// 128-byte halves of the bank row and rows r + 2, r + 3 moved by four chunks (bit 1 of r -> chunk bit 2) -> all 64 banks once.
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 1) << 2 | ((row >> 2) & 1) << 1 | ((row >> 3) & 1); }
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
   const f32x2 v = {a, b};
@@ -65,53 +69,33 @@ __device__ __forceinline__ void store_rows(unsigned char* tile, const Chunks& ch
 #pragma unroll
   for (int j = 0; j < FILL_IT; ++j) {
     const int i = tid + 512 * j, row = i >> 3, c = i & 7;
-    if (row < nrows) *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = ch.v[j];
-  }
-}
-// transposed tile [64][TP]: element (d, row) = src[row][d]; columns T .. ncols - 1 zero.  Lanes l and l ^ 8 hold the same chunk of
-// two adjacent rows (row = chunk index >> 3): they exchange their dwords so that each writes FOUR dwords (row pair packed) for half
-// of the chunk's eight d -- instead of eight 2-byte stores per lane, which collide on banks and on half-dwords.
-__device__ __forceinline__ void store_transposed(unsigned char* tile, const Chunks& ch, int ncols, int tid) {
-  unsigned* t32 = reinterpret_cast<unsigned*>(tile);
-#pragma unroll
-  for (int j = 0; j < FILL_IT; ++j) {
-    const int i = tid + 512 * j, row = i >> 3, c = i & 7, p = row & 1;
-    unsigned mine[4], other[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      mine[e] = ch.v[j][e];
-      other[e] = __shfl_xor(mine[e], 8);
-    }
-    if (row < ncols) {                                // (ncols is a multiple of 32: both rows of a pair exist together)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const unsigned ev = p ? other[2 * p + u] : mine[2 * p + u];      // the even row's dword (d = 8c + 4p + 2u, + 1)
-        const unsigned od = p ? mine[2 * p + u] : other[2 * p + u];
-        const int d = 8 * c + 4 * p + 2 * u, r2 = (row & ~1) >> 1;
-        t32[(d * TP) / 2 + r2] = (ev & 0xFFFFu) | (od << 16);
-        t32[((d + 1) * TP) / 2 + r2] = (ev >> 16) | (od & 0xFFFF0000u);
-      }
-    }
+    if (row < nrows) *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ swz(row)) << 4)) = ch.v[j];
   }
 }
 // fragment of a row-major tile: rows rbase + (lane & 31), 8 consecutive head-dimension elements 16 ks + 8 (lane >> 5) ..
 __device__ __forceinline__ bf16x8 frag_rows(const unsigned char* tile, int row, int ks, int h) {
   const int c = 2 * ks + h;
-  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((c ^ swz(row)) << 4));
 }
 // the same fragment straight from global memory (rows of the strip itself: read once per strip); rows >= T clamp to T - 1
 __device__ __forceinline__ bf16x8 frag_global(const bf16_t* __restrict__ src, long long ld, int row, int T, int ks, int h) {
   const int r = row < T ? row : T - 1;
   return *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + 16 * ks + 8 * h);
 }
-// A fragment of a transposed tile for the permuted contraction: row d, columns base + {0..3, 8..11}
-__device__ __forceinline__ bf16x8 frag_transposed(const unsigned char* tile, int d, int base) {
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tile + (d * TP + base) * 2);
-  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tile + (d * TP + base + 8) * 2);
-  bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
+// TRANSPOSED fragment of a row-major tile [row][64] for the permuted contraction: for lane (column = col0 + (lane & 31), half h) the
+// eight tile rows row0 + {0..3, 8..11} of that column (row0 = block base + 16 s2 + 4 h, a multiple of 4) -- two transposing reads
+// (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block, lane i supplying the 8-byte piece (i & 3) of row i >> 2
+// and receiving the four rows of column i).  No transposed copy of the tile exists.
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int col0, int row0, int lane) {
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  const int i = lane & 15, q = i >> 2;
+  const int chunk = (col0 + 16 * ((lane >> 4) & 1)) / 8 + ((i & 3) >> 1);
+  const int r_lo = row0 + q, r_hi = row0 + 8 + q;
+  const unsigned char* p_lo = tile + r_lo * 128 + ((chunk ^ swz(r_lo)) << 4) + (i & 1) * 8;
+  const unsigned char* p_hi = tile + r_hi * 128 + ((chunk ^ swz(r_hi)) << 4) + (i & 1) * 8;
+  const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)p_lo);
+  const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_t __attribute__((address_space(3)))*)p_hi);
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 // registers 8 s2 .. 8 s2 + 7 of a result block, rounded to bf16: the B operand of the next product (slot order = register order)
 __device__ __forceinline__ bf16x8 pack_regs(const f32x16& p, int s2) {
@@ -149,14 +133,18 @@ __device__ __forceinline__ void store_strip(const f32x16 (&acc)[2], unsigned cha
 // Persistent over (image, head) items: the next item's K / V chunks and query fragments are requested into registers right after
 // the barrier that publishes the current item's tiles, and land under its MFMAs and softmax (one workgroup per CU: nothing else
 // would cover the prologue's memory latency).
-__global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, float* __restrict__ lse,
-                                                           int T, int heads, float scale, int items) {
+// PREFETCH = false: no next-item registers -> under 128 VGPRs, four waves per SIMD, two workgroups per CU (56 KB of LDS each)
+// cover each other's prologue instead.
+template <bool PREFETCH>
+__global__ __launch_bounds__(512, PREFETCH ? 2 : 4) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                                             float* __restrict__ lse, int T, int heads, float scale,
+                                                                             int items) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int D = heads * DH, nb = (T + 31) / 32;
   const long long ld = 3ll * D;
   unsigned char* Ks = lds;                       // [nb*32][64]
-  unsigned char* Vt = lds + nb * 32 * 128;       // [64][TP]
+  unsigned char* Vs = lds + nb * 32 * 128;       // [nb*32][64]
   const int strip = wave;
   const bool active = strip < nb;
   auto q_of = [&](int bh) { return qkv + (long long)(bh / heads) * T * ld + (bh % heads) * DH; };
@@ -164,26 +152,22 @@ __global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restr
   Chunks ck, cv, nk, nv;
   int bh = blockIdx.x;
   if (bh >= items) return;
-  {
-    const bf16_t* q = q_of(bh);
+  auto load_item = [&](int item, bf16x8 (&qq)[4], Chunks& kk, Chunks& vv) {
+    const bf16_t* q = q_of(item);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_global(q, ld, strip * 32 + l31, T, ks, h);
-    load_chunks(ck, q + D, ld, T, tid);
-    load_chunks(cv, q + 2 * D, ld, T, tid);
-  }
+    for (int ks = 0; ks < 4; ++ks) qq[ks] = frag_global(q, ld, strip * 32 + l31, T, ks, h);
+    load_chunks(kk, q + D, ld, T, tid);
+    load_chunks(vv, q + 2 * D, ld, T, tid);
+  };
+  if (PREFETCH) load_item(bh, qf, ck, cv);
   for (; bh < items; bh += gridDim.x) {
     const int b = bh / heads, head = bh % heads;
+    if (!PREFETCH) load_item(bh, qf, ck, cv);    // (nothing carried across items: the registers are free during the compute)
     store_rows(Ks, ck, nb * 32, tid);
-    store_transposed(Vt, cv, nb * 32, tid);
+    store_rows(Vs, cv, nb * 32, tid);
     __syncthreads();
     const int next = bh + gridDim.x;
-    if (next < items) {                          // in flight under this item's compute
-      const bf16_t* q = q_of(next);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) qn[ks] = frag_global(q, ld, strip * 32 + l31, T, ks, h);
-      load_chunks(nk, q + D, ld, T, tid);
-      load_chunks(nv, q + 2 * D, ld, T, tid);
-    }
+    if (PREFETCH && next < items) load_item(next, qn, nk, nv);   // in flight under this item's compute
     f32x16 oT[2];
     if (active) {
       // Two passes over the key blocks instead of holding the 224-key score row (112 registers) beside the prefetch registers:
@@ -236,7 +220,7 @@ __global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restr
           const int base = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
           for (int db = 0; db < 2; ++db)
-            oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Vt, db * 32 + l31, base), pf, oT[db], 0, 0, 0);
+            oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Vs, db * 32, base, lane), pf, oT[db], 0, 0, 0);
         }
       }
       sum += __shfl_xor(sum, 32);
@@ -250,14 +234,16 @@ __global__ __launch_bounds__(512) void vit_attn_fwd_kernel(const bf16_t* __restr
     __syncthreads();                             // every wave is done with the tiles: the staging rows reuse them
     if (active) store_strip(oT, lds + wave * 4096, o + (long long)b * T * D + head * DH, D, strip * 32, T, lane);
     __syncthreads();                             // staging rows read back: the next item's tiles may be written
+    if (PREFETCH) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
-    ck = nk; cv = nv;
+      for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+      ck = nk; cv = nv;
+    }
   }
 }
 
 // ================================================================ backward, query strips: dq (and D = rowsum(do .* o) for the dk/dv kernel)
-__global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(512, 4) void vit_attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ Dsum, bf16_t* __restrict__ dqkv, int T, int heads,
                                                               float scale) {
@@ -273,7 +259,6 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
   const bf16_t* O = o + (long long)b * T * D + head * DH;
   unsigned char* Ks = lds;
   unsigned char* Vs = Ks + nb * 32 * 128;
-  unsigned char* Kt = Vs + nb * 32 * 128;
   const int strip = wave;
   const bool active = strip < nb;
   const int qi = strip * 32 + l31;
@@ -290,7 +275,6 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
     load_chunks(ck, k, ld, T, tid);
     load_chunks(cv, v, ld, T, tid);
     store_rows(Ks, ck, nb * 32, tid);
-    store_transposed(Kt, ck, nb * 32, tid);
     store_rows(Vs, cv, nb * 32, tid);
   }
   __syncthreads();
@@ -333,7 +317,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dq_kernel(const bf16_t* __re
         const int base = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
-          dqT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Kt, db * 32 + l31, base), df, dqT[db], 0, 0, 0);
+          dqT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Ks, db * 32, base, lane), df, dqT[db], 0, 0, 0);
       }
     }
   }
@@ -356,9 +340,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
   const bf16_t* dO = dout + (long long)b * T * D + head * DH;
   unsigned char* Qs = lds;
   unsigned char* dOs = Qs + nb * 32 * 128;
-  unsigned char* Qt = dOs + nb * 32 * 128;
-  unsigned char* dOt = Qt + TT_B;
-  float* lseS = reinterpret_cast<float*>(dOt + TT_B);   // [nb*32] lse, then [nb*32] D
+  float* lseS = reinterpret_cast<float*>(dOs + nb * 32 * 128);   // [nb*32] lse, then [nb*32] D
   float* DS = lseS + nb * 32;
   const int strip = wave;
   const bool active = strip < nb;
@@ -375,9 +357,7 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
     load_chunks(cd, dO, D, T, tid);
     const float lv = tid < T ? lse[(long long)bh * T + tid] : 0.0f, dv = tid < T ? Dsum[(long long)bh * T + tid] : 0.0f;
     store_rows(Qs, cq, nb * 32, tid);
-    store_transposed(Qt, cq, nb * 32, tid);
     store_rows(dOs, cd, nb * 32, tid);
-    store_transposed(dOt, cd, nb * 32, tid);
     if (tid < nb * 32) { lseS[tid] = lv * 1.44269504088896340736f; DS[tid] = dv; }   // lse in the exp2 domain
   }
   __syncthreads();
@@ -426,8 +406,8 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
         const int base = qb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(dOt, db * 32 + l31, base), pf, dvT[db], 0, 0, 0);
-          dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(Qt, db * 32 + l31, base), df, dkT[db], 0, 0, 0);
+          dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOs, db * 32, base, lane), pf, dvT[db], 0, 0, 0);
+          dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, db * 32, base, lane), df, dkT[db], 0, 0, 0);
         }
       }
     }
@@ -449,16 +429,26 @@ extern "C" int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B,
   MCL_CLEAR_ERROR();
   if (!qkv || !o || !lse || B <= 0 || T <= 0 || heads <= 0) return MCL_EINVAL;
   if (T > 224 || (reinterpret_cast<uintptr_t>(qkv) & 15u) || (reinterpret_cast<uintptr_t>(o) & 15u)) return MCL_EUNSUPPORTED;
-  size_t lds_bytes = rows_bytes(T) + TT_B;
+  size_t lds_bytes = 2 * rows_bytes(T);
   if (lds_bytes < (size_t)8 * 4096) lds_bytes = (size_t)8 * 4096;
   static mcl_device_once attr_once;
-  if (auto attr_guard = attr_once.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const char* e_p = getenv("MCL_VIT_ATTN_PERSIST");     // 0: one workgroup per item (A/B)
+  if (auto attr_guard = attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  // Long sequences (T = 197): one workgroup per item without next-item registers -- four waves per SIMD, two workgroups per CU cover
+  // each other's prologue (136-139 us per layer at B = 256 against 146-148 persistent).  Short ones (T = 50): the persistent walk
+  // with the next item prefetched into registers (41 against 43.6 us).  MCL_VIT_ATTN_PERSIST=0 / 1 forces one form (A/B).
+  const char* e_p = getenv("MCL_VIT_ATTN_PERSIST");
   const int items = B * heads;
-  const int grid = (items < 2 * mcl_cu_count() || (e_p && e_p[0] == '0')) ? items : mcl_cu_count();   // persistent from two rounds up
-  hipLaunchKernelGGL(vit_attn_fwd_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
-                     (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
+  const bool persist = e_p ? e_p[0] != '0' : T <= 128;
+  const int grid = (items < 2 * mcl_cu_count() || !persist) ? items : mcl_cu_count();
+  if (grid < items)
+    hipLaunchKernelGGL(vit_attn_fwd_kernel<true>, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
+                       (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
+  else
+    hipLaunchKernelGGL(vit_attn_fwd_kernel<false>, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
+                       (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
@@ -476,11 +466,12 @@ extern "C" int mcl_vit_attn_bwd(const void* qkv, const void* o, const void* dout
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipStream_t st = mcl_stream(stream);
-  size_t lds_dq = 2 * rows_bytes(T) + TT_B;
+  size_t lds_dq = 2 * rows_bytes(T);
   if (lds_dq < (size_t)8 * 4096) lds_dq = (size_t)8 * 4096;
   hipLaunchKernelGGL(vit_attn_bwd_dq_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_dq, st, (const bf16_t*)qkv, (const bf16_t*)o,
                      (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);
-  const size_t lds_dkv = 2 * rows_bytes(T) + 2 * TT_B + (size_t)((T + 31) / 32) * 32 * 8;
+  size_t lds_dkv = 2 * rows_bytes(T) + (size_t)((T + 31) / 32) * 32 * 8;
+  if (lds_dkv < (size_t)8 * 4096) lds_dkv = (size_t)8 * 4096;
   hipLaunchKernelGGL(vit_attn_bwd_dkv_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_dkv, st, (const bf16_t*)qkv,
                      (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);
   MCL_CHECK_LAUNCH();
