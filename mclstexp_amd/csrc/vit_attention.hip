@@ -129,6 +129,27 @@ __device__ __forceinline__ void store_strip(const f32x16 (&acc)[2], unsigned cha
   }
 }
 
+// the same through a 2 KB wave-private staging area, one 32-d half at a time (64-byte row pieces leave the CU)
+__device__ __forceinline__ void store_strip_halves(const f32x16 (&acc)[2], unsigned char* stage, bf16_t* __restrict__ out, long long ld,
+                                                   int tok0, int T, int lane) {
+  const int h = lane >> 5, l31 = lane & 31;
+  bf16_t* st = reinterpret_cast<bf16_t*>(stage);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x2 w = {pack2(acc[db][4 * g], acc[db][4 * g + 1]), pack2(acc[db][4 * g + 2], acc[db][4 * g + 3])};
+      *reinterpret_cast<u32x2*>(st + l31 * 32 + 8 * g + 4 * h) = w;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = it * 16 + (lane >> 2), c = lane & 3;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * 32 + 8 * c);
+      if (tok0 + row < T) *reinterpret_cast<u32x4*>(out + (long long)(tok0 + row) * ld + db * 32 + 8 * c) = v;
+    }
+  }
+}
+
 // ================================================================ forward
 // Persistent over (image, head) items: the next item's K / V chunks and query fragments are requested into registers right after
 // the barrier that publishes the current item's tiles, and land under its MFMAs and softmax (one workgroup per CU: nothing else
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(512, 4) void vit_attn_bwd_dq_kernel(const bf16_t* _
 }
 
 // ================================================================ backward, key strips: dk, dv
-__global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(512, 4) void vit_attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ Dsum,
                                                                bf16_t* __restrict__ dqkv, int T, int heads, float scale) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -361,62 +382,85 @@ __global__ __launch_bounds__(512) void vit_attn_bwd_dkv_kernel(const bf16_t* __r
     if (tid < nb * 32) { lseS[tid] = lv * 1.44269504088896340736f; DS[tid] = dv; }   // lse in the exp2 domain
   }
   __syncthreads();
-  f32x16 dkT[2], dvT[2];
+  // Two passes over the query blocks -- dv (needs P only), then dk (needs P and dP) -- so that at most one 32-register result, one
+  // or two score blocks and the strip's fragments are live: under 128 registers, four waves per SIMD, two workgroups per CU (the
+  // single-pass form needed 194 registers and ran one).  The scores of a block are computed twice; the matrix pipe has the room.
+  const float sl2 = scale * 1.44269504088896340736f;
+  auto probs = [&](f32x16& s, int qb) {                    // s: scores S[q][key] -> P, queries beyond T zero
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                          // registers 4g .. 4g + 3 = queries qb*32 + 8g + 4h + 0..3
+      const float4 lq = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * g + 4 * h);
+      s[4 * g] = __builtin_amdgcn_exp2f(fmaf(s[4 * g], sl2, -lq.x));
+      s[4 * g + 1] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + 1], sl2, -lq.y));
+      s[4 * g + 2] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + 2], sl2, -lq.z));
+      s[4 * g + 3] = __builtin_amdgcn_exp2f(fmaf(s[4 * g + 3], sl2, -lq.w));
+    }
+    const int qmax = T - qb * 32;                          // only the last query block is partial
+    if (qmax < 32) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = reg_row(r, h) < qmax ? s[r] : 0.0f;
+    }
+  };
+  bf16_t* dbase = dqkv + (long long)b * T * ld + head * DH;
+  unsigned char* stage = reinterpret_cast<unsigned char*>(DS + nb * 32) + wave * 2048;   // wave-private, behind the tiles
   if (active) {
+    f32x16 acc[2];
+    // ---- pass 1: dv^T[d][key] = sum_q dO^T[d][q] P[q][key]
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { dkT[db][r] = 0.0f; dvT[db][r] = 0.0f; }
-    const float sl2 = scale * 1.44269504088896340736f;
+      for (int r = 0; r < 16; ++r) acc[db][r] = 0.0f;
+    for (int qb = 0; qb < nb; ++qb) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qb * 32 + l31, ks, h), kf[ks], s, 0, 0, 0);     // S[q][key]
+      probs(s, qb);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack_regs(s, s2);
+        const int base = qb * 32 + 16 * s2 + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOs, db * 32, base, lane), pf, acc[db], 0, 0, 0);
+      }
+    }
+    store_strip_halves(acc, stage, dbase + 2 * D, ld, strip * 32, T, lane);
+    // ---- pass 2: dk^T[d][key] = sum_q Q^T[d][q] dS[q][key],  dS = P (dP - D) scale
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[db][r] = 0.0f;
     for (int qb = 0; qb < nb; ++qb) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qb * 32 + l31, ks, h), kf[ks], s, 0, 0, 0);     // S[q][key]
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, qb * 32 + l31, ks, h), kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, qb * 32 + l31, ks, h), vf[ks], dp, 0, 0, 0);  // dP[q][key]
       }
-      f32x16 ds;
-      const int qmax = T - qb * 32;                        // only the last query block is partial
+      probs(s, qb);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {                        // registers 4g .. 4g + 3 = queries qb*32 + 8g + 4h + 0..3
-        const float4 lq = *reinterpret_cast<const float4*>(lseS + qb * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g) {
         const float4 dq4 = *reinterpret_cast<const float4*>(DS + qb * 32 + 8 * g + 4 * h);
-        const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dv4[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -lv[e]));
-          s[r] = p;
-          ds[r] = p * ((dp[r] - dv4[e]) * scale);
-        }
-      }
-      if (qmax < 32) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool ok = reg_row(r, h) < qmax;
-          s[r] = ok ? s[r] : 0.0f;
-          ds[r] = ok ? ds[r] : 0.0f;
-        }
+        s[4 * g] *= (dp[4 * g] - dq4.x) * scale;
+        s[4 * g + 1] *= (dp[4 * g + 1] - dq4.y) * scale;
+        s[4 * g + 2] *= (dp[4 * g + 2] - dq4.z) * scale;
+        s[4 * g + 3] *= (dp[4 * g + 3] - dq4.w) * scale;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = pack_regs(s, s2), df = pack_regs(ds, s2);
+        const bf16x8 df = pack_regs(s, s2);
         const int base = qb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          dvT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOs, db * 32, base, lane), pf, dvT[db], 0, 0, 0);
-          dkT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, db * 32, base, lane), df, dkT[db], 0, 0, 0);
-        }
+        for (int db = 0; db < 2; ++db)
+          acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qs, db * 32, base, lane), df, acc[db], 0, 0, 0);
       }
     }
-  }
-  __syncthreads();
-  if (active) {
-    bf16_t* dbase = dqkv + (long long)b * T * ld + head * DH;
-    store_strip(dkT, lds + wave * 4096, dbase + D, ld, strip * 32, T, lane);
-    store_strip(dvT, lds + wave * 4096, dbase + 2 * D, ld, strip * 32, T, lane);
+    store_strip_halves(acc, stage, dbase + D, ld, strip * 32, T, lane);
   }
 }
 
@@ -470,8 +514,7 @@ extern "C" int mcl_vit_attn_bwd(const void* qkv, const void* o, const void* dout
   if (lds_dq < (size_t)8 * 4096) lds_dq = (size_t)8 * 4096;
   hipLaunchKernelGGL(vit_attn_bwd_dq_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_dq, st, (const bf16_t*)qkv, (const bf16_t*)o,
                      (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);
-  size_t lds_dkv = 2 * rows_bytes(T) + (size_t)((T + 31) / 32) * 32 * 8;
-  if (lds_dkv < (size_t)8 * 4096) lds_dkv = (size_t)8 * 4096;
+  const size_t lds_dkv = 2 * rows_bytes(T) + (size_t)((T + 31) / 32) * 32 * 8 + (size_t)8 * 2048;   // tiles, lse / D, staging rows (74 KB at T = 197: two workgroups per CU)
   hipLaunchKernelGGL(vit_attn_bwd_dkv_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_dkv, st, (const bf16_t*)qkv,
                      (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);
   MCL_CHECK_LAUNCH();
