@@ -236,12 +236,17 @@ def test_vit_row_kernels():
         assert (dp[:, n:] == 0).all()
 
 
-@pytest.mark.parametrize("name,B", [("vit_base_patch32_224", 6), ("vit_base_patch16_224", 3)])
-def test_vit_fused_matches_fp64_module(name, B):
+@pytest.mark.parametrize("name,B,fused_attn", [("vit_base_patch32_224", 6, True), ("vit_base_patch16_224", 3, True),
+                                             ("vit_base_patch32_224", 4, False)])
+def test_vit_fused_matches_fp64_module(name, B, fused_attn, monkeypatch):
     """Whole encoder forward + backward on the bf16 kernels vs an fp64 run of the same module (timm layout restated in
-    backbones.py): features 3e-2 of max|feature|, parameter gradients median relative deviation 3e-2, max 0.25."""
+    backbones.py): features 3e-2 of max|feature|, parameter gradients median relative deviation 3e-2, max 0.25.  With the
+    fused attention core (csrc/vit_attention.hip) and, once, with the batched GEMM + softmax path that sequences beyond 224
+    tokens still take."""
+    from mclstexp_amd import vit_fused as _vf
     from mclstexp_amd.backbones import ImageEncoder_VIT
     from mclstexp_amd.vit_fused import vit_features_fused
+    monkeypatch.setattr(_vf, "FUSED_ATTN", fused_attn)
     torch.manual_seed(0)
     enc = ImageEncoder_VIT(name)
     with torch.no_grad():
