@@ -141,9 +141,9 @@ __device__ __forceinline__ float gelu_g(float x) {
 // Loads, stores and LDS-DMA pieces retire in issue order on one counter, so a load waited for after a store drains that store:
 // the bias is loaded once before the first store, and the residual / gelu' operand rows of iteration i + 1 are requested before
 // the stores of iteration i (round 4; the per-iteration loads used to wait out the previous iteration's store acknowledgements).
-template <int NI>
-__device__ __forceinline__ void gemm_epilogue(const GemmB& g, f32x16 (&acc)[NI][2], unsigned char* lds, int wave, int lane,
-                                              int mw0, int nw, int ks, long long c_off, int b1) {
+template <int NI, bool HAS_X>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmB& g, f32x16 (&acc)[NI][2], unsigned char* lds, int wave, int lane,
+                                                   int mw0, int nw, int ks, long long c_off, int b1) {
   constexpr int EP = 64;
   const int h = lane >> 5, l31 = lane & 31;
   float* et = reinterpret_cast<float*>(lds) + wave * (64 * EP);
@@ -152,7 +152,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmB& g, f32x16 (&acc)[NI][
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = (g.bias && n + e < g.N) ? g.bias[n + e] : 0.0f;
-  const bool has_x = g.gelu_bwd || g.resid;
+  constexpr bool has_x = HAS_X;                      // residual / gelu' operand rows (compile-time: the plain form carries no
+                                                     // prefetch registers and no per-iteration moves)
   auto load_x = [&](int m, u32x4& xa, u32x4& xr) {
     if (m >= g.M || n >= g.N) return;
     if (g.gelu_bwd) xa = *reinterpret_cast<const u32x4*>(g.aux + (long long)m * g.ldaux + n);
@@ -220,9 +221,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmB& g, f32x16 (&acc)[NI][
               u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
         }
       }
-      xa = xa_n; xr = xr_n;
+      if (has_x) { xa = xa_n; xr = xr_n; }
     }
   }
+}
+template <int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmB& g, f32x16 (&acc)[NI][2], unsigned char* lds, int wave, int lane,
+                                              int mw0, int nw, int ks, long long c_off, int b1) {
+  if (g.gelu_bwd || g.resid) gemm_epilogue_impl<NI, true>(g, acc, lds, wave, lane, mw0, nw, ks, c_off, b1);
+  else gemm_epilogue_impl<NI, false>(g, acc, lds, wave, lane, mw0, nw, ks, c_off, b1);
 }
 
 // SUBS = 2: 256 x 256 tile, 8 waves (2 x 4, 128 x 64 each) -- the large linears.  SUBS = 1: 128 x 128 tile, 4 waves
