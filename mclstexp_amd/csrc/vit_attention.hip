@@ -30,7 +30,7 @@ namespace {
 
 typedef unsigned short bf16_t;
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -87,7 +87,6 @@ __device__ __forceinline__ bf16x8 frag_global(const bf16_t* __restrict__ src, lo
 // (ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block, lane i supplying the 8-byte piece (i & 3) of row i >> 2
 // and receiving the four rows of column i).  No transposed copy of the tile exists.
 __device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int col0, int row0, int lane) {
-  typedef short v4s_t __attribute__((ext_vector_type(4)));
   const int i = lane & 15, q = i >> 2;
   const int chunk = (col0 + 16 * ((lane >> 4) & 1)) / 8 + ((i & 3) >> 1);
   const int r_lo = row0 + q, r_hi = row0 + 8 + q;
