@@ -151,7 +151,35 @@ __global__ __launch_bounds__(256) void colred_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[u][i] = b[u][i] = 0.0f;
   if (lane_on) {
-    for (long long r = (long long)blockIdx.x * RP + rl; r < rows; r += (long long)gridDim.x * RP) {
+    long long r = (long long)blockIdx.x * RP + rl;
+    const long long stride = (long long)gridDim.x * RP;
+    if (MODE == 0) {
+      // bias gradient: four rows per trip with all eight loads requested before the first add (one or two loads in flight per
+      // thread left the kernel at 2.4 TB/s)
+      for (; r + 3 * stride < rows; r += 4 * stride) {
+        uint4 w[4][U];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int c = c0 + 256 * u;
+            w[q][u] = make_uint4(0, 0, 0, 0);
+            if (c < nch) w[q][u] = *reinterpret_cast<const uint4*>(dy + (r + q * stride) * lddy + c * 8);
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)               // (row order kept: the sums are the same bits as the one-row loop's)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const unsigned dd[4] = {w[q][u].x, w[q][u].y, w[q][u].z, w[q][u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              a[u][2 * i] += __uint_as_float(dd[i] << 16);
+              a[u][2 * i + 1] += __uint_as_float(dd[i] & 0xFFFF0000u);
+            }
+          }
+      }
+    }
+    for (; r < rows; r += stride) {
       float mu = 0.0f, rs = 0.0f;
       if (MODE == 1) {
         mu = mean[r];
