@@ -53,22 +53,25 @@ __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w <<
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 // ---- tile fills in two phases so that EVERY global load of a workgroup's prologue is in flight before the first LDS write waits
-// for one: thread t owns the 16-byte chunks t, t + 512, t + 1024, t + 1536 of a [rows][64] source (rows <= 224: 1792 chunks).
+// for one: thread t of NT owns the 16-byte chunks t, t + NT, t + 2 NT, t + 3 NT of a [rows][64] source (rows <= NT / 2: a workgroup
+// has one wave per 32-row strip -- 512 threads up to 224 tokens, 256 up to 128, 128 up to 64).
 constexpr int FILL_IT = 4;
 struct Chunks { u32x4 v[FILL_IT]; };
+template <int NT>
 __device__ __forceinline__ void load_chunks(Chunks& ch, const bf16_t* __restrict__ src, long long ld, int T, int tid) {
 #pragma unroll
   for (int j = 0; j < FILL_IT; ++j) {
-    const int i = tid + 512 * j, row = i >> 3, c = i & 7;
+    const int i = tid + NT * j, row = i >> 3, c = i & 7;
     ch.v[j] = u32x4{0, 0, 0, 0};
     if (row < T) ch.v[j] = *reinterpret_cast<const u32x4*>(src + (long long)row * ld + 8 * c);
   }
 }
 // row-major tile [nrows][64]; rows >= T zero
+template <int NT>
 __device__ __forceinline__ void store_rows(unsigned char* tile, const Chunks& ch, int nrows, int tid) {
 #pragma unroll
   for (int j = 0; j < FILL_IT; ++j) {
-    const int i = tid + 512 * j, row = i >> 3, c = i & 7;
+    const int i = tid + NT * j, row = i >> 3, c = i & 7;
     if (row < nrows) *reinterpret_cast<u32x4*>(tile + row * 128 + ((c ^ swz(row)) << 4)) = ch.v[j];
   }
 }
@@ -155,8 +158,8 @@ __device__ __forceinline__ void store_strip_halves(const f32x16 (&acc)[2], unsig
 // would cover the prologue's memory latency).
 // PREFETCH = false: no next-item registers -> under 128 VGPRs, four waves per SIMD, two workgroups per CU (56 KB of LDS each)
 // cover each other's prologue instead.
-template <bool PREFETCH>
-__global__ __launch_bounds__(512, PREFETCH ? 2 : 4) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+template <bool PREFETCH, int NT>
+__global__ __launch_bounds__(NT, PREFETCH ? 2 : 4) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                                              float* __restrict__ lse, int T, int heads, float scale,
                                                                              int items) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -176,15 +179,15 @@ __global__ __launch_bounds__(512, PREFETCH ? 2 : 4) void vit_attn_fwd_kernel(con
     const bf16_t* q = q_of(item);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qq[ks] = frag_global(q, ld, strip * 32 + l31, T, ks, h);
-    load_chunks(kk, q + D, ld, T, tid);
-    load_chunks(vv, q + 2 * D, ld, T, tid);
+    load_chunks<NT>(kk, q + D, ld, T, tid);
+    load_chunks<NT>(vv, q + 2 * D, ld, T, tid);
   };
   if (PREFETCH) load_item(bh, qf, ck, cv);
   for (; bh < items; bh += gridDim.x) {
     const int b = bh / heads, head = bh % heads;
     if (!PREFETCH) load_item(bh, qf, ck, cv);    // (nothing carried across items: the registers are free during the compute)
-    store_rows(Ks, ck, nb * 32, tid);
-    store_rows(Vs, cv, nb * 32, tid);
+    store_rows<NT>(Ks, ck, nb * 32, tid);
+    store_rows<NT>(Vs, cv, nb * 32, tid);
     __syncthreads();
     const int next = bh + gridDim.x;
     if (PREFETCH && next < items) load_item(next, qn, nk, nv);   // in flight under this item's compute
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(512, PREFETCH ? 2 : 4) void vit_attn_fwd_kernel(con
 }
 
 // ================================================================ backward, query strips: dq (and D = rowsum(do .* o) for the dk/dv kernel)
-__global__ __launch_bounds__(512, 4) void vit_attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void vit_attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                               const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ Dsum, bf16_t* __restrict__ dqkv, int T, int heads,
                                                               float scale) {
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(512, 4) void vit_attn_bwd_dq_kernel(const bf16_t* _
   const float l = lse[(long long)bh * T + (qi < T ? qi : T - 1)];
   {
     Chunks ck, cv;
-    load_chunks(ck, k, ld, T, tid);
-    load_chunks(cv, v, ld, T, tid);
-    store_rows(Ks, ck, nb * 32, tid);
-    store_rows(Vs, cv, nb * 32, tid);
+    load_chunks<NT>(ck, k, ld, T, tid);
+    load_chunks<NT>(cv, v, ld, T, tid);
+    store_rows<NT>(Ks, ck, nb * 32, tid);
+    store_rows<NT>(Vs, cv, nb * 32, tid);
   }
   __syncthreads();
   f32x16 dqT[2];
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(512, 4) void vit_attn_bwd_dq_kernel(const bf16_t* _
 }
 
 // ================================================================ backward, key strips: dk, dv
-__global__ __launch_bounds__(512, 4) void vit_attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void vit_attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ Dsum,
                                                                bf16_t* __restrict__ dqkv, int T, int heads, float scale) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -373,11 +378,11 @@ __global__ __launch_bounds__(512, 4) void vit_attn_bwd_dkv_kernel(const bf16_t* 
   }
   {
     Chunks cq, cd;
-    load_chunks(cq, q, ld, T, tid);
-    load_chunks(cd, dO, D, T, tid);
+    load_chunks<NT>(cq, q, ld, T, tid);
+    load_chunks<NT>(cd, dO, D, T, tid);
     const float lv = tid < T ? lse[(long long)bh * T + tid] : 0.0f, dv = tid < T ? Dsum[(long long)bh * T + tid] : 0.0f;
-    store_rows(Qs, cq, nb * 32, tid);
-    store_rows(dOs, cd, nb * 32, tid);
+    store_rows<NT>(Qs, cq, nb * 32, tid);
+    store_rows<NT>(dOs, cd, nb * 32, tid);
     if (tid < nb * 32) { lseS[tid] = lv * 1.44269504088896340736f; DS[tid] = dv; }   // lse in the exp2 domain
   }
   __syncthreads();
@@ -476,22 +481,33 @@ extern "C" int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B,
   if (lds_bytes < (size_t)8 * 4096) lds_bytes = (size_t)8 * 4096;
   static mcl_device_once attr_once;
   if (auto attr_guard = attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_fwd_kernel<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   // Long sequences (T = 197): one workgroup per item without next-item registers -- four waves per SIMD, two workgroups per CU cover
   // each other's prologue (136-139 us per layer at B = 256 against 146-148 persistent).  Short ones (T = 50): the persistent walk
   // with the next item prefetched into registers (41 against 43.6 us).  MCL_VIT_ATTN_PERSIST=0 / 1 forces one form (A/B).
+  // One wave per 32-token strip: 128 / 256 / 512 threads for up to 64 / 128 / 224 tokens.
   const char* e_p = getenv("MCL_VIT_ATTN_PERSIST");
-  const int items = B * heads;
+  const int items = B * heads, nb = (T + 31) / 32;
   const bool persist = e_p ? e_p[0] != '0' : T <= 128;
-  const int grid = (items < 2 * mcl_cu_count() || !persist) ? items : mcl_cu_count();
-  if (grid < items)
-    hipLaunchKernelGGL(vit_attn_fwd_kernel<true>, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
-                       (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
-  else
-    hipLaunchKernelGGL(vit_attn_fwd_kernel<false>, dim3((unsigned)grid), dim3(512), lds_bytes, mcl_stream(stream),
-                       (const bf16_t*)qkv, (bf16_t*)o, lse, T, heads, scale, items);
+  const int wg_per_cu = nb <= 2 ? 4 : (nb <= 4 ? 2 : 1);           // persistent grid: eight waves per CU whatever the workgroup size
+  const int pgrid = mcl_cu_count() * wg_per_cu;
+  const int grid = (items < 2 * pgrid || !persist) ? items : pgrid;
+  hipStream_t st = mcl_stream(stream);
+#define MCL_FWD(PF, NTV)                                                                                              \
+  hipLaunchKernelGGL((vit_attn_fwd_kernel<PF, NTV>), dim3((unsigned)grid), dim3(NTV), lds_bytes, st, (const bf16_t*)qkv, \
+                     (bf16_t*)o, lse, T, heads, scale, items)
+  if (grid < items) {
+    if (nb <= 2) MCL_FWD(true, 128);
+    else if (nb <= 4) MCL_FWD(true, 256);
+    else MCL_FWD(true, 512);
+  } else {
+    if (nb <= 2) MCL_FWD(false, 128);
+    else if (nb <= 4) MCL_FWD(false, 256);
+    else MCL_FWD(false, 512);
+  }
+#undef MCL_FWD
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
@@ -505,17 +521,25 @@ extern "C" int mcl_vit_attn_bwd(const void* qkv, const void* o, const void* dout
     return MCL_EUNSUPPORTED;
   static mcl_device_once attr_once;
   if (auto attr_guard = attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_bwd_dq_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(vit_attn_bwd_dkv_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   hipStream_t st = mcl_stream(stream);
+  const int nb = (T + 31) / 32;
   size_t lds_dq = 2 * rows_bytes(T);
   if (lds_dq < (size_t)8 * 4096) lds_dq = (size_t)8 * 4096;
-  hipLaunchKernelGGL(vit_attn_bwd_dq_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_dq, st, (const bf16_t*)qkv, (const bf16_t*)o,
-                     (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);
-  const size_t lds_dkv = 2 * rows_bytes(T) + (size_t)((T + 31) / 32) * 32 * 8 + (size_t)8 * 2048;   // tiles, lse / D, staging rows (74 KB at T = 197: two workgroups per CU)
-  hipLaunchKernelGGL(vit_attn_bwd_dkv_kernel, dim3((unsigned)(B * heads)), dim3(512), lds_dkv, st, (const bf16_t*)qkv,
-                     (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);
+  const size_t lds_dkv = 2 * rows_bytes(T) + (size_t)nb * 32 * 8 + (size_t)8 * 2048;   // tiles, lse / D, staging rows (74 KB at T = 197: two workgroups per CU)
+#define MCL_BWD(NTV)                                                                                                   \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL((vit_attn_bwd_dq_kernel<NTV>), dim3((unsigned)(B * heads)), dim3(NTV), lds_dq, st, (const bf16_t*)qkv, \
+                       (const bf16_t*)o, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);             \
+    hipLaunchKernelGGL((vit_attn_bwd_dkv_kernel<NTV>), dim3((unsigned)(B * heads)), dim3(NTV), lds_dkv, st,           \
+                       (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum, (bf16_t*)dqkv, T, heads, scale);           \
+  } while (0)
+  if (nb <= 2) MCL_BWD(128);
+  else if (nb <= 4) MCL_BWD(256);
+  else MCL_BWD(512);
+#undef MCL_BWD
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
