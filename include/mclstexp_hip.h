@@ -189,7 +189,8 @@ int mcl_cast_f32_to_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int6
 /* ---- ViT image encoder on bf16 (csrc/gemm_bf16.hip, csrc/vit_ops.hip; /root/reference/model.py:104-116).
  * mcl_gemm_bf16: C[b] = epilogue(alpha * A[b] B[b]) with fp32 accumulation on the bf16 MFMA; per-operand storage flags
  * (bit 0: A stored reduction-major [K][M]; bit 1: B stored reduction-major [K][N]; default: A [M][K], B [N][K]),
- * bit 2: exact-erf GELU (pre_out != NULL also stores the pre-activation), bit 3: multiply by gelu'(aux), bit 4: fp32
+ * bit 2: exact-erf GELU (pre_out != NULL also stores the pre-activation; with bit 5: stores gelu'(pre-activation) instead),
+ * bit 3: multiply by gelu'(aux), bit 6: multiply by aux itself (aux = the derivative stored through bit 5), bit 4: fp32
  * output.  Two-level batch: problem bi = (bi / batch2, bi % batch2) with strides (s?b, s?b2) -- (image, head) for the
  * attention products.  bias [N] fp32, resid [M][N] bf16 (outer-batch stride sRb, 0 = broadcast).  Leading dimensions multiples of 8 (bf16) /
  * 4 (fp32 C); ragged M, N, K allowed; bf16 C needs ldc >= round_up(N, 8).  ksplit > 1 (fp32 output, batch 1, no

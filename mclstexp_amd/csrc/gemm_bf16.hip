@@ -194,15 +194,34 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmB& g, f32x16 (&acc)
             for (int e = 0; e < 8 && n + e < g.N; ++e) o[e] = v[e];
           }
         } else {
-          if (g.pre_out) {
-            *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
-                u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-          }
-          if (g.gelu) {
+          if (g.gelu == 2) {                           // GELU, and pre_out <- gelu'(pre-activation): one exp / rcp serves both
+            float gr[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            for (int e = 0; e < 8; ++e) {
+              float Phi, ex;
+              gelu_parts(v[e], Phi, ex);
+              gr[e] = fmaf(v[e] * 0.39894228040143267794f, ex, Phi);
+              v[e] *= Phi;
+            }
+            *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+                u32x4{pack_bf16(gr[0], gr[1]), pack_bf16(gr[2], gr[3]), pack_bf16(gr[4], gr[5]), pack_bf16(gr[6], gr[7])};
+          } else {
+            if (g.pre_out) {
+              *reinterpret_cast<u32x4*>(g.pre_out + (long long)m * g.ldp + n) =
+                  u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+            }
+            if (g.gelu) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            }
           }
-          if (g.gelu_bwd) {
+          if (g.gelu_bwd == 2) {                       // aux holds the stored derivative
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] *= bf_lo(xa[e]);
+              v[2 * e + 1] *= bf_hi(xa[e]);
+            }
+          } else if (g.gelu_bwd) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[2 * e] *= gelu_g(bf_lo(xa[e]));
@@ -547,7 +566,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_stag_kernel(GemmB g) {
 
 }  // namespace
 
-// flags: bit 0 A reduction-major, bit 1 B reduction-major, bit 2 GELU, bit 3 multiply by gelu'(aux), bit 4 fp32 output
+// flags: bit 0 A reduction-major, bit 1 B reduction-major, bit 2 GELU, bit 3 multiply by gelu'(aux), bit 4 fp32 output,
+// bit 5 (with bit 2 and pre_out): pre_out receives gelu'(pre-activation) instead of the pre-activation, bit 6: multiply by aux itself
+// (aux = that stored derivative): the backward's epilogue then needs no exp / rcp per element
 extern "C" int64_t mcl_gemm_bf16_workspace_floats(int32_t M, int64_t ldc, int32_t ksplit) {
   if (M <= 0 || ldc <= 0 || ksplit <= 1) return 0;
   return (int64_t)ksplit * ((int64_t)M * ldc + 64);
@@ -561,7 +582,9 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
                              int32_t accumulate, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch2 <= 0 || (batch % batch2)) return MCL_EINVAL;
-  const bool akm = flags & 1, bkm = flags & 2, gelu = flags & 4, gbwd = flags & 8, f32 = flags & 16;
+  const bool akm = flags & 1, bkm = flags & 2, gelu = flags & 4, gbwd = flags & (8 | 64), f32 = flags & 16;
+  const bool gelu_grad_out = flags & 32, aux_is_grad = flags & 64;
+  if (gelu_grad_out && (!gelu || !pre_out)) return MCL_EINVAL;
   if ((lda % 8) || (ldb % 8) || (reinterpret_cast<uintptr_t>(A) & 15u) || (reinterpret_cast<uintptr_t>(B) & 15u) ||
       (reinterpret_cast<uintptr_t>(C) & 15u) || (sAb % 8) || (sBb % 8) || (sAb2 % 8) || (sBb2 % 8) || (sCb % 4) || (sCb2 % 4))
     return MCL_EUNSUPPORTED;
@@ -581,7 +604,7 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   g.resid = (const bf16_t*)resid; g.ldr = ldr; g.sRb = sRb;
   g.aux = (const bf16_t*)aux; g.ldaux = ldaux;
   g.pre_out = (bf16_t*)pre_out; g.ldp = ldp;
-  g.gelu = gelu; g.gelu_bwd = gbwd; g.out_f32 = f32;
+  g.gelu = gelu ? (gelu_grad_out ? 2 : 1) : 0; g.gelu_bwd = gbwd ? (aux_is_grad ? 2 : 1) : 0; g.out_f32 = f32;
   // small problems (batched attention products) take the 128 x 128 tile, two workgroups per CU
   const int subs = (M <= 512 && N <= 512) ? 1 : 2;
   const int BMh = 128 * subs;

@@ -27,6 +27,7 @@ from .densenet_fused import _direct_grad_ok, _ws
 Tensor = torch.Tensor
 BF = torch.bfloat16
 A_KM, B_KM, GELU, GELU_BWD, OUT_F32 = 1, 2, 4, 8, 16
+GELU_GRAD_OUT, AUX_IS_GRAD = 32, 64           # fc1 stores gelu'(pre-activation); the data gradient multiplies by it directly
 
 
 def _st() -> int:
@@ -212,7 +213,7 @@ class ViTFn(torch.autograd.Function):
             Dh = m.fc1.out_features
             h1 = torch.empty((B, T, Dh), device=dev, dtype=BF)
             pre = torch.empty((B, T, Dh), device=dev, dtype=BF)
-            gemm(u2, _w16(m.fc1.weight), h1, M, Dh, D, D, D, Dh, flags=GELU, bias=m.fc1.bias, pre_out=pre, ldp=Dh)
+            gemm(u2, _w16(m.fc1.weight), h1, M, Dh, D, D, D, Dh, flags=GELU | GELU_GRAD_OUT, bias=m.fc1.bias, pre_out=pre, ldp=Dh)
             x2 = torch.empty_like(x)
             gemm(h1, _w16(m.fc2.weight), x2, M, D, Dh, Dh, Dh, D, bias=m.fc2.bias, resid=x1, ldr=D, sRb=0)
             saved += [x, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h1]
@@ -247,7 +248,7 @@ class ViTFn(torch.autograd.Function):
             # MLP
             _param_grads(dx, h1, m.fc2, M, grads)
             dpre = torch.empty((B, T, Dh), device=dev, dtype=BF)
-            gemm(dx, _w16(m.fc2.weight), dpre, M, Dh, D, D, Dh, Dh, flags=B_KM | GELU_BWD, aux=pre, ldaux=Dh)
+            gemm(dx, _w16(m.fc2.weight), dpre, M, Dh, D, D, Dh, Dh, flags=B_KM | AUX_IS_GRAD, aux=pre, ldaux=Dh)   # pre = gelu'
             _param_grads(dpre, u2, m.fc1, M, grads)
             du2 = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dpre, _w16(m.fc1.weight), du2, M, D, Dh, Dh, D, D, flags=B_KM)

@@ -141,6 +141,30 @@ def test_vit_fused_attention_vs_fp64(B, T, heads):
     assert torch.isfinite(dqkv.float()).all()
 
 
+def test_gemm_bf16_gelu_derivative_handoff():
+    """fc1 -> fc2 hand-off of the ViT MLP: the forward epilogue stores gelu'(pre-activation) beside gelu(pre-activation) (one
+    exp / rcp serves both), the data-gradient epilogue multiplies by that stored derivative (no transcendental per element)."""
+    from mclstexp_amd import vit_fused as vf
+    M, N, K = 1024, 768, 256
+    A = _r(M, K, seed=41).to(BF).to(DEV)
+    W = _r(N, K, seed=42, scale=0.3).to(BF).to(DEV)
+    bias = _r(N, seed=43).to(DEV)
+    h = torch.empty((M, N), device=DEV, dtype=BF)
+    gp = torch.empty((M, N), device=DEV, dtype=BF)
+    vf.gemm(A, W, h, M, N, K, K, K, N, flags=vf.GELU | vf.GELU_GRAD_OUT, bias=bias, pre_out=gp, ldp=N)
+    pre = (A.double() @ W.double().t() + bias.double()).cpu().requires_grad_(True)
+    ref_h = torch.nn.functional.gelu(pre)
+    ref_h.sum().backward()
+    assert_close(h.float().cpu(), ref_h.detach(), 4e-3, 2 ** -7, what="gelu")
+    assert_close(gp.float().cpu(), pre.grad, 4e-3, 2 ** -7, what="stored gelu'")
+    dy = _r(M, K, seed=44).to(BF).to(DEV)
+    W2 = _r(K, N, seed=45, scale=0.3).to(BF).to(DEV)               # dy (M, K) @ W2 (K, N) as the reduction-major operand
+    dpre = torch.empty((M, N), device=DEV, dtype=BF)
+    vf.gemm(dy, W2, dpre, M, N, K, K, N, N, flags=vf.B_KM | vf.AUX_IS_GRAD, aux=gp, ldaux=N)
+    ref = (dy.double() @ W2.double()) * gp.double()
+    assert_close(dpre.float().cpu(), ref.cpu(), 4e-3, 2 ** -7, what="dgrad * stored gelu'")
+
+
 def test_gemm_bf16_epilogues_and_batch():
     """bias + GELU (+ stored pre-activation), gelu' multiply, residual add, two-level batch with strides, fp32 output,
     split-K with accumulation (deterministic)."""

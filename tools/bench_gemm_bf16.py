@@ -49,14 +49,14 @@ for name, m, n, k, flags, epi in cases:
     if "bias" in epi:
         kw["bias"] = torch.randn(n, device=dev)
     if "gelu_pre" in epi:
-        flags |= vf.GELU
+        flags |= vf.GELU | (0 if os.environ.get("MCL_BENCH_OLD_GELU") == "1" else vf.GELU_GRAD_OUT)
         kw["pre_out"] = torch.empty((m, n), device=dev, dtype=BF)
         kw["ldp"] = n
     if "resid" in epi:
         kw["resid"] = torch.randn((m, n), device=dev).to(BF)
         kw["ldr"] = n
     if epi == "gelu_bwd":
-        flags |= vf.GELU_BWD
+        flags |= vf.GELU_BWD if os.environ.get("MCL_BENCH_OLD_GELU") == "1" else vf.AUX_IS_GRAD
         kw["aux"] = torch.randn((m, n), device=dev).to(BF)
         kw["ldaux"] = n
     t = timeit(lambda: vf.gemm(A, B, C, m, n, k, A.shape[1], B.shape[1], n, flags=flags, ksplit=ks, accumulate=False, **kw))
