@@ -65,6 +65,7 @@ def _w16(w: Tensor) -> Tensor:
     return w.detach().to(BF).contiguous()
 
 
+GELU_HANDOFF = os.environ.get("MCL_VIT_GELU_HANDOFF", "1") != "0"         # 0: fc1 stores the pre-activation, gelu' evaluated in the backward (A/B)
 FUSED_ATTN = os.environ.get("MCL_VIT_FUSED_ATTN", "1") != "0"            # 0: batched GEMMs + softmax launches (A/B, T > 224)
 JOIN_EVERY = int(os.environ.get("MCL_VIT_JOIN_EVERY", "4"))              # encoder blocks between joins of the side stream
 KSPLIT_TARGET = int(os.environ.get("MCL_VIT_KSPLIT_TARGET", "128"))     # workgroups a split-K weight gradient aims for (side lane: 60.5 ms/step at 256, 59.7 at 128)
@@ -213,7 +214,7 @@ class ViTFn(torch.autograd.Function):
             Dh = m.fc1.out_features
             h1 = torch.empty((B, T, Dh), device=dev, dtype=BF)
             pre = torch.empty((B, T, Dh), device=dev, dtype=BF)
-            gemm(u2, _w16(m.fc1.weight), h1, M, Dh, D, D, D, Dh, flags=GELU | GELU_GRAD_OUT, bias=m.fc1.bias, pre_out=pre, ldp=Dh)
+            gemm(u2, _w16(m.fc1.weight), h1, M, Dh, D, D, D, Dh, flags=GELU | (GELU_GRAD_OUT if GELU_HANDOFF else 0), bias=m.fc1.bias, pre_out=pre, ldp=Dh)
             x2 = torch.empty_like(x)
             gemm(h1, _w16(m.fc2.weight), x2, M, D, Dh, Dh, Dh, D, bias=m.fc2.bias, resid=x1, ldr=D, sRb=0)
             saved += [x, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h1]
@@ -248,7 +249,7 @@ class ViTFn(torch.autograd.Function):
             # MLP
             _param_grads(dx, h1, m.fc2, M, grads)
             dpre = torch.empty((B, T, Dh), device=dev, dtype=BF)
-            gemm(dx, _w16(m.fc2.weight), dpre, M, Dh, D, D, Dh, Dh, flags=B_KM | AUX_IS_GRAD, aux=pre, ldaux=Dh)   # pre = gelu'
+            gemm(dx, _w16(m.fc2.weight), dpre, M, Dh, D, D, Dh, Dh, flags=B_KM | (AUX_IS_GRAD if GELU_HANDOFF else GELU_BWD), aux=pre, ldaux=Dh)   # pre = gelu' (hand-off)
             _param_grads(dpre, u2, m.fc1, M, grads)
             du2 = torch.empty((B, T, D), device=dev, dtype=BF)
             gemm(dpre, _w16(m.fc1.weight), du2, M, D, Dh, Dh, D, D, flags=B_KM)
