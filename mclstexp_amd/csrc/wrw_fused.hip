@@ -450,8 +450,42 @@ void mcl_launch_wrw_merge(const float* wpart, int ks, long long MN, float* dW, i
                      (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, MN);
 }
 
+namespace {
+// Few slabs (split-K of the ViT weight gradients: 2 .. 16): a thread owns one float4 of the result, requests that float4 of every
+// slab before the first add and sums in slab order.  The many-slab kernel above gives a 256-thread workgroup 32 floats x 32
+// slab groups: with 4 slabs an eighth of its lanes load anything (1.8 TB/s on 60 MB merges).
+constexpr int FEW = 16;
+__global__ __launch_bounds__(256) void wrw_merge_few_kernel(const float* __restrict__ wpart, int ks, long long MN, long long stride,
+                                                            float* __restrict__ dW, int accumulate_w) {
+  const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= MN) return;
+  float4 v[FEW];
+#pragma unroll
+  for (int z = 0; z < FEW; ++z) {
+    v[z] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (z < ks) v[z] = *reinterpret_cast<const float4*>(wpart + (long long)z * stride + e);
+  }
+  float4 a = v[0];
+#pragma unroll
+  for (int z = 1; z < FEW; ++z) {
+    if (z < ks) { a.x += v[z].x; a.y += v[z].y; a.z += v[z].z; a.w += v[z].w; }
+  }
+  float4* o = reinterpret_cast<float4*>(dW + e);
+  if (accumulate_w) {
+    const float4 pv = *o;
+    a.x += pv.x; a.y += pv.y; a.z += pv.z; a.w += pv.w;
+  }
+  *o = a;
+}
+}  // namespace
+
 void mcl_launch_wrw_merge_strided(const float* wpart, int ks, long long MN, long long stride, float* dW, int accumulate_w,
                                   hipStream_t st) {
+  if (ks <= FEW && (MN % 4) == 0) {
+    hipLaunchKernelGGL(wrw_merge_few_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, st, wpart, ks, MN, stride, dW,
+                       accumulate_w);
+    return;
+  }
   const int nb = (int)((MN / 4 + MQ - 1) / MQ);
   hipLaunchKernelGGL(wrw_merge_kernel, dim3(nb), dim3(256), 0, st, wpart, ks, MN, 0, 1LL, dW, accumulate_w, 0,
                      (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, stride);
