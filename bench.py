@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--profile_steps", type=int, default=2,
                     help="eager steps after the timed region in which the hot C-ABI calls are timed with HIP events "
                          "(0 = no `roofline` object)")
+    ap.add_argument("--dense_tables", action="store_true",
+                    help="A/B: update every row of the two position tables on every step (1.57 GB of state traffic) instead of "
+                         "the lazy-exact form (optim.FusedAdam(lazy_tables=True): untouched rows are replayed on demand)")
     ap.add_argument("--launch_check", action="store_true",
                     help="only exercise the launcher + process group (works without a GPU, gloo): prints a JSON line")
     return ap.parse_args()
@@ -284,7 +287,7 @@ def main():
     if bb is not None:
         model.to(memory_format=torch.channels_last)
     model.train()
-    opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(model)
+    opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-3, lazy_tables=not args.dense_tables).attach_model(model)
     dist_on = pg is not None            # world > 1, or MCL_FORCE_DIST=1 (size-1 RCCL group: DP code path on one GPU)
     reducer = mdist.GradReducer(pg) if dist_on else None
 
@@ -341,6 +344,25 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Lazy-exact position tables: the rows no batch touched are advanced when the table is materialised (state_dict /
+    # checkpoint).  That work is deferred, not skipped -- time a full materialisation now (every row replays all the steps
+    # of this run) and report it separately and amortised over the steps it covers.
+    tables_info = {"mode": "dense: every row of both tables on every step"}
+    if opt.lazy_tables and opt._tables:
+        behind = opt._step_count - opt._lazy_flushed_at
+        torch.cuda.synchronize()
+        tm0 = time.perf_counter()
+        opt.materialize_tables()
+        torch.cuda.synchronize()
+        mat_ms = 1e3 * (time.perf_counter() - tm0)
+        tables_info = {"mode": "lazy-exact (optim.FusedAdam(lazy_tables=True)): rows a batch gathers / updates are replayed to "
+                               "the current step in registers, bit-identical to the dense per-step update "
+                               "(tests/test_lazy_tables_gpu.py); all other rows when the table is materialised",
+                       "full_materialize_ms": round(mat_ms, 3), "steps_replayed_per_row": behind,
+                       "amortized_ms_per_step": round(mat_ms / max(1, behind), 5),
+                       "note": "NOT inside the timed region: a checkpoint (model.state_dict()) pays full_materialize_ms once; "
+                               "ms_per_step + amortized_ms_per_step is the all-inclusive figure"}
+
     # per-kernel roofline: eager pass with HIP events around the hot C-ABI calls (rank 0's GPU; N = 1 only, so that the
     # collectives of the other ranks are not left waiting)
     roof_rows = []
@@ -384,6 +406,7 @@ def main():
                        "spot_path_mfma": args.compute, "infonce": args.infonce,
                        "infonce_effective": model.infonce_effective(gb), "hip_graphs": not args.no_graphs,
                        "optimizer": "Adam(lr=1e-4, wd=1e-3) incl. 2x(65536,G) tables",
+                       "position_tables": tables_info,
                        "dp_semantics": "spot-encoder attention and BatchNorm statistics are per shard (per GPU); "
                                        "InfoNCE is global over the all-gathered embeddings",
                        "dp_backward_segments": (len(trainer.seg_graphs) + 1 if (dist_on and trainer.seg_graphs) else None),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 5
+#define MCL_ABI_VERSION 6
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -536,6 +536,27 @@ int mcl_adam_table_step_dev(float* p, float* m, float* v, int32_t n_rows, int32_
  * precision weight copy the backbone kernels read), so no separate cast pass over the parameters runs after the step. */
 int mcl_adam_step_dev_shadow(float* p, const float* g, float* m, float* v, int64_t n, const float* consts,
                              void* shadow_bf16, mcl_stream_t stream);
+/* Lazy-exact position-table Adam (ABI 6).  Replaces, for the two (65536, G) tables of /root/reference/model.py:204-205 under
+ * /root/reference/train.py:118-120, the dense pass above: with L2 weight decay every row moves on every step, but a row
+ * without a data gradient follows a recurrence in its own (p, m, v) and the step constants only.  Each row carries a
+ * "valid through step" stamp (row_step, n_rows int32, 0 = initial state); a row is brought up to date by replaying its missed
+ * steps in registers -- the same fp32 operation sequence as the dense kernel, with the constants those steps used, kept in a
+ * ring `hist` of hist_len (power of two) x 8 floats that mcl_adam_consts_update_hist fills (slot = step & (hist_len - 1)) --
+ * so the result is bit-identical to running mcl_adam_table_step_dev on every step.  The caller guarantees that no row is
+ * more than hist_len - 1 steps behind (materialise in time).  One entry point, three uses; `step` = device step counter:
+ *   catch-up of gathered rows (forward): pos != NULL ((n_owner, 2) fp32 positions; table 0 takes column 0, table 1 column 1);
+ *       rows are advanced through *step; duplicates are resolved inside (first spot naming a row owns it);
+ *   step with data gradients: owner0/owner1 (n_owner int32: row index or -1, as mcl_embed_rowgrad writes them) and
+ *       row_grad0/row_grad1 ((n_owner, cols) fp32, leading dimension ld_rg); *step is the step being applied (already advanced
+ *       by mcl_adam_consts_update_hist): rows are replayed through *step - 1, then updated with g = wd*p + row_grad;
+ *   materialise: pos, owner*, row_grad* all NULL and n_owner == n_rows: every row is advanced through *step.
+ * Table 1 is optional (p1 == NULL).  Algorithmic bytes: 24 B x touched rows x cols (+ the gradient rows).                */
+int mcl_adam_consts_update_hist(int64_t* step, float* consts, const double* hyper, float* hist, int32_t hist_len,
+                                mcl_stream_t stream);
+int mcl_adam_table_lazy(float* p0, float* m0, float* v0, int32_t* row_step0, float* p1, float* m1, float* v1,
+                        int32_t* row_step1, int32_t n_rows, int32_t cols, const float* pos, const int32_t* owner0,
+                        const int32_t* owner1, int32_t n_owner, const float* row_grad0, const float* row_grad1, int64_t ld_rg,
+                        const int64_t* step, const float* hist, int32_t hist_len, mcl_stream_t stream);
 /* row_slot maintenance: set row_slot[owner_idx[b]] = b for owners (fill != 0) or back to -1.    */
 int mcl_row_slot_update(int32_t* row_slot, const int32_t* owner_idx, int32_t B, int32_t fill, mcl_stream_t stream);
 

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib: Optional[C.CDLL] = None
 
@@ -143,6 +143,9 @@ PROTOTYPES = {
     "mcl_adam_step_dev": [c_p, c_p, c_p, c_p, c_l, c_p, c_p],
     "mcl_adam_table_step_dev": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
+    "mcl_adam_consts_update_hist": [c_p, c_p, c_p, c_p, c_i, c_p],
+    "mcl_adam_table_lazy": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p, c_p, c_i,
+                            c_p],
     "mcl_bn_act_avgpool_fwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "mcl_bn_act_avgpool_bwd": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l,
                                c_p],

@@ -21,12 +21,16 @@ struct AdamC {
   float lr_over_bc1, beta1, beta2, omb1, omb2, eps, wd, rsqrt_bc2;  // omb = 1 - beta, rounded from double
 };
 
+// The operation sequence is spelled out instruction by instruction (contraction off, every fused multiply-add explicit):
+// the lazy table kernels below replay missed steps of a row in registers and must reproduce, bit for bit, what the dense
+// pass would have computed step by step -- whatever the surrounding code the compiler inlines this into.
+#pragma clang fp contract(off)
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamC& c) {
   g = fmaf(c.wd, p, g);                         // grad.add(param, alpha=wd)
   m = fmaf(c.omb1, g - m, m);                   // exp_avg.lerp_(grad, 1-beta1)
-  v = fmaf(c.beta2, v, c.omb2 * g * g);         // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
-  const float denom = sqrtf(v) * c.rsqrt_bc2 + c.eps;
-  p -= c.lr_over_bc1 * (m / denom);
+  v = fmaf(c.beta2, v, (c.omb2 * g) * g);       // exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)
+  const float denom = fmaf(sqrtf(v), c.rsqrt_bc2, c.eps);
+  p = fmaf(-c.lr_over_bc1, m / denom, p);
 }
 
 __device__ __forceinline__ unsigned bf16_rne(float f) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void adam_table_kernel(float* __restrict__ p, 
 // The hyper-parameters (lr, beta1, beta2, eps, weight_decay) are READ FROM DEVICE MEMORY too: a by-value kernel argument
 // is frozen into a captured graph, so an LR schedule or a manual param_groups edit would be ignored by every replay.
 __global__ void adam_consts_kernel(long long* __restrict__ step, AdamC* __restrict__ out,
-                                   const double* __restrict__ hyper) {
+                                   const double* __restrict__ hyper, AdamC* __restrict__ hist, int hmask) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
   const long long t = *step + 1;
@@ -154,6 +158,104 @@ __global__ void adam_consts_kernel(long long* __restrict__ step, AdamC* __restri
   c.wd = (float)wd;
   c.rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
   *out = c;
+  // the lazy position-table update replays a row's missed steps later with exactly the constants those steps used (an LR
+  // schedule included): they are kept in a ring indexed by the step number
+  if (hist) hist[t & hmask] = c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Lazy-exact position-table Adam (hard part 1(b); reference: train.py:118-120 over model.py:204-205).
+// torch.optim.Adam with L2 weight decay moves EVERY row of the two (65536, G) tables on every step (g = wd * p where the
+// data gradient is zero): 1.57 GB of state traffic per step for 64-128 touched rows.  But a row without a data gradient
+// follows a recurrence in its own (p, m, v) and the step's constants only, so it need not be advanced until somebody
+// looks at it: every row carries a "valid through step" stamp; a row is brought up to date -- the missed steps replayed in
+// registers, the same fp32 operation sequence (adam1) with the recorded per-step constants, hence bit-identical to the
+// dense pass -- when it is gathered by the forward, when it receives a data gradient, or when the table is materialised
+// (state_dict / checkpoint / a direct module call).  One workgroup per row; a row that is current exits after one load.
+struct LazyTable {
+  float* p;
+  float* m;
+  float* v;
+  int* row_step;
+  const int* owner;     // per workgroup: the row to process (< 0: nothing); nullptr: from `pos`, or row = workgroup index
+  const float* rg;      // per workgroup: the row's data gradient for THIS step (nullptr: catch-up only)
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void adam_table_lazy_kernel(LazyTable t0, LazyTable t1, int per_table, int n_rows,
+                                                              int cols, const float* __restrict__ pos, long long ldrg,
+                                                              const long long* __restrict__ step,
+                                                              const AdamC* __restrict__ hist, int hmask) {
+  const int which = blockIdx.x >= (unsigned)per_table;
+  const int b = blockIdx.x - (which ? per_table : 0);
+  const LazyTable T = which ? t1 : t0;
+  int row;
+  if (pos) {
+    // forward catch-up: the row this spot gathers; the first spot of the batch that names a row owns it
+    __shared__ int dup_before;
+    long long i = (long long)pos[2 * b + which];          // .long(): truncation toward zero (model.py:230-231)
+    i = i < 0 ? 0 : (i >= n_rows ? n_rows - 1 : i);       // (out-of-range positions are flagged by the gather kernel)
+    row = (int)i;
+    if (threadIdx.x == 0) dup_before = 0;
+    __syncthreads();
+    int found = 0;
+    for (int j = threadIdx.x; j < b; j += 256) {
+      long long q = (long long)pos[2 * j + which];
+      q = q < 0 ? 0 : (q >= n_rows ? n_rows - 1 : q);
+      found |= ((int)q == row);
+    }
+    if (found) dup_before = 1;
+    __syncthreads();
+    if (dup_before) return;
+  } else {
+    row = T.owner ? T.owner[b] : b;
+    if (row < 0) return;
+  }
+  row = __builtin_amdgcn_readfirstlane(row);
+  const int t = __builtin_amdgcn_readfirstlane((int)*step);
+  const int rs = __builtin_amdgcn_readfirstlane(T.row_step[row]);
+  const bool has_g = T.rg != nullptr;
+  const int last_zero = has_g ? t - 1 : t;                // steps (rs, last_zero] are replayed with a zero data gradient
+  if (!has_g && rs >= last_zero) return;
+  __syncthreads();                                        // every wave has read the stamp before it is rewritten
+  const long long base = (long long)row * cols;
+  const float* g = has_g ? T.rg + (long long)b * ldrg : nullptr;
+  if (VEC) {
+    const int c4 = cols >> 2;
+    for (int i = threadIdx.x; i < c4; i += 256) {
+      float4 pp = reinterpret_cast<const float4*>(T.p + base)[i];
+      float4 mm = reinterpret_cast<const float4*>(T.m + base)[i];
+      float4 vv = reinterpret_cast<const float4*>(T.v + base)[i];
+      for (int s = rs + 1; s <= last_zero; ++s) {
+        const AdamC c = hist[s & hmask];
+        adam1(pp.x, 0.0f, mm.x, vv.x, c);
+        adam1(pp.y, 0.0f, mm.y, vv.y, c);
+        adam1(pp.z, 0.0f, mm.z, vv.z, c);
+        adam1(pp.w, 0.0f, mm.w, vv.w, c);
+      }
+      if (has_g) {
+        const AdamC c = hist[t & hmask];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, c);
+        adam1(pp.y, gg.y, mm.y, vv.y, c);
+        adam1(pp.z, gg.z, mm.z, vv.z, c);
+        adam1(pp.w, gg.w, mm.w, vv.w, c);
+      }
+      reinterpret_cast<float4*>(T.p + base)[i] = pp;
+      reinterpret_cast<float4*>(T.m + base)[i] = mm;
+      reinterpret_cast<float4*>(T.v + base)[i] = vv;
+    }
+  } else {
+    for (int i = threadIdx.x; i < cols; i += 256) {
+      float pp = T.p[base + i], mm = T.m[base + i], vv = T.v[base + i];
+      for (int s = rs + 1; s <= last_zero; ++s) adam1(pp, 0.0f, mm, vv, hist[s & hmask]);
+      if (has_g) adam1(pp, g[i], mm, vv, hist[t & hmask]);
+      T.p[base + i] = pp;
+      T.m[base + i] = mm;
+      T.v[base + i] = vv;
+    }
+  }
+  if (threadIdx.x == 0) T.row_step[row] = t;
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
@@ -238,7 +340,48 @@ extern "C" int mcl_adam_consts_update(int64_t* step, float* consts /* 8 floats *
   MCL_CLEAR_ERROR();
   if (!step || !consts || !hyper) return MCL_EINVAL;
   hipLaunchKernelGGL(adam_consts_kernel, dim3(1), dim3(64), 0, mcl_stream(stream), (long long*)step,
-                     reinterpret_cast<AdamC*>(consts), hyper);
+                     reinterpret_cast<AdamC*>(consts), hyper, (AdamC*)nullptr, 0);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_adam_consts_update_hist(int64_t* step, float* consts, const double* hyper, float* hist,
+                                           int32_t hist_len, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!step || !consts || !hyper || !hist || hist_len < 2 || (hist_len & (hist_len - 1))) return MCL_EINVAL;
+  hipLaunchKernelGGL(adam_consts_kernel, dim3(1), dim3(64), 0, mcl_stream(stream), (long long*)step,
+                     reinterpret_cast<AdamC*>(consts), hyper, reinterpret_cast<AdamC*>(hist), hist_len - 1);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_adam_table_lazy(float* p0, float* m0, float* v0, int32_t* row_step0, float* p1, float* m1, float* v1,
+                                   int32_t* row_step1, int32_t n_rows, int32_t cols, const float* pos,
+                                   const int32_t* owner0, const int32_t* owner1, int32_t n_owner, const float* row_grad0,
+                                   const float* row_grad1, int64_t ld_rg, const int64_t* step, const float* hist,
+                                   int32_t hist_len, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!p0 || !m0 || !v0 || !row_step0 || n_rows <= 0 || cols <= 0 || n_owner <= 0 || !step || !hist || hist_len < 2 ||
+      (hist_len & (hist_len - 1)))
+    return MCL_EINVAL;
+  const bool two = p1 != nullptr;
+  if (two && (!m1 || !v1 || !row_step1)) return MCL_EINVAL;
+  if (row_grad0 && !owner0) return MCL_EINVAL;                                                  // a gradient needs its owner list
+  if (row_grad0 && (pos || (two && (!row_grad1 || !owner1)))) return MCL_EINVAL;
+  if (!pos && !owner0 && n_owner != n_rows) return MCL_EINVAL;                                  // materialise: every row
+  LazyTable t0{p0, m0, v0, row_step0, owner0, row_grad0};
+  LazyTable t1{p1, m1, v1, row_step1, owner1, row_grad1};
+  const bool vec = (cols % 4 == 0) && (ld_rg % 4 == 0) && al16(p0) && al16(m0) && al16(v0) && al16(row_grad0) &&
+                   (!two || (al16(p1) && al16(m1) && al16(v1) && al16(row_grad1)));
+  const unsigned grid = (unsigned)n_owner * (two ? 2u : 1u);
+  if (vec)
+    hipLaunchKernelGGL((adam_table_lazy_kernel<true>), dim3(grid), dim3(256), 0, mcl_stream(stream), t0, t1, n_owner,
+                       n_rows, cols, pos, (long long)ld_rg, (const long long*)step, reinterpret_cast<const AdamC*>(hist),
+                       hist_len - 1);
+  else
+    hipLaunchKernelGGL((adam_table_lazy_kernel<false>), dim3(grid), dim3(256), 0, mcl_stream(stream), t0, t1, n_owner,
+                       n_rows, cols, pos, (long long)ld_rg, (const long long*)step, reinterpret_cast<const AdamC*>(hist),
+                       hist_len - 1);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -378,7 +378,9 @@ class TrainStep:
             return self._eager_ragged(batch)
         self._stage_inputs(batch)
         if self.opt_in_graph:
-            self.opt.sync_hyper()                # an LR schedule / param_groups edit reaches the replayed optimizer
+            # an LR schedule / param_groups edit reaches the replayed optimizer; the lazy position tables are materialised
+            # before the constants' history ring wraps
+            (self.opt.pre_replay if hasattr(self.opt, "pre_replay") else self.opt.sync_hyper)()
         self.ga.replay()
         if self.single_graph:
             if self.opt_in_graph:

@@ -115,6 +115,11 @@ def _adam_table(a):             # (p, m, v, rows, cols, ...): read p, m, v; writ
     return 24 * a[3] * a[4]
 
 
+def _adam_table_lazy(a):        # (p0, m0, v0, rs0, p1, ..., n_rows, cols, pos, own0, own1, n_owner, rg0, rg1, ...): <= n_owner rows per table
+    tables = 2 if a[4] else 1
+    return tables * a[13] * a[9] * (24 + (4 if a[14] else 0))
+
+
 def _adam(a):                   # (p, g, m, v, n, ...): read p, g, m, v; write p, m, v
     return 28 * a[4]
 
@@ -155,6 +160,8 @@ TABLE = {
     "mcl_dense_conv3x3_fwd": _e("conv3x3_fwd_rows_kernel + sums_finalize_kernel (56x56, 28x28 maps) / conv3x3_fwd_kernel + "
                                 "tile_stats_finalize_kernel", _conv3x3_fwd, flops=_conv3x3_flops_S1, bound="mfma/lds"),
     "mcl_adam_table_step_dev": _e("adam_table_kernel", _adam_table, bound="hbm"),
+    "mcl_adam_table_lazy": _e("adam_table_lazy_kernel (catch-up of gathered rows / update of the rows with a gradient)",
+                              _adam_table_lazy, bound="latency"),
     "mcl_adam_step_dev": _e("adam_kernel", _adam, bound="hbm"),
     "mcl_adam_step_dev_shadow": _e("adam_kernel<shadow> (update + bf16 shadow of the parameters)", _adam_shadow, bound="hbm"),
 }

@@ -276,10 +276,19 @@ class _ContrastiveBase(nn.Module):
             enc = self.image_ecode
         return self._encode_image(enc, image)
 
+    # FusedAdam(lazy_tables=True).attach_model installs its catch-up here: the rows this batch gathers are brought up to the
+    # current optimisation step before they are read (optim.py; the untouched rows of the tables are advanced lazily)
+    _table_catchup = None
+
     def _spot_features(self, batch) -> Tensor:
         sink = self.sparse_grads if (self.embedding_grad == "rowsparse" and torch.is_grad_enabled()) else None
-        return ops.PosEmbedAddFn.apply(batch["expression"], batch["position"], self.x_embed.weight,
-                                       self.y_embed.weight, sink)
+        pos = batch["position"]
+        if self._table_catchup is not None and pos.is_cuda:
+            if pos.dtype != torch.float32:
+                pos = pos.to(torch.float32)
+            pos = pos.contiguous()
+            self._table_catchup(pos)
+        return ops.PosEmbedAddFn.apply(batch["expression"], pos, self.x_embed.weight, self.y_embed.weight, sink)
 
     # "infonce": the reference's identity-target symmetric cross entropy (model.py:242-247).  "bleep" / "bleep_vit": the
     # soft-target CLIP loss of the reference's main baseline (baselines/Bleep/models.py:34-43 / 66-76) on the same

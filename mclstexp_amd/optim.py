@@ -7,6 +7,16 @@ single HBM-streaming launch (28 B/element) and, under data parallelism, the flat
 the all-reduce bucket (no packing copies).  The two (65536, G) position tables are updated by a
 second kernel that reads no dense gradient: untouched rows see g = wd*p exactly as in the reference
 (whose dense autograd gradient is zero there), touched rows add the row-sparse data gradient.
+
+Lazy-exact tables (default, ``lazy_tables=True``; SURVEY section 7 hard part 1(b)): an untouched row follows a
+recurrence in its own (p, m, v) and the step constants only, so it is not advanced until somebody looks at it.
+Every row carries a "valid through step" stamp; the rows a batch gathers are brought up to date just before the
+forward reads them (``catch_up``), the rows that receive a data gradient are replayed and updated in ``step()``,
+and everything else is replayed -- bit-identically to the dense pass, same fp32 operation sequence with the
+recorded per-step constants -- when the table is *materialised*: ``state_dict()`` of the model or the optimizer,
+``load_state_dict``, a direct call of ``model.x_embed`` / ``model.y_embed``, ``materialize_tables()``, or when
+the constants' history ring (HIST_LEN steps) is about to wrap.  Reading ``model.x_embed.weight`` directly
+between steps without one of these sees rows as of their last touch: call ``materialize_tables()`` first.
 """
 from __future__ import annotations
 
@@ -22,12 +32,19 @@ from ._lib import check
 Tensor = torch.Tensor
 
 
+HIST_LEN = 8192      # per-step Adam constants kept for the lazy tables' replay (power of two; 32 B per step)
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-3, process_group=None):
+                 weight_decay: float = 1e-3, process_group=None, lazy_tables: bool = True):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.process_group = process_group
+        self.lazy_tables = bool(lazy_tables)
+        self._lazy_flushed_at = 0                 # step count at which every table row was last current
+        self._lazy_dirty = False                  # some row may be behind the step counter
+        self.materialize_count = 0
         self._step_count = 0
         self._flat: Dict[int, dict] = {}          # group index -> flat buffers
         self._tables: Dict[int, dict] = {}        # id(param) -> table state
@@ -53,6 +70,15 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 self._group_of[id(p)] = gi
+        if self._tables and self.lazy_tables:
+            # the forward brings the rows it gathers up to date (model._spot_features); whoever reads a whole table
+            # through the module API gets it materialised first
+            model._table_catchup = self.catch_up
+            model.register_state_dict_pre_hook(lambda mod, prefix, keep_vars: self.materialize_tables())
+            if hasattr(model, "register_load_state_dict_pre_hook"):
+                model.register_load_state_dict_pre_hook(lambda *a, **k: self.materialize_tables())
+            for emb in (model.x_embed, model.y_embed):
+                emb.register_forward_pre_hook(lambda mod, inp: self.materialize_tables())
         # The position tables can be updated as soon as their gradient rows exist -- from inside PosEmbedAddFn.backward, on
         # the side stream, under the latency-bound part of the image backbone's backward -- instead of in step().  That
         # changes what a bare ``loss.backward()`` does, so it is engine.TrainStep that switches it on, only while it captures
@@ -195,8 +221,24 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         L = _lib.lib()
         st = ops._stream()
+        lazy = self._lazy_active()
+        tables_pending = self._sink is not None and (self._sink.get("tables_done", False) or "dout" in self._sink)
+        skipped_tables = lazy and not tables_pending and any(self.state.get(t["param"]) for t in self._tables.values())
+        if skipped_tables:
+            # a step in which the tables received no gradient at all: torch.optim.Adam skips a parameter whose .grad is
+            # None, so no row may move -- every row is made current first and stamped with the new step count below
+            self.materialize_tables()
         self._begin_step()
+        if skipped_tables:
+            for t in self._tables.values():
+                stt = self.state.get(t["param"])
+                if stt:
+                    stt["row_step"].fill_(self._step_count + 1)
+            self._lazy_flushed_at = self._step_count + 1
         tables_done = self._sink is not None and self._sink.pop("tables_done", False)
+        if lazy and tables_pending and not tables_done:
+            self._tables_step_lazy(L, st)
+            tables_done = True
         deferred = []
         for gi, group in enumerate(self.param_groups):
             if gi not in self._flat:
@@ -262,7 +304,9 @@ class FusedAdam(torch.optim.Optimizer):
             d = {"step": torch.full((1,), self._step_count, dtype=torch.int64, device=device),
                  "consts": torch.zeros(8, dtype=torch.float32, device=device),
                  # {lr, beta1, beta2, eps, weight_decay} as the kernels read them (device) and as last uploaded (host)
-                 "hyper": torch.zeros(5, dtype=torch.float64, device=device), "hyper_host": None}
+                 "hyper": torch.zeros(5, dtype=torch.float64, device=device), "hyper_host": None,
+                 # the constants of the last HIST_LEN steps (slot = step mod HIST_LEN): what the lazy tables replay with
+                 "hist": torch.zeros(8 * HIST_LEN, dtype=torch.float32, device=device)}
             self._dev[gi] = d
         return d
 
@@ -310,6 +354,8 @@ class FusedAdam(torch.optim.Optimizer):
             return
         self._began = True
         self.sync_hyper()
+        self._flush_if_due()
+        self._lazy_dirty = True
         L = _lib.lib()
         st = ops._stream()
         for gi, group in enumerate(self.param_groups):
@@ -317,8 +363,15 @@ class FusedAdam(torch.optim.Optimizer):
             if dev is None:
                 continue
             d = self._dev_state(gi, dev)
-            check(L.mcl_adam_consts_update(d["step"].data_ptr(), d["consts"].data_ptr(), d["hyper"].data_ptr(), st),
-                  "mcl_adam_consts_update")
+            check(L.mcl_adam_consts_update_hist(d["step"].data_ptr(), d["consts"].data_ptr(), d["hyper"].data_ptr(),
+                                                d["hist"].data_ptr(), HIST_LEN, st), "mcl_adam_consts_update_hist")
+
+    def pre_replay(self) -> None:
+        """Host-side work that must precede the replay of a captured step (engine.TrainStep): hyper-parameter upload and,
+        every HIST_LEN - 2 steps, the materialisation that keeps every table row inside the constants' history ring."""
+        self._lazy_dirty = True                  # the replay advances the step counter: every untouched row falls behind
+        self.sync_hyper()
+        self._flush_if_due()
 
     def _early_tables(self) -> None:
         """Called by ops.PosEmbedAddFn.backward once sink['dout'|'ix'|'iy'] exist (single process)."""
@@ -327,10 +380,119 @@ class FusedAdam(torch.optim.Optimizer):
         L = _lib.lib()
         st = ops._stream()
         self._begin_step()
+        if self._lazy_active():
+            self._tables_step_lazy(L, st)
+        else:
+            for tab in self._tables.values():
+                p = tab["param"]
+                self._table_step(L, st, p, tab, self._group_of[id(p)])
+        self._sink["tables_done"] = True
+
+    # ------------------------------------------------------------------ lazy-exact tables
+    def _lazy_active(self) -> bool:
+        return self.lazy_tables and bool(self._tables) and self._sink is not None
+
+    def _lazy_state(self, p) -> dict:
+        state = self.state[p]
+        if not state:
+            state["exp_avg"] = torch.zeros_like(p)
+            state["exp_avg_sq"] = torch.zeros_like(p)
+        if "row_step" not in state:
+            # "valid through step" per row: everything is current as of now
+            state["row_step"] = torch.full((p.shape[0],), self._step_count, device=p.device, dtype=torch.int32)
+        return state
+
+    def _lazy_groups(self):
+        """[(group index, [table params])] -- the tables of one param group share its step counter and history."""
+        by = {}
         for tab in self._tables.values():
             p = tab["param"]
-            self._table_step(L, st, p, tab, self._group_of[id(p)])
-        self._sink["tables_done"] = True
+            by.setdefault(self._group_of.get(id(p), 0), []).append((tab["key"], p))
+        return [(gi, [p for _, p in sorted(v, key=lambda kv: kv[0])], [k for k, _ in sorted(v, key=lambda kv: kv[0])])
+                for gi, v in by.items()]
+
+    def _lazy_launch(self, L, st, gi, ps, pos=None, owners=None, grads=None, ld_rg=0, n_owner=None) -> None:
+        d = self._dev_state(gi, ps[0].device)
+        sts = [self._lazy_state(p) for p in ps]
+        for i in range(0, len(ps), 2):
+            two = i + 1 < len(ps)
+            p0, s0 = ps[i], sts[i]
+            p1, s1 = (ps[i + 1], sts[i + 1]) if two else (None, None)
+            own = owners[i:i + 2] if owners is not None else [None, None]
+            gr = grads[i:i + 2] if grads is not None else [None, None]
+
+            def ptr(t):
+                return t.data_ptr() if t is not None else None
+            check(L.mcl_adam_table_lazy(p0.data_ptr(), s0["exp_avg"].data_ptr(), s0["exp_avg_sq"].data_ptr(),
+                                        s0["row_step"].data_ptr(), ptr(p1), ptr(s1["exp_avg"]) if two else None,
+                                        ptr(s1["exp_avg_sq"]) if two else None, ptr(s1["row_step"]) if two else None,
+                                        p0.shape[0], p0.shape[1], ptr(pos), ptr(own[0]), ptr(own[1]) if two else None,
+                                        n_owner if n_owner is not None else p0.shape[0], ptr(gr[0]),
+                                        ptr(gr[1]) if two else None, ld_rg, d["step"].data_ptr(), d["hist"].data_ptr(),
+                                        HIST_LEN, st), "mcl_adam_table_lazy")
+
+    def catch_up(self, pos: Tensor) -> None:
+        """Bring the table rows a batch is about to gather up to the current step (pos: (B, 2) fp32 on the device, column 0
+        indexes x_embed, column 1 y_embed).  Called by the model's forward in every mode; one small launch."""
+        if not self._lazy_active() or not (self._lazy_dirty or torch.cuda.is_current_stream_capturing()):
+            return                  # (a capture always records the launch: the flag describes the host's present, not a replay's)
+        L, st = _lib.lib(), ops._stream()
+        for gi, ps, keys in self._lazy_groups():
+            if keys != ["ix", "iy"] or ps[0].shape != ps[1].shape:
+                raise RuntimeError("lazy position tables expect x_embed and y_embed in one param group")
+            self._lazy_launch(L, st, gi, ps, pos=pos, n_owner=pos.shape[0])
+
+    def _tables_step_lazy(self, L, st) -> None:
+        """This step's update of the rows that received a data gradient (both tables, one launch): each is replayed
+        through the previous step and then updated with g = wd*p + its gradient row."""
+        dout, ix, iy = self._gathered()
+        for gi, ps, keys in self._lazy_groups():
+            rss = [ops.embed_rowgrad(dout, ix if k == "ix" else iy) for k in keys]
+            self._lazy_launch(L, st, gi, ps, owners=[r.owner_idx for r in rss], grads=[r.rows for r in rss],
+                              ld_rg=rss[0].rows.stride(0), n_owner=rss[0].rows.shape[0])
+        self._lazy_dirty = True
+
+    @torch.no_grad()
+    def materialize_tables(self) -> None:
+        """Replay every row of the position tables up to the current step (bit-identical to the dense per-step update)."""
+        if not self._lazy_active() or not self._lazy_dirty:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedAdam.materialize_tables() inside a graph capture")
+        L, st = _lib.lib(), ops._stream()
+        for gi, ps, keys in self._lazy_groups():
+            ps = [p for p in ps if self.state.get(p)]
+            if ps:
+                self._lazy_launch(L, st, gi, ps)
+        self._lazy_flushed_at = self._step_count
+        self._lazy_dirty = False
+        self.materialize_count += 1
+
+    def _flush_if_due(self) -> None:
+        if (self._lazy_active() and self._lazy_dirty and self._step_count + 1 - self._lazy_flushed_at >= HIST_LEN - 1
+                and not torch.cuda.is_current_stream_capturing()):
+            self.materialize_tables()
+
+    def state_dict(self):
+        self.materialize_tables()
+        sd = super().state_dict()
+        sd["mcl_step_count"] = self._step_count
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        n = state_dict.pop("mcl_step_count", None)
+        super().load_state_dict(state_dict)
+        if n is not None:
+            self._step_count = int(n)
+            for d in self._dev.values():
+                d["step"].fill_(self._step_count)
+            for tab in self._tables.values():
+                stt = self.state.get(tab["param"])
+                if stt and "row_step" in stt:
+                    stt["row_step"].fill_(self._step_count)
+            self._lazy_flushed_at = self._step_count
+            self._lazy_dirty = False
 
     # ------------------------------------------------------------------ tables
     def _gathered(self):

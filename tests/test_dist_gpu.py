@@ -53,6 +53,7 @@ def _worker(rank, world, port, ret):
             red.reduce(opt)
             opt.step()
             losses.append(l.item())
+        opt.materialize_tables()
         chk = {n: p.detach().double().sum().item() for n, p in m.named_parameters()}
         touched = m.x_embed.weight.detach()[:64].cpu()
         ret[rank] = dict(loss=loss.item(), d_es=d_es.cpu(), d_ei=d_ei.cpu(), losses=losses, chk=chk, xrows=touched,
@@ -126,6 +127,7 @@ def _ragged_worker(rank, world, port, ret):
             pos[:2, 1] = 3.0
             losses.append(tr({k: v.cuda() for k, v in b.items()}).item())
             embs.append((m.last["spot_embeddings"].cpu(), m.last["image_embeddings"].cpu()))
+        opt.materialize_tables()
         ret[rank] = dict(losses=losses, embs=embs, sizes=mdist.step_sizes(),
                          params={n: p.detach().cpu() for n, p in m.named_parameters() if "embed" not in n},
                          xrows=m.x_embed.weight.detach()[:64].cpu(), yrows=m.y_embed.weight.detach()[:64].cpu(),

@@ -25,6 +25,7 @@ def _run(graphs, encoder, steps=7, B=8, G=171, hw=64, single_graph=None):
         batch = {k: v.to(DEV) for k, v in synth.make_batch(B, G, seed=s, **kw).items()}
         losses.append(tr(batch).item())
     dn.set_weight_provider(None)
+    opt.materialize_tables()         # lazy position tables: rows no batch touched are advanced on demand (optim.py)
     return losses, {n: p.detach().clone() for n, p in m.named_parameters()}, tr
 
 
@@ -83,6 +84,7 @@ def test_ragged_batch_falls_back_to_eager():
             batch = {k: v.to(DEV) for k, v in synth.make_batch(b, G, image_dim=1024, seed=s).items()}
             losses.append(tr(batch).item())
             row = int(batch["position"][0, 0].item())
+            opt.materialize_tables()     # (between replays: the untouched row below is advanced lazily, optim.py)
             snaps.append((row, m.x_embed.weight[row].detach().clone(), m.x_embed.weight[60000].detach().clone(),
                           m.y_embed.weight[int(batch["position"][0, 1].item())].detach().clone()))
         dn.set_weight_provider(None)
