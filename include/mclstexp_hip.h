@@ -504,6 +504,32 @@ int mcl_gap_nhwc_fwd(const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t 
 int mcl_gap_nhwc_bwd(const float* g, int32_t B, int32_t HW, int32_t C, int32_t dtype, void* dx, mcl_stream_t stream);
 int mcl_add_relu(const void* a, const void* b, void* y, int64_t n, int32_t backward, int32_t dtype, mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- a whole dense block, forward, 7 x 7 maps (ABI 6)
+ * torchvision _DenseBlock (/root/reference/model.py:75-76: densenet121(...).features.denseblock4) in train mode as ONE
+ * persistent launch: replaces, per layer, mcl_dense_conv1x1_fwd + mcl_dense_conv3x3_fwd (and their statistics finalize
+ * launches) on H = W = 7 maps.  One workgroup per image (B <= compute units, all resident); the batch statistics are
+ * exchanged in-launch (two all-to-all seams per layer, write-through stores + flags, fixed-order merges: deterministic).
+ *   buf        (B, 7, 7, Ct) bf16 NHWC concat buffer, Ct = C0 + 32*L <= 1024; channels [0, C0) hold the block input on entry,
+ *              channels [C0, Ct) are written;
+ *   layer_ptrs HOST array of 10*L pointers, per layer: norm1.weight, norm1.bias (fp32 [C_in]), conv1 weight PACKED by
+ *              mcl_dense_block_pack_w1 (bf16, 128*C_in elements in the kernel's MFMA-fragment streaming order),
+ *              norm2.weight, norm2.bias (fp32 [128]), conv2 weight (bf16 [32][3][3][128]), z out (bf16 (B, 7, 7, 128), saved
+ *              for the backward), norm2 batch mean / biased var / rstd out (fp32 [128] each);
+ *   mean / var / rstd  fp32 [Ct] batch statistics of the concat channels: [0, C0) given (mean, rstd read), [C0, Ct) written;
+ *   workspace  mcl_dense_block_fwd_workspace_bytes(B, L) bytes, 256-byte aligned; err_flag: device int32, set to 1 if a seam
+ *              wait timed out (results invalid; never hangs).
+ * Algorithmic bytes: the block input read once, z and the new channels written once (+ the weights).                      */
+/* conv1 weights (bf16 [128][C_in_l], C_in_l = C0 + 32*l, k-contiguous rows) of the L layers -> the packed order (same sizes);
+ * w1_ptrs / out_ptrs: HOST arrays of L device pointers.  One launch; run it whenever the weights have changed. */
+int mcl_dense_block_pack_w1(const void* const* w1_ptrs, void* const* out_ptrs, int32_t L, int32_t C0, mcl_stream_t stream);
+int64_t mcl_dense_block_fwd_workspace_bytes(int32_t B, int32_t L);
+/* debugging aid: a device buffer of B*L*8 uint64 that later mcl_dense_block_fwd launches fill with in-kernel phase stamps
+ * (100 MHz wall clock) per image and layer; NULL switches it off (the default). */
+int mcl_dense_block_debug_stamps(void* stamps);
+int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, int32_t Ct, int32_t C0, int32_t L,
+                        const void* const* layer_ptrs, float eps1, float eps2, float* mean, float* var, float* rstd,
+                        void* workspace, int32_t* err_flag, mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;

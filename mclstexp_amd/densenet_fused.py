@@ -676,6 +676,79 @@ CAPTURE_BLOCKS: Optional[list] = None
 CAPTURE_MISC: Optional[list] = None
 
 
+USE_BLOCK_PERSISTENT = os.environ.get("MCL_BLOCK_PERSIST", "1") != "0"
+_block_err: dict = {}
+
+
+def _block_persistent_ok(buf: Tensor, params, growth: int, L: int, C0: int, dt: torch.dtype) -> bool:
+    B, Ct, H, W = buf.shape
+    if not (USE_BLOCK_PERSISTENT and H == 7 and W == 7 and growth == 32 and dt == torch.bfloat16 and L <= 24 and Ct <= 1024
+            and C0 % 32 == 0 and B <= 256 and buf.is_cuda):
+        return False
+    for l in range(L):
+        w1, w2 = params[6 * l + 2], params[6 * l + 5]
+        if tuple(w1.shape) != (128, C0 + l * growth, 1, 1) or tuple(w2.shape) != (32, 128, 3, 3):
+            return False
+    return True
+
+
+def block_persistent_error(device) -> bool:
+    """True if a persistent dense-block launch on ``device`` gave up waiting at a seam since the last call (host sync)."""
+    t = _block_err.get(device.index)
+    if t is None:
+        return False
+    bad = int(t.item()) != 0
+    if bad:
+        t.zero_()
+    return bad
+
+
+def dense_block_fwd_persistent(buf: Tensor, params, wcast, stats: "_BlockStats", bn2_stats, C0: int, L: int, eps1: float,
+                               eps2: float):
+    """csrc/dense_block.hip: all L layers of the block in one launch; fills buf[:, C0:], stats[C0:], bn2_stats, returns
+    the per-layer z tensors (saved for the backward)."""
+    import ctypes as C
+    B, Ct, H, W = buf.shape
+    dev = buf.device
+    Lb = _lib.lib()
+    zs = [torch.empty((B, 128, H, W), device=dev, dtype=torch.bfloat16, memory_format=CL) for _ in range(L)]
+    # conv1 weights in the kernel's streaming order (one launch per call: the weights change every step)
+    sizes = [128 * (C0 + 32 * l) for l in range(L)]
+    packed = torch.empty(sum(sizes), device=dev, dtype=torch.bfloat16)
+    offs, o = [], 0
+    for n in sizes:
+        offs.append(o)
+        o += n
+    for l in range(L):
+        w1c, w2c = wcast[2 * l], wcast[2 * l + 1]
+        if not (w1c.permute(0, 2, 3, 1).is_contiguous() and w2c.permute(0, 2, 3, 1).is_contiguous()):
+            raise RuntimeError("dense_block_fwd_persistent: weights must be channels-last / (N, K) row-major")
+    src = (C.c_void_p * L)(*[wcast[2 * l].data_ptr() for l in range(L)])
+    dst = (C.c_void_p * L)(*[packed.data_ptr() + 2 * offs[l] for l in range(L)])
+    check(Lb.mcl_dense_block_pack_w1(src, dst, L, C0, _stream()), "mcl_dense_block_pack_w1")
+    ptrs = []
+    for l in range(L):
+        g1, b1, _, g2, b2, _ = params[6 * l: 6 * l + 6]
+        w2c = wcast[2 * l + 1]
+        m2, v2, r2 = bn2_stats[l]
+        ptrs += [g1.data_ptr(), b1.data_ptr(), packed.data_ptr() + 2 * offs[l], g2.data_ptr(), b2.data_ptr(), w2c.data_ptr(),
+                 zs[l].data_ptr(), m2.data_ptr(), v2.data_ptr(), r2.data_ptr()]
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    nbytes = Lb.mcl_dense_block_fwd_workspace_bytes(B, L)
+    ws = _ws((nbytes + 255 + 3) // 4 + 64, dev)
+    base = (ws.data_ptr() + 255) & ~255
+    err = _block_err.get(dev.index)
+    if err is None:
+        err = torch.zeros(1, device=dev, dtype=torch.int32)
+        _block_err[dev.index] = err
+    px, S, C_, ld = _rows(buf)
+    if ld != Ct:
+        raise RuntimeError("dense_block_fwd_persistent: the concat buffer must be dense channels-last")
+    check(Lb.mcl_dense_block_fwd(px, B, H, W, Ct, C0, L, arr, eps1, eps2, stats.mean.data_ptr(), stats.var.data_ptr(),
+                                 stats.rstd.data_ptr(), base, err.data_ptr(), _stream()), "mcl_dense_block_fwd")
+    return zs
+
+
 class DenseBlockFn(torch.autograd.Function):
     """A whole torchvision ``_DenseBlock`` (forward AND hand-scheduled backward).
 
@@ -713,7 +786,17 @@ class DenseBlockFn(torch.autograd.Function):
             bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
         saved = []
         wcast = []
-        for l in range(L):
+        if _block_persistent_ok(buf, params, growth, L, C0, dt):
+            # 7 x 7 maps: the whole block as ONE persistent launch (csrc/dense_block.hip) -- one workgroup per image, the
+            # batch statistics exchanged through two all-to-all seams per layer instead of four dependent launches per layer
+            wcast = [_weight(params[6 * l + k], dt) for l in range(L) for k in (2, 5)]
+            zs = dense_block_fwd_persistent(buf, params, wcast, stats, bn2_stats, C0, L, eps1[0], eps2[0])
+            for l in range(L):
+                saved += [buf.new_empty(0), zs[l], buf.new_empty(0)]
+            L_done = L
+        else:
+            L_done = 0
+        for l in range(L_done, L):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
             cin = C0 + l * growth
             w1c = _weight(w1, dt)

@@ -192,8 +192,9 @@ class TrainStep:
         # kernels (what DDP's bucketed overlap does for /root/reference/baselines/Bleep/BLEEP_main.py:76-78,147 -- here with
         # ranges that follow the flat bucket's layout, no packing copies), and the position tables are updated beside the
         # remaining segments as soon as segment 0 has produced their gradient rows.  MCL_DP_SEGMENTS = number of segments
-        # (default 2: [heads, spot branch, norm5, last dense block] = 70 % of the gradient bytes | the rest; up to one per
-        # dense block; 1 = one backward graph and one all-reduce after it, the round-3 form).  Every cut adds a join of the
+        # (default 1 = one backward graph and one all-reduce after it: the only form MEASURED so far -- on one GPU every cut
+        # costs time and there is nothing to overlap; 2 = [heads, spot branch, norm5, last dense block] = 70 % of the gradient
+        # bytes | the rest; up to one per dense block.  Until a multi-GPU run decides, the default follows the measurement).  Every cut adds a join of the
         # weight-gradient side stream at its block's end and a graph launch: measured on ONE GPU (size-1 RCCL group, nothing
         # to overlap) 2 segments cost +0.27 ms/step, 4 segments +0.35 (profiles/r04_dp_segments_size1.txt).
         # (a group of ONE rank -- MCL_FORCE_DIST=1 on a single GPU -- has nothing to overlap: one backward graph by default)
@@ -201,7 +202,7 @@ class TrainStep:
             world = torch.distributed.get_world_size(self.reducer.pg) if self.reducer is not None else 1
         except Exception:
             world = 1
-        n_seg = int(os.environ.get("MCL_DP_SEGMENTS", "2" if world > 1 else "1"))
+        n_seg = int(os.environ.get("MCL_DP_SEGMENTS", "1"))
         n_blocks = 0
         enc = getattr(m, "image_encoder", None)
         feats = enc.model[0] if enc is not None and hasattr(enc, "model") and hasattr(enc, "forward_fused") else None

@@ -255,6 +255,12 @@ class _ContrastiveBase(nn.Module):
         if (self.fused_backbone and image.is_cuda and image.dim() == 4 and isinstance(
                 encoder, (backbones.ImageEncoder_Resnet, backbones.ImageEncdoer_res18, backbones.ImageEncdoer_res101))):
             # ResNet selector values (model.py:88-148) on the generic own-kernel path, bf16 or fp32 activations
+            if not encoder.training and torch.is_grad_enabled() and (image.requires_grad or any(
+                    p.requires_grad for p in encoder.parameters())):
+                # eval-mode BatchNorm is a raw affine kernel on this path (no autograd node): a gradient would silently stop
+                # at the first BatchNorm.  The reference never differentiates in eval mode (train.py:31, evel_*.py: no_grad).
+                raise RuntimeError("the fused ResNet path has no backward in eval mode: call model.train() to train, or wrap "
+                                   "inference in torch.no_grad()")
             return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
         if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder_VIT) and image.is_cuda
                 and self.backbone_dtype == torch.bfloat16):
