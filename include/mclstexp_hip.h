@@ -530,6 +530,24 @@ int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, int32_t Ct, 
                         const void* const* layer_ptrs, float eps1, float eps2, float* mean, float* var, float* rstd,
                         void* workspace, int32_t* err_flag, mcl_stream_t stream);
 
+/* The same dense block BACKWARD (7 x 7 maps) as one persistent launch: replaces, per layer, mcl_dense_conv3x3_bwd_fix and
+ * mcl_dense_bn1_dx_sums (+ their finalize launches and bn2_dz) with the same arithmetic; the two weight gradients of a layer
+ * stay mcl_dense_conv3x3_wrw_det / mcl_conv1x1_wrw_det on the dz / dyc tensors this launch writes.
+ *   buf        the forward's concat buffer (B, 7, 7, Ct) bf16;  gbuf: the block's gradient buffer, same shape: read whole,
+ *              channels [0, C0) (the gradient of the block input) written back;
+ *   layer_ptrs HOST array of 15*L pointers, per layer: norm1.weight, norm1.bias, conv1 weight packed by
+ *              mcl_dense_block_pack_bwd (w1t), norm2.weight, norm2.bias, conv2 weight packed (w2t), z (forward, (B,7,7,128)),
+ *              norm2 batch mean, norm2 batch rstd, dz out (B,7,7,128), dyc out (B,7,7,32: the gradient of the layer's output as
+ *              consumed), then the fp32 gradients of norm1.weight, norm1.bias, norm2.weight, norm2.bias (ACCUMULATED into);
+ *   mean / rstd  fp32 [Ct] batch statistics of the concat channels (forward);
+ *   workspace  mcl_dense_block_bwd_workspace_bytes(B, L) bytes, 256-byte aligned; err_flag as in the forward.            */
+int mcl_dense_block_pack_bwd(const void* const* w1_ptrs, const void* const* w2_ptrs, void* const* w1t_ptrs,
+                             void* const* w2t_ptrs, int32_t L, int32_t C0, mcl_stream_t stream);
+int64_t mcl_dense_block_bwd_workspace_bytes(int32_t B, int32_t L);
+int mcl_dense_block_bwd(const void* buf, void* gbuf, int32_t B, int32_t H, int32_t W, int32_t Ct, int32_t C0, int32_t L,
+                        const void* const* layer_ptrs, const float* mean, const float* rstd, void* workspace,
+                        int32_t* err_flag, mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:
  *   g += wd*p ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;

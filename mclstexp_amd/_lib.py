@@ -146,6 +146,9 @@ PROTOTYPES = {
     "mcl_dense_block_fwd_workspace_bytes": [c_i, c_i],
     "mcl_dense_block_debug_stamps": [c_p],
     "mcl_dense_block_pack_w1": [c_p, c_p, c_i, c_i, c_p],
+    "mcl_dense_block_pack_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "mcl_dense_block_bwd_workspace_bytes": [c_i, c_i],
+    "mcl_dense_block_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_dense_block_fwd": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_adam_consts_update_hist": [c_p, c_p, c_p, c_p, c_i, c_p],
     "mcl_adam_table_lazy": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p, c_p, c_i,
@@ -166,7 +169,7 @@ PROTOTYPES = {
     "mcl_topk_rows": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
     "mcl_knn_weighted_average": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
 }
-_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_dense_block_fwd_workspace_bytes": C.c_int64, "mcl_bn_workspace_floats": C.c_int64,
+_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_dense_block_fwd_workspace_bytes": C.c_int64, "mcl_dense_block_bwd_workspace_bytes": C.c_int64, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64,

@@ -25,6 +25,7 @@ Train-mode semantics of nn.BatchNorm2d are kept: batch statistics, running_mean 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional, Tuple
 
@@ -652,7 +653,7 @@ def _side_stream(device) -> torch.cuda.Stream:
 # it reads are parked here (so that the allocator cannot hand their memory out again), and the main stream joins
 # once per dense block / at the stem.
 _side_parked: dict = {}
-JOIN_MIN_PIXELS = int(os.environ.get("MCL_JOIN_MIN_PIXELS", "50000"))
+JOIN_MIN_PIXELS = int(os.environ.get("MCL_JOIN_MIN_PIXELS", "300000"))
 
 
 def _side_park(device, *tensors) -> None:
@@ -660,10 +661,40 @@ def _side_park(device, *tensors) -> None:
 
 
 def _side_join(device) -> None:
+    if _side_pending.get(device.index):
+        # deferred side work that no later fork picked up (the block was the last one of this backward): issue it now
+        main = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _run_side_pending(device)
     parked = _side_parked.get(device.index)
     if parked:
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
         parked.clear()
+
+
+# Side work whose only dependency is "everything the main stream has issued so far", deferred to the NEXT fork the backward
+# makes anyway.  The persistent dense-block backward is ONE kernel followed by 32 weight-gradient launches: forking the side
+# stream right behind that kernel (one cross-stream edge out of a 0.9 ms node) made the replayed step graph lose its two-lane
+# execution -- the spot branch's backward, which precedes those launches on the side stream, then ran 4.5 ms late
+# (profiles/r05_persistent_bwd_lanes.txt).  Riding on the next block's first per-layer fork keeps the graph's edge structure
+# what it was.
+_side_pending: dict = {}
+
+
+def _defer_to_side(device, fn) -> None:
+    _side_pending.setdefault(device.index, []).append(fn)
+
+
+def _run_side_pending(device) -> None:
+    """Called with the side stream current, after it has waited for an event the main stream recorded later than every
+    deferred job's inputs."""
+    jobs = _side_pending.get(device.index)
+    if jobs:
+        for fn in jobs:
+            fn()
+        jobs.clear()
 
 
 # Test instrumentation (tests/test_layerwise_gpu.py): a list that receives, per dense block, the tensors every fused layer
@@ -701,6 +732,69 @@ def block_persistent_error(device) -> bool:
     if bad:
         t.zero_()
     return bad
+
+
+USE_BLOCK_PERSISTENT_BWD = os.environ.get("MCL_BLOCK_PERSIST_BWD", "1") != "0"
+
+
+def _block_bwd_persistent_ok(buf: Tensor, gbuf: Tensor, params, L: int) -> bool:
+    """The persistent backward adds every BatchNorm gradient straight into ``.grad`` and hands dz / dy' to the direct weight
+    gradient kernels: all parameters of the block must take the direct path."""
+    if not (USE_BLOCK_PERSISTENT_BWD and DIRECT_PARAM_GRADS and gbuf.dtype == torch.bfloat16
+            and gbuf.is_contiguous(memory_format=CL) and tuple(gbuf.shape) == tuple(buf.shape)):
+        return False
+    for l in range(L):
+        g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
+        if not all(_direct_grad_ok(p) for p in (g1, b1, g2, b2, w2)):
+            return False
+    return True
+
+
+def dense_block_bwd_persistent(buf: Tensor, gbuf: Tensor, params, wcast, zs, stats: "_BlockStats", bn2_stats, C0: int, L: int):
+    """csrc/dense_block.hip dense_block_bwd_kernel: the data-gradient chain of all L layers in one launch.  gbuf[:, :C0]
+    receives the block-input gradient; norm1 / norm2 gradients are accumulated into ``.grad``; returns (dz list, dy' list)."""
+    import ctypes as C
+    B, Ct, H, W = buf.shape
+    dev = buf.device
+    Lb = _lib.lib()
+    dzs = [torch.empty((B, 128, H, W), device=dev, dtype=torch.bfloat16, memory_format=CL) for _ in range(L)]
+    dycs = [torch.empty((B, 32, H, W), device=dev, dtype=torch.bfloat16, memory_format=CL) for _ in range(L)]
+    n1 = [128 * (C0 + 32 * l) for l in range(L)]
+    n2 = 4 * 18 * 64 * 8
+    packed = torch.empty(sum(n1) + L * n2, device=dev, dtype=torch.bfloat16)
+    o1, o = [], 0
+    for n in n1:
+        o1.append(o)
+        o += n
+    o2 = [o + l * n2 for l in range(L)]
+    vp = C.c_void_p * L
+    check(Lb.mcl_dense_block_pack_bwd(vp(*[wcast[2 * l].data_ptr() for l in range(L)]),
+                                      vp(*[wcast[2 * l + 1].data_ptr() for l in range(L)]),
+                                      vp(*[packed.data_ptr() + 2 * o1[l] for l in range(L)]),
+                                      vp(*[packed.data_ptr() + 2 * o2[l] for l in range(L)]), L, C0, _stream()),
+          "mcl_dense_block_pack_bwd")
+    ptrs = []
+    for l in range(L):
+        g1, b1, _, g2, b2, _ = params[6 * l: 6 * l + 6]
+        m2, v2, r2 = bn2_stats[l]
+        ptrs += [g1.data_ptr(), b1.data_ptr(), packed.data_ptr() + 2 * o1[l], g2.data_ptr(), b2.data_ptr(),
+                 packed.data_ptr() + 2 * o2[l], zs[l].data_ptr(), m2.data_ptr(), r2.data_ptr(), dzs[l].data_ptr(),
+                 dycs[l].data_ptr(), g1.grad.data_ptr(), b1.grad.data_ptr(), g2.grad.data_ptr(), b2.grad.data_ptr()]
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    nbytes = Lb.mcl_dense_block_bwd_workspace_bytes(B, L)
+    ws = _ws((nbytes + 255 + 3) // 4 + 64, dev)
+    base = (ws.data_ptr() + 255) & ~255
+    err = _block_err.get(dev.index)
+    if err is None:
+        err = torch.zeros(1, device=dev, dtype=torch.int32)
+        _block_err[dev.index] = err
+    px, S, C_, ld = _rows(buf)
+    pg, S2, C2, ldg = _rows(gbuf)
+    if ld != Ct or ldg != Ct:
+        raise RuntimeError("dense_block_bwd_persistent: the concat and gradient buffers must be dense channels-last")
+    check(Lb.mcl_dense_block_bwd(px, pg, B, H, W, Ct, C0, L, arr, stats.mean.data_ptr(), stats.rstd.data_ptr(), base,
+                                 err.data_ptr(), _stream()), "mcl_dense_block_bwd")
+    return dzs, dycs
 
 
 def dense_block_fwd_persistent(buf: Tensor, params, wcast, stats: "_BlockStats", bn2_stats, C0: int, L: int, eps1: float,
@@ -786,6 +880,7 @@ class DenseBlockFn(torch.autograd.Function):
             bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
         saved = []
         wcast = []
+        ctx.persistent = False
         if _block_persistent_ok(buf, params, growth, L, C0, dt):
             # 7 x 7 maps: the whole block as ONE persistent launch (csrc/dense_block.hip) -- one workgroup per image, the
             # batch statistics exchanged through two all-to-all seams per layer instead of four dependent launches per layer
@@ -794,6 +889,7 @@ class DenseBlockFn(torch.autograd.Function):
             for l in range(L):
                 saved += [buf.new_empty(0), zs[l], buf.new_empty(0)]
             L_done = L
+            ctx.persistent = True
         else:
             L_done = 0
         for l in range(L_done, L):
@@ -853,6 +949,44 @@ class DenseBlockFn(torch.autograd.Function):
             ctx.cap["gbuf"] = gbuf
         grads = [None] * (6 * L)
         stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} start (main)")
+        if getattr(ctx, "persistent", False) and _block_bwd_persistent_ok(buf, gbuf, params, L):
+            # 7 x 7 maps: the block's whole data-gradient chain as ONE persistent launch (csrc/dense_block.hip); the two weight
+            # gradients of every layer follow on the side stream from the dz / dy' tensors it wrote
+            zs = [saved[3 * l + 1] for l in range(L)]
+            dzs, dycs = dense_block_bwd_persistent(buf, gbuf, params, wcast, zs, stats, bn2_stats, C0, L)
+            if ctx.cap is not None:
+                ctx.cap["dz"] = list(dzs)
+                ctx.cap["dyc"] = list(dycs)
+            dev = buf.device
+            gw1s = {}
+
+            def _weight_grads():
+                for l in range(L - 1, -1, -1):
+                    g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
+                    cin = C0 + l * growth
+                    m2, v2, r2 = bn2_stats[l]
+                    ok = dense_conv3x3_wrw(dycs[l], zs[l], g2, b2, m2, r2, w2)
+                    assert ok
+                    gw1s[l] = conv1x1_wrw(dzs[l], buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
+                if STAMPS:
+                    stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} weight gradients done (side)")
+
+            joins = buf.shape[0] * buf.shape[2] * buf.shape[3] >= JOIN_MIN_PIXELS or ctx.first_block
+            direct_w1 = all(_direct_grad_ok(params[6 * l + 2]) and params[6 * l + 2].grad.is_contiguous() for l in range(L))
+            if USE_SIDE_STREAM and direct_w1:
+                # (every gradient goes straight into .grad: nothing to hand back to autograd, the launches can be deferred)
+                _defer_to_side(dev, _weight_grads)
+                _side_park(dev, gbuf, buf, *dzs, *dycs, *zs)
+            else:
+                _weight_grads()
+                for l in range(L):
+                    grads[6 * l + 2] = gw1s[l]
+            if STAMPS:
+                stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} end (main)")
+            if joins:
+                _side_join(dev)
+                stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} after join (main)")
+            return (gbuf[:, :C0], None, *grads)
         kacc = None             # single-pass BatchNorm-1 backward: the previous pass's mean terms, [C_total][2]
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
@@ -911,6 +1045,7 @@ class DenseBlockFn(torch.autograd.Function):
                                              gbuf[:, :cin], into_param_grads=d1)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
+                    _run_side_pending(z.device)         # (deferred weight gradients of the block before: persistent backward)
                     dense_conv3x3_wrw(dy_w, z, g2, b2, m2, r2, w2)
                     if not fused_wrw:
                         gw1 = conv1x1_wrw(dz, buf[:, :cin], w1, bn=(g1, b1, stats.mean[:cin], stats.rstd[:cin]))
@@ -1346,6 +1481,7 @@ class TransitionFn(torch.autograd.Function):
             side = _side_stream(buf.device)
             side.wait_event(ev)
             with torch.cuda.stream(side):
+                _run_side_pending(buf.device)            # (deferred weight gradients of the dense block before)
                 dw = conv1x1_wrw(dy, p, w)
             _side_park(buf.device, dy, p)
         else:

@@ -136,3 +136,53 @@ def test_persistent_block_backward_runs_on_its_outputs():
     for n in gp0:
         assert torch.isfinite(gp1[n]).all(), n
         assert float((gp1[n] - gp0[n]).abs().mean()) < 0.12 * float(gp0[n].abs().mean()) + 1e-6, n
+
+
+def _fwd_bwd(blk, x, gout, persistent_bwd):
+    from mclstexp_amd import densenet_fused as dn
+    old = dn.USE_BLOCK_PERSISTENT_BWD
+    dn.USE_BLOCK_PERSISTENT_BWD = persistent_bwd
+    dn.CAPTURE_BLOCKS = []
+    try:
+        for p in blk.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        buf, _ = dn.dense_block(blk, xi, dn._RunningStats(), force_join=True)
+        buf.backward(gout.clone())
+        torch.cuda.synchronize()
+        assert not dn.block_persistent_error(x.device)
+        cap = dn.CAPTURE_BLOCKS[0]
+        dyc = cap.get("dyc") or [None] * 16
+        dys = [(dyc[l] if dyc[l] is not None else cap["gbuf"][:, 512 + 32 * l: 544 + 32 * l]).float().clone() for l in range(16)]
+        return (xi.grad.float().clone(), {n: p.grad.float().clone() for n, p in blk.named_parameters()},
+                [t.float().clone() for t in cap["dz"]], dys)
+    finally:
+        dn.USE_BLOCK_PERSISTENT_BWD = old
+        dn.CAPTURE_BLOCKS = None
+
+
+@pytest.mark.parametrize("B", [128, 33, 5])
+def test_persistent_block_backward_vs_per_layer_kernels(B):
+    """csrc/dense_block.hip dense_block_bwd_kernel against the per-layer launch sequence it replaces (same forward tensors, same
+    arithmetic; only the order of the batch sums differs): every layer's dz and consumed dy, the block-input gradient and all
+    parameter gradients; and run-to-run determinism."""
+    blk = _block(seed=4)
+    x = _input(B, seed=9)
+    g = torch.Generator().manual_seed(13)
+    gout = torch.randn(B, 1024, 7, 7, generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=CL)
+    gx1, gp1, dz1, dy1 = _fwd_bwd(blk, x, gout, True)
+    gx2, gp2, dz2, dy2 = _fwd_bwd(blk, x, gout, True)
+    assert torch.equal(gx1, gx2)
+    for n in gp1:
+        assert torch.equal(gp1[n], gp2[n]), n
+    gx0, gp0, dz0, dy0 = _fwd_bwd(blk, x, gout, False)
+    worst = {"dz": 0.0, "dy": 0.0}
+    for l in range(16):
+        worst["dz"] = max(worst["dz"], float((dz1[l] - dz0[l]).abs().max() / dz0[l].abs().max()))
+        worst["dy"] = max(worst["dy"], float((dy1[l] - dy0[l]).abs().max() / dy0[l].abs().max()))
+    e_gx = float((gx1 - gx0).abs().max() / gx0.abs().max())
+    e_gp = max(float((gp1[n] - gp0[n]).abs().max() / (gp0[n].abs().max() + 1e-20)) for n in gp0)
+    print(f"B={B}: persistent backward vs per-layer kernels (of max): dz {worst['dz']:.2e}  dy consumed {worst['dy']:.2e}  "
+          f"block-input gradient {e_gx:.2e}  parameter gradients {e_gp:.2e}")
+    # identical arithmetic up to the summation order of the batch means: differences are single bf16 roundings that flipped
+    assert worst["dz"] < 2e-2 and worst["dy"] < 2e-2 and e_gx < 2e-2 and e_gp < 2e-2, (worst, e_gx, e_gp)

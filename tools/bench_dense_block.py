@@ -79,3 +79,41 @@ print("  start skew across images, layer 0 (us): max - min =", float(t[:, 0, 0].
 print("  span (first layer-0 top -> last seam-2 publish):", float(t[:, -1, 5].max() - t[:, 0, 0].min()), "us")
 print(json.dumps({"B": B, "block": "denseblock4 forward, 16 layers, 7x7", **out}))
 assert not dn.block_persistent_error(x.device)
+
+# ------------------------------------------------------------------------------------------------ backward
+dn.USE_BLOCK_PERSISTENT = True
+for p_ in blk.parameters():
+    p_.grad = torch.zeros_like(p_)
+gout = torch.randn(B, 1024, 7, 7, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+def fwd_bwd():
+    xi = x.clone().requires_grad_(True)
+    buf, _ = dn.dense_block(blk, xi, dn._RunningStats(), force_join=True)
+    buf.backward(gout.clone())
+
+
+res = {}
+for mode in (True, False, True, False):
+    dn.USE_BLOCK_PERSISTENT_BWD = mode
+    res.setdefault("persistent_bwd" if mode else "per_layer_bwd", []).append(round(timeit(fwd_bwd, 10), 1))
+print(json.dumps({"forward(persistent)+backward eager, us": res}))
+st = torch.zeros(B * L * 8 + 64, device=DEV, dtype=torch.int64)
+dn.USE_BLOCK_PERSISTENT_BWD = True
+fwd_bwd(); torch.cuda.synchronize()
+_lib.lib().mcl_dense_block_debug_stamps(st.data_ptr())
+# (the forward kernel writes the same buffer first; the backward's stamps overwrite them)
+fwd_bwd(); torch.cuda.synchronize()
+_lib.lib().mcl_dense_block_debug_stamps(None)
+t = st[:B * L * 8].view(B, L, 8).double().cpu() * 0.01
+print("BACKWARD phase medians over images, per layer l = 15 .. 0 (us)")
+order = list(range(L - 1, -1, -1))
+print("  a-c: dy', conv2^T, g2 sums -> seam A published ", med((t[:, :, 1] - t[:, :, 0])[:, order]))
+print("  seam A wait                                    ", med((t[:, :, 2] - t[:, :, 1])[:, order]))
+print("  seam A merge + dz                              ", med((t[:, :, 3] - t[:, :, 2])[:, order]))
+print("  d/e: dz W1, mask, sums, G update -> B1 published", med((t[:, :, 4] - t[:, :, 3])[:, order]))
+print("  hop-1 wait                                     ", med((t[:, :, 5] - t[:, :, 4])[:, order]))
+print("  hop-1 merge + hop-2 wait                       ", med((t[:, :, 6] - t[:, :, 5])[:, order]))
+print("  layer total                                    ", med((t[:, :, 6] - t[:, :, 0])[:, order]))
+print("  span:", float(t[:, 0, 6].max() - t[:, L - 1, 0].min()), "us")
+assert not dn.block_persistent_error(x.device)
