@@ -455,6 +455,10 @@ int mcl_bn_gap_fwd(const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t C,
 int mcl_bn_gap_bwd(const float* g, const float* xmean, const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t C,
                    const float* gamma, const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta,
                    int32_t accumulate_params, void* dx, int64_t lddx, mcl_stream_t stream);
+/* eval mode (evel_her2st.py:48-50: model.eval()): rstd_out[k][c] = 1 / sqrt(running_var[k][c] + eps[k]) for n BatchNorm
+ * layers (HOST arrays of n device pointers / values), 64 layers per launch. */
+int mcl_bn_eval_rstd(int32_t n, const float* const* running_var, float* const* rstd_out, const int32_t* C, const float* eps,
+                     mcl_stream_t stream);
 int mcl_bn_running_update(int32_t n, float* const* running_mean, float* const* running_var, const float* const* mean,
                           const float* const* var, int64_t* const* num_batches_tracked, const int32_t* C,
                           const float* factor, const float* momentum, mcl_stream_t stream);
@@ -502,6 +506,8 @@ int mcl_avgpool2_nhwc_any(const void* x, void* y, int32_t N, int32_t H, int32_t 
 int mcl_gap_nhwc_fwd(const void* x, int64_t ldx, int32_t B, int32_t HW, int32_t C, int32_t dtype, float* out,
                      mcl_stream_t stream);
 int mcl_gap_nhwc_bwd(const float* g, int32_t B, int32_t HW, int32_t C, int32_t dtype, void* dx, mcl_stream_t stream);
+/* backward: 0 = y = relu(a + b); 1 = dx = dy*[y > 0] (a = dy, b = forward output); 2 = y = a + b (gradient of a tensor with
+ * two consumers: the fork in front of a residual block). */
 int mcl_add_relu(const void* a, const void* b, void* y, int64_t n, int32_t backward, int32_t dtype, mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- a whole dense block, forward, 7 x 7 maps (ABI 6)

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "mcl_bn_gap_fwd": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "mcl_bn_gap_bwd": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_p],
     "mcl_bn_running_update": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mcl_bn_eval_rstd": [c_i, c_p, c_p, c_p, c_p, c_p],
     "mcl_image_to_bf16_nhwc": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_fill_zero": [c_p, c_l, c_p],
     "mcl_stamp": [c_p, c_i, c_p],

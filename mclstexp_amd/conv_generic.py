@@ -285,6 +285,27 @@ class AddReluFn(torch.autograd.Function):
         return dx, dx
 
 
+class Fork2Fn(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers (the input of a residual block feeds the block and its shortcut): the
+    backward adds the two gradients with this library's kernel instead of autograd's ATen accumulation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        g1, g2 = g1.contiguous(memory_format=CL), g2.contiguous(memory_format=CL)
+        out = torch.empty_like(g1, memory_format=CL)
+        check(_lib.lib().mcl_add_relu(g1.data_ptr(), g2.data_ptr(), out.data_ptr(), g1.numel(), 2, _dt(g1), _stream()),
+              "mcl_add_relu (plain add)")
+        return out
+
+
+def fork2(x: Tensor):
+    return Fork2Fn.apply(x) if (x.requires_grad and torch.is_grad_enabled()) else (x, x)
+
+
 def max_pool_3s2(x: Tensor) -> Tensor:
     return MaxPool3s2Fn.apply(x)
 

@@ -231,6 +231,21 @@ __global__ __launch_bounds__(256) void add_relu_bwd_kernel(const T* __restrict__
   }
 }
 
+// y = a + b (the gradient of a tensor with two consumers: the residual fork of a ResNet block)
+template <typename T>
+__global__ __launch_bounds__(256) void add_plain_kernel(const T* __restrict__ a, const T* __restrict__ b, long long nv,
+                                                        T* __restrict__ y) {
+  constexpr int V = El<T>::V;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    float u[V], w[V];
+    El<T>::load(a + i * V, u);
+    El<T>::load(b + i * V, w);
+#pragma unroll
+    for (int e = 0; e < V; ++e) u[e] += w[e];
+    El<T>::store(y + i * V, u);
+  }
+}
+
 inline bool ok16(const void* p) { return p && (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline unsigned grid_for(long long total) {
   long long b = (total + 255) / 256;
@@ -328,7 +343,10 @@ extern "C" int mcl_add_relu(const void* a, const void* b, void* y, int64_t n, in
   if (n % V) return MCL_EUNSUPPORTED;
   hipStream_t st = mcl_stream(stream);
   const dim3 grid(grid_for(n / V));
-  if (!backward) {     // y = relu(a + b)
+  if (backward == 2) {  // y = a + b
+    if (dtype == 0) hipLaunchKernelGGL(add_plain_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (long long)(n / V), (float*)y);
+    else hipLaunchKernelGGL(add_plain_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)a, (const unsigned short*)b, (long long)(n / V), (unsigned short*)y);
+  } else if (!backward) {     // y = relu(a + b)
     if (dtype == 0) hipLaunchKernelGGL(add_relu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)b, (long long)(n / V), (float*)y);
     else hipLaunchKernelGGL(add_relu_fwd_kernel<unsigned short>, grid, dim3(256), 0, st, (const unsigned short*)a, (const unsigned short*)b, (long long)(n / V), (unsigned short*)y);
   } else {             // a = dy, b = forward output, y = dx

@@ -161,6 +161,21 @@ __global__ __launch_bounds__(256) void bn_running_kernel(RunBatch t) {
   if (threadIdx.x == 0 && e.nbt != nullptr) *e.nbt += 1;
 }
 
+// eval mode: rstd[c] = 1 / sqrt(running_var[c] + eps) for up to 64 BatchNorm layers per launch (same by-value pointer table)
+struct RstdEntry {
+  const float* var;
+  float* out;
+  int C;
+  float eps;
+};
+struct RstdBatch {
+  RstdEntry e[RUN_MAX];
+};
+__global__ __launch_bounds__(256) void bn_rstd_kernel(RstdBatch t) {
+  const RstdEntry& e = t.e[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += 256) e.out[c] = 1.0f / sqrtf(e.var[c] + e.eps);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // image (B, C, H, W) fp32 with arbitrary element strides -> bf16 NHWC contiguous.
 // Generic form: 8 consecutive NHWC elements per thread, one scalar load each (any strides).
@@ -413,6 +428,25 @@ extern "C" int mcl_bn_running_update(int32_t n, float* const* running_mean, floa
                         factor[k], momentum[k], 0};
     }
     hipLaunchKernelGGL(bn_running_kernel, dim3(m), dim3(256), 0, st, t);
+  }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_bn_eval_rstd(int32_t n, const float* const* running_var, float* const* rstd_out, const int32_t* C,
+                                const float* eps, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (n < 0 || (n > 0 && (!running_var || !rstd_out || !C || !eps))) return MCL_EINVAL;
+  hipStream_t st = mcl_stream(stream);
+  for (int i0 = 0; i0 < n; i0 += RUN_MAX) {
+    RstdBatch t;
+    const int m = n - i0 < RUN_MAX ? n - i0 : RUN_MAX;
+    for (int i = 0; i < m; ++i) {
+      const int k = i0 + i;
+      if (!running_var[k] || !rstd_out[k] || C[k] <= 0) return MCL_EINVAL;
+      t.e[i] = RstdEntry{running_var[k], rstd_out[k], C[k], eps[k]};
+    }
+    hipLaunchKernelGGL(bn_rstd_kernel, dim3(m), dim3(256), 0, st, t);
   }
   MCL_CHECK_LAUNCH();
   return MCL_OK;

@@ -613,6 +613,21 @@ def set_weight_provider(fn) -> None:
     _weight_provider = fn
 
 
+def cast_dense_bf16(w: Tensor) -> Optional[Tensor]:
+    """bf16 copy of a dense fp32 GPU tensor with the SAME strides, on this library's cast kernel (inference without an attached
+    FusedAdam has no flat shadow: ~120 per-weight ATen casts per forward otherwise).  None when the tensor is not eligible."""
+    w = w.detach()
+    if not (w.is_cuda and w.dtype == torch.float32 and w.numel() % 8 == 0 and w.numel() > 0 and w.data_ptr() % 16 == 0):
+        return None
+    dense = w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=CL))
+    if not dense:
+        return None
+    out = torch.empty_strided(w.shape, w.stride(), device=w.device, dtype=torch.bfloat16)
+    check(_lib.lib().mcl_cast_f32_to_bf16(w.data_ptr(), w.numel(), out.data_ptr(), w.numel(), 1, w.numel(), _stream()),
+          "mcl_cast_f32_to_bf16")
+    return out
+
+
 def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
     if w.dtype == dt:
         return w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
@@ -620,6 +635,10 @@ def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
         v = _weight_provider(w, dt)
         if v is not None:
             return v if v.is_contiguous(memory_format=CL) else v.contiguous(memory_format=CL)
+    if dt == torch.bfloat16 and w.dim() == 4 and w.is_contiguous(memory_format=CL):
+        v = cast_dense_bf16(w)
+        if v is not None:
+            return v
     return w.to(dtype=dt, memory_format=CL)
 
 
@@ -1675,6 +1694,29 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
 
 # --------------------------------------------------------------------------- inference (eval mode, running statistics)
 @torch.no_grad()
+def eval_rstd(bns) -> List[Tensor]:
+    """1 / sqrt(running_var + eps) of every BatchNorm layer in two launches (mcl_bn_eval_rstd: pointer table by value)."""
+    import ctypes as C
+    if not bns:
+        return []
+    dev = bns[0].running_var.device
+    sizes = [bn.running_var.numel() for bn in bns]
+    flat = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+    outs, o = [], 0
+    for n in sizes:
+        outs.append(flat[o:o + n])
+        o += n
+    for bn in bns:
+        if bn.running_var.dtype != torch.float32 or not bn.running_var.is_contiguous():
+            raise RuntimeError("eval_rstd: running statistics must be contiguous fp32")
+    n = len(bns)
+    vp = C.c_void_p * n
+    check(_lib.lib().mcl_bn_eval_rstd(n, vp(*[bn.running_var.data_ptr() for bn in bns]), vp(*[t.data_ptr() for t in outs]),
+                                      (C.c_int32 * n)(*sizes), (C.c_float * n)(*[float(bn.eps) for bn in bns]), _stream()),
+          "mcl_bn_eval_rstd")
+    return outs
+
+
 def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.dtype = torch.bfloat16,
                            pooled: bool = False) -> Tensor:
     """Eval-mode forward of torchvision-layout DenseNet ``features`` (what ``model.image_encoder`` computes for
@@ -1683,14 +1725,10 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
     no finalize) and nothing but the concat buffers and the 128-channel bottleneck outputs touches HBM."""
     if not x.is_cuda:
         raise RuntimeError("densenet_features_eval: input is on the CPU; the fused backbone path is GPU-only")
-    if act_dtype != torch.bfloat16:
-        raise RuntimeError("densenet_features_eval: the fused kernels are bf16")
+    if act_dtype not in (torch.bfloat16, torch.float32):
+        raise RuntimeError("densenet_features_eval: activations are bf16 (fused kernels) or fp32 (generic own-kernel path)")
     bns = [m for m in features.modules() if isinstance(m, nn.BatchNorm2d)]
-    # rstd of every BatchNorm in three multi-tensor launches
-    rstd = torch._foreach_add([bn.running_var.float() for bn in bns], [float(bn.eps) for bn in bns])
-    torch._foreach_sqrt_(rstd)
-    torch._foreach_reciprocal_(rstd)
-    rs = {id(bn): r for bn, r in zip(bns, rstd)}
+    rs = {id(bn): r for bn, r in zip(bns, eval_rstd(bns))}
 
     def affine(t: Tensor, bn: nn.BatchNorm2d, relu: bool) -> Tensor:
         t = t.contiguous(memory_format=CL)
@@ -1698,13 +1736,20 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
         bn_act_fwd(t, bn.weight, bn.bias, bn.running_mean, rs[id(bn)], relu, out)
         return out
 
+    def copy_into(dst: Tensor, src: Tensor) -> None:
+        # an identity affine on the own BatchNorm kernel: a strided copy without an ATen launch
+        one, zero = _identity_bn(src.device)
+        C = src.shape[1]
+        bn_act_fwd(src, one[:C], zero[:C], zero[:C], one[:C], False, dst)
+
     x = image_to_act(x, act_dtype)
     if _conv0_ok(x, features.conv0):
         x = conv0_fwd(x, _weight(features.conv0.weight, act_dtype), features.norm0.eps, None)
     else:
         from . import conv_generic as cg
         x = cg.conv_fwd(x, _weight(features.conv0.weight, act_dtype), features.conv0.stride[0], features.conv0.padding[0])
-    x = x.contiguous(memory_format=CL)
+    if not x.is_contiguous(memory_format=CL):
+        raise RuntimeError("densenet_features_eval: the stem convolution must produce a channels-last tensor")
     if _stem_tail_ok(x):
         x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, features.norm0.running_mean,
                              rs[id(features.norm0)])
@@ -1712,12 +1757,17 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
         x = max_pool_3s2(affine(x, features.norm0, True))
     i = 1
     out = None
+    pre = None                      # the next block's concat buffer when the transition wrote its output straight into it
     while hasattr(features, f"denseblock{i}"):
         layers = list(getattr(features, f"denseblock{i}").values())
         growth = layers[0].conv2.out_channels
         B, C0, H, W = x.shape
-        buf = torch.empty((B, C0 + len(layers) * growth, H, W), device=x.device, dtype=act_dtype, memory_format=CL)
-        buf[:, :C0].copy_(x)
+        if pre is not None:
+            buf = pre
+        else:
+            buf = torch.empty((B, C0 + len(layers) * growth, H, W), device=x.device, dtype=act_dtype, memory_format=CL)
+            copy_into(buf[:, :C0], x)
+        pre = None
         for l, ly in enumerate(layers):
             cin = C0 + l * growth
             w1c, w2c = _weight(ly.conv1.weight, act_dtype), _weight(ly.conv2.weight, act_dtype)
@@ -1728,18 +1778,30 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
                                   buf[:, cin:cin + growth], ly.norm1.eps, None, None, None)
             else:
                 from . import conv_generic as cg
-                a = affine(buf[:, :cin], ly.norm1, True)
+                a = torch.empty((B, cin, H, W), device=x.device, dtype=act_dtype, memory_format=CL)
+                bn_act_fwd(buf[:, :cin], ly.norm1.weight, ly.norm1.bias, ly.norm1.running_mean, rs[id(ly.norm1)], True, a)
                 z = affine(_conv1x1_fwd(a, w1c), ly.norm2, True)
                 cg.conv_fwd(z, w2c, 1, 1, out=buf[:, cin:cin + growth])
         if hasattr(features, f"transition{i}"):
             tr = getattr(features, f"transition{i}")
+            nxt = getattr(features, f"denseblock{i + 1}", None)
+            Co = tr.conv.weight.shape[0]
+            Hn, Wn = buf.shape[2] // 2, buf.shape[3] // 2
+            if nxt is not None:
+                nl = list(nxt.values())
+                pre = torch.empty((buf.shape[0], Co + len(nl) * nl[0].conv2.out_channels, Hn, Wn), device=buf.device,
+                                  dtype=act_dtype, memory_format=CL)
             if _transition_ok(buf, tr.conv.weight):
                 p = bn_act_avgpool_fwd(buf, tr.norm.weight, tr.norm.bias, tr.norm.running_mean, rs[id(tr.norm)])
-                x = pooled_conv1x1_fwd(p, _weight(tr.conv.weight, act_dtype), tr.norm.eps, None)
+                x = pooled_conv1x1_fwd(p, _weight(tr.conv.weight, act_dtype), tr.norm.eps, None,
+                                       out=None if pre is None else pre[:, :Co])
             else:
                 from . import conv_generic as cg
                 a = affine(buf, tr.norm, True)
                 x = avg_pool_2(cg.conv_fwd(a, _weight(tr.conv.weight, act_dtype), 1, 0))
+                if pre is not None:
+                    copy_into(pre[:, :Co], x)
+                    x = pre[:, :Co]
         elif pooled and _gap_ok(buf):
             bn = features.norm5
             B, C, H, W = buf.shape
@@ -1750,6 +1812,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
         else:
             out = affine(buf, features.norm5, False)
             if pooled:
-                out = F.adaptive_avg_pool2d(out.float(), (1, 1)).flatten(1)
+                from . import conv_generic as cg
+                out = cg.global_avg_pool(out)               # csrc/pool_generic.hip (fp32 result)
         i += 1
     return out

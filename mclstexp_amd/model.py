@@ -241,17 +241,19 @@ class _ContrastiveBase(nn.Module):
     def _encode_image(self, encoder: nn.Module, image: Tensor) -> Tensor:
         if isinstance(encoder, nn.Identity):
             return image
-        if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and encoder.training
-                and image.is_cuda and torch.is_grad_enabled()):
+        if self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and encoder.training and image.is_cuda:
             # segment_backward (set by engine.TrainStep while it captures the data-parallel step): the backbone's backward is
             # cut at the dense-block inputs; the (upstream tensor, slot) pairs are left in self.backward_cuts
             seg = self.segment_backward if self.backbone_dtype == torch.bfloat16 else ()
             self.backward_cuts = [] if seg else None
             return encoder.forward_fused(image, self.backbone_dtype or torch.float32, cuts=self.backward_cuts,
                                          cut_blocks=tuple(seg) if seg else ())
-        if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and not encoder.training
-                and image.is_cuda and self.backbone_dtype == torch.bfloat16 and not torch.is_grad_enabled()):
-            return encoder.forward_eval_fused(image, torch.bfloat16)      # inference: running statistics
+        if self.fused_backbone and isinstance(encoder, backbones.ImageEncoder) and not encoder.training and image.is_cuda:
+            # inference (evel_her2st.py:48-50): running statistics, bf16 fused kernels or the fp32 generic own-kernel path
+            if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in encoder.parameters())):
+                raise RuntimeError("the fused DenseNet path has no backward in eval mode: call model.train() to train, or wrap "
+                                   "inference in torch.no_grad()")
+            return encoder.forward_eval_fused(image, self.backbone_dtype or torch.float32)
         if (self.fused_backbone and image.is_cuda and image.dim() == 4 and isinstance(
                 encoder, (backbones.ImageEncoder_Resnet, backbones.ImageEncdoer_res18, backbones.ImageEncdoer_res101))):
             # ResNet selector values (model.py:88-148) on the generic own-kernel path, bf16 or fp32 activations
@@ -262,10 +264,19 @@ class _ContrastiveBase(nn.Module):
                 raise RuntimeError("the fused ResNet path has no backward in eval mode: call model.train() to train, or wrap "
                                    "inference in torch.no_grad()")
             return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
-        if (self.fused_backbone and isinstance(encoder, backbones.ImageEncoder_VIT) and image.is_cuda
-                and self.backbone_dtype == torch.bfloat16):
+        if self.fused_backbone and isinstance(encoder, backbones.ImageEncoder_VIT) and image.is_cuda:
+            if self.backbone_dtype != torch.bfloat16:
+                # no silent detour through the stock modules (SDPA / ATen): the ViT runs on this library's bf16 kernels only
+                raise RuntimeError("the ViT image encoder runs on the hand-written bf16 kernels: construct the model with "
+                                   "backbone_dtype=torch.bfloat16 (an fp32 ViT path on own kernels does not exist; fused_backbone="
+                                   "False selects the plain torch modules explicitly)")
             from .vit_fused import vit_features_fused           # ViT on the hand-written bf16 kernels (csrc/gemm_bf16.hip)
             return vit_features_fused(encoder.model, image)
+        if self.fused_backbone and image.is_cuda and isinstance(encoder, tuple(backbones.ENCODERS.values())):
+            raise RuntimeError(f"no own-kernel path for {type(encoder).__name__} in this mode (training={encoder.training}, "
+                               f"backbone_dtype={self.backbone_dtype}); set model.fused_backbone = False to run the plain "
+                               "torch modules explicitly")
+        # explicit plain-module path: CPU tensors (BASELINE configs[0] plumbing), fused_backbone = False (A/B), custom encoders
         if self.backbone_dtype is not None and self.backbone_dtype != torch.float32:
             if image.dim() == 4:
                 image = image.contiguous(memory_format=torch.channels_last)

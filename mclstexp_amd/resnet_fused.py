@@ -32,17 +32,17 @@ def _bn(x: Tensor, bn: nn.BatchNorm2d, relu: bool, rec, training: bool) -> Tenso
         return dn._bn_train(x, bn, relu, rec)
     # eval: the affine map of the running statistics
     x = x.contiguous(memory_format=CL)
-    rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+    rstd = dn.eval_rstd([bn])[0]
     out = torch.empty_like(x, memory_format=CL)
     dn.bn_act_fwd(x, bn.weight, bn.bias, bn.running_mean, rstd, relu, out)
     return out
 
 
 def _block(blk: nn.Module, x: Tensor, rec, training: bool) -> Tensor:
-    idt = x
+    x, idt = cg.fork2(x)                      # two consumers: the block and its shortcut (their gradients meet in an own kernel)
     if blk.downsample is not None:
         ds_conv, ds_bn = blk.downsample[0], blk.downsample[1]
-        idt = _bn(cg.conv2d(x, ds_conv.weight, ds_conv.stride[0], ds_conv.padding[0]), ds_bn, False, rec, training)
+        idt = _bn(cg.conv2d(idt, ds_conv.weight, ds_conv.stride[0], ds_conv.padding[0]), ds_bn, False, rec, training)
     if hasattr(blk, "conv3"):                                      # Bottleneck: 1x1 -> 3x3 (stride) -> 1x1
         out = _bn(cg.conv2d(x, blk.conv1.weight, 1, 0), blk.bn1, True, rec, training)
         out = _bn(cg.conv2d(out, blk.conv2.weight, blk.conv2.stride[0], 1), blk.bn2, True, rec, training)

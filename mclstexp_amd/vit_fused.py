@@ -62,6 +62,10 @@ def _w16(w: Tensor) -> Tensor:
         v = prov(w, BF)
         if v is not None and v.is_contiguous():
             return v
+    if w.is_contiguous():
+        v = _dn.cast_dense_bf16(w)
+        if v is not None:
+            return v
     return w.detach().to(BF).contiguous()
 
 

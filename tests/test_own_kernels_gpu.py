@@ -247,3 +247,52 @@ def test_dropout_path_runs_on_own_kernels():
     bad = [n for n in kernel_audit.foreign(ks) if "FillFunctor" not in n and "CUDAFunctor_add" not in n]
     assert not bad, bad
     assert any("dropout_fwd_kernel" in n for n in ks) and any("gelu_kernel" in n for n in ks)
+
+
+@pytest.mark.parametrize("encoder_name,dim", [("densenet121", 1024), ("resnet50", 2048), ("res18", 512), ("res101", 2048),
+                                                ("vit", 768)])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_every_encoder_selector_runs_on_own_kernels(encoder_name, dim, dtype, mode):
+    """/root/reference/model.py:206-215 selector values x {bf16, fp32 activations} x {train step, eval-mode inference
+    (evel_her2st.py:48-50)}: the image branch launches this library's kernels only -- no ATen / MIOpen / hipBLASLt kernel --
+    or refuses loudly (ViT with fp32 activations: no own-kernel path exists; never a silent detour through the stock modules)."""
+    from mclstexp_amd import kernel_audit
+    from mclstexp_amd.model import mclSTExp_Attention
+    torch.manual_seed(0)
+    bb = torch.bfloat16 if dtype == "bf16" else None
+    hw = 224 if encoder_name == "vit" else 64
+    m = mclSTExp_Attention(encoder_name, 1.0, dim, 171, 256, 8, 64, 2, backbone_dtype=bb).to(DEV)
+    m.to(memory_format=torch.channels_last)
+    x = torch.rand(4, 3, hw, hw, device=DEV).contiguous(memory_format=torch.channels_last)
+    if encoder_name == "vit" and dtype == "f32":
+        m.train(mode == "train")
+        with pytest.raises(RuntimeError, match="bf16 kernels"):
+            with torch.no_grad():
+                m.encode_image(x)
+        return
+    if mode == "train":
+        m.train()
+        seed = torch.randn(4, dim, device=DEV)            # the gradient of the features: no loss kernels inside the audit
+
+        def run():
+            m.encode_image(x).backward(seed)
+    else:
+        m.eval()
+
+        def run():
+            with torch.no_grad():
+                m.encode_image(x)
+        if encoder_name != "vit":                          # (the ViT function differentiates in either mode)
+            with pytest.raises(RuntimeError, match="eval mode"):
+                m.encode_image(x)                          # grad mode on + eval: refused instead of a silently cut graph
+    run()                                                  # (first call: dense .grad tensors are created here, outside the audit)
+    ks = kernel_audit.step_kernels(run)
+    bad = kernel_audit.foreign(ks)
+    if (encoder_name, dtype, mode) in (("densenet121", "f32", "train"), ("vit", "bf16", "train"), ("vit", "bf16", "eval")):
+        # KNOWN GAP (stated in DESIGN.md): these three still issue a handful of ATen ELEMENTWISE launches -- strided copies into
+        # the concat buffer (fp32 DenseNet training), the class-token / position-embedding assembly, the final token mean and
+        # dtype casts (ViT).  Every contraction, normalisation, attention and pooling kernel is this library's.
+        glue = ("copy_kernel", "FillFunctor", "CUDAFunctor_add", "MulFunctor", "MeanOps", "sum_functor")
+        bad = [k for k in bad if not any(t in k for t in glue)]
+    assert not bad, bad
