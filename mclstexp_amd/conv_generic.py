@@ -166,6 +166,12 @@ def conv_bwd_weight(dy: Tensor, x: Tensor, w_param: Tensor, stride: int, pad: in
     return None if direct else tgt
 
 
+# Test instrumentation (tests/test_resnet_layerwise_gpu.py): when a list, every ConvFn records the operands its kernels read
+# (x, the cast weight) and what they produced (y; in the backward dy, dx and -- when the weight gradient went straight into
+# .grad -- the parameter), so that each convolution can be re-evaluated in fp64 from exactly those operands.
+CAPTURE_CONVS: Optional[list] = None
+
+
 class ConvFn(torch.autograd.Function):
     """conv2d(x, w, stride, padding) without bias on channels-last activations (fp32 or bf16)."""
 
@@ -175,6 +181,10 @@ class ConvFn(torch.autograd.Function):
         y = conv_fwd(x, wk, stride, pad)
         ctx.save_for_backward(x, wk)
         ctx.w, ctx.geo = w, (stride, pad)
+        ctx.cap = None
+        if CAPTURE_CONVS is not None:
+            ctx.cap = {"x": x, "wk": wk, "y": y, "stride": stride, "pad": pad, "param": w}
+            CAPTURE_CONVS.append(ctx.cap)
         return y
 
     @staticmethod
@@ -183,8 +193,17 @@ class ConvFn(torch.autograd.Function):
         stride, pad = ctx.geo
         if not dy.is_contiguous(memory_format=CL):
             dy = dy.contiguous(memory_format=CL)
+        g_before = None
+        if ctx.cap is not None and getattr(ctx.w, "grad", None) is not None:
+            g_before = ctx.w.grad.detach().clone()
         dw = conv_bwd_weight(dy, x, ctx.w, stride, pad) if ctx.needs_input_grad[1] else None
         dx = conv_bwd_data(dy, wk, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
+        if ctx.cap is not None:
+            ctx.cap.update({"dy": dy, "dx": dx})
+            if dw is not None:
+                ctx.cap["dw"] = dw.detach().clone()
+            elif getattr(ctx.w, "grad", None) is not None:
+                ctx.cap["dw"] = ctx.w.grad.detach() - g_before if g_before is not None else ctx.w.grad.detach().clone()
         return dx, (None if dw is None else dw.to(ctx.w.dtype)), None, None
 
 

@@ -178,8 +178,17 @@ def test_resnet_fused_vs_fp64_module(name, dtype):
     e_s, med_s, worst_s = dev(stock, ys)
     print(f"{name} {dtype}: features {e_f:.2e} of max (stock ops {e_s:.2e}); parameter-gradient deviation median {med:.2e} "
           f"(stock {med_s:.2e}), worst {worst[0]:.2e} ({worst[1]}; stock {worst_s[0]:.2e})")
-    floor = 1e-5 if dtype == torch.float32 else 2e-2
-    assert e_f <= 2.0 * e_s + floor and med <= 2.0 * med_s + floor, (e_f, e_s, med, med_s)
+    if dtype == torch.float32:
+        # (ResNet-18: 3e-6; the 50 / 101-layer nets amplify even fp32 rounding at this batch: bounded relative to the stock
+        # fp32 modules, and kernel by kernel in tests/test_resnet_layerwise_gpu.py)
+        assert e_f <= 2.0 * e_s + 1e-5 and med <= 2.0 * med_s + 1e-5, (e_f, e_s, med, med_s)
+    else:
+        # bf16 end to end: a random-init BatchNorm net at a small batch amplifies rounding chaotically on EVERY bf16 path
+        # (own and stock alike deviate by tens of percent): no kernel can be bounded here.  The kernels are bounded one by one,
+        # from the operands they read, in tests/test_resnet_layerwise_gpu.py; this test keeps the plumbing (all parameters
+        # receive finite gradients, running statistics, no library kernel) and only a loose sanity relation to the stock path.
+        assert all(torch.isfinite(p.grad).all() for p in enc.parameters())
+        assert e_f <= 2.0 * e_s + 2e-2 and med <= 2.0 * med_s + 2e-2, (e_f, e_s, med, med_s)
     bn, bnr = enc.model[1], ref.model[1]
     assert_close(bn.running_mean.cpu(), bnr.running_mean.float().cpu(), 2e-3 if dtype == torch.bfloat16 else 1e-5, what="running_mean")
     assert int(bn.num_batches_tracked) == int(bnr.num_batches_tracked) == 1
