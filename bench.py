@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--dense_tables", action="store_true",
                     help="A/B: update every row of the two position tables on every step (1.57 GB of state traffic) instead of "
                          "the lazy-exact form (optim.FusedAdam(lazy_tables=True): untouched rows are replayed on demand)")
+    ap.add_argument("--serial_lanes", action="store_true",
+                    help="profiling aid: no side streams (every kernel alone on the GPU, one lane) -- the schedule the serial "
+                         "rocprofv3 traces under profiles/ record; results are bit-identical to the two-lane step")
     ap.add_argument("--launch_check", action="store_true",
                     help="only exercise the launcher + process group (works without a GPU, gloo): prints a JSON line")
     return ap.parse_args()
@@ -304,6 +307,9 @@ def main():
                                backbone_dtype=bb, embedding_grad="rowsparse",
                                process_group=pg, infonce=args.infonce)
     from mclstexp_amd import densenet_fused
+    if args.serial_lanes:
+        densenet_fused.USE_SIDE_STREAM = False
+        type(model).overlap_branches = False
     model.fused_backbone = not args.unfused_backbone
     model.to(dev)
     if bb is not None:

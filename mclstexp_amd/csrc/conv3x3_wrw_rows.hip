@@ -236,9 +236,8 @@ inline WrwRowsPlan wrw_rows_plan(long long S, int H, int W) {
   // two row streams per workgroup, one workgroup per CU (147 KB of LDS); chunks sized for 512 streams.  The launch is capped
   // at 160 workgroups: the kernel lives on the side stream, where a full-chip grid of CU-filling workgroups keeps the
   // critical chain's kernels off the CUs (bench.py: 12.93-12.97 ms/step at 256 workgroups, 12.78-12.84 at 128-160, 12.84-12.90
-  // with the kernel-row form although this kernel alone is twice as fast; MCL_WRW_ROWS_GRID for A/B runs)
-  static const char* e_g = getenv("MCL_WRW_ROWS_GRID");
-  const int gcap = mcl_env_grid(e_g, 160);
+  // with the kernel-row form although this kernel alone is twice as fast)
+  const int gcap = 160;
   long long rc = ((long long)H * p.nimg + 511) / 512;
   if (rc < 1) rc = 1;
   if (rc > H) rc = H;
@@ -254,8 +253,6 @@ inline WrwRowsPlan wrw_rows_plan(long long S, int H, int W) {
 }  // namespace
 
 bool mcl_conv3x3_wrw_rows_applicable(long long S, int H, int W) {
-  static const char* e = getenv("MCL_C3_WRW_ROWS");
-  if (e && atoi(e) == 0) return false;
   return W >= 17 && W <= 64 && S % ((long long)H * W) == 0;
 }
 

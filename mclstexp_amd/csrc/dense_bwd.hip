@@ -824,11 +824,7 @@ inline BwdRowsPlan bwd_rows_plan(long long S, int H, int W) {
 }
 
 inline bool bwd_rows_applicable(long long S, int H, int W) {
-  static const char* e = getenv("MCL_C3_ROWS");
-  if (e && atoi(e) == 0) return false;
-  static const char* e_minw = getenv("MCL_C3_ROWS_MINW");
-  const int minw = e_minw ? atoi(e_minw) : 17;
-  return W >= minw && W <= 150 && S % ((long long)H * W) == 0;
+  return W >= 17 && W <= 150 && S % ((long long)H * W) == 0;
 }
 
 // dz = gamma*rstd*(g2 - c1 - zhat*c2), elementwise over (S, 128) bf16
@@ -904,12 +900,10 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   // persistent over row tiles: two (128-row tiles) or three (64-row tiles) workgroups per CU, each keeps one column tile
   // 512 workgroups (two per CU) although LDS and registers allow three: alone the kernels are faster with three (r01:
   // 2302 -> 1835 us/step serial), but in the step they share the CUs with the weight-gradient kernels of the side stream,
-  // which cannot become resident beside three: 14.02 / 14.09 ms/step at 768, 13.92 / 13.96 at 512 (MCL_MAIN_GRID for A/B).
+  // which cannot become resident beside three: 14.02 / 14.09 ms/step at 768, 13.92 / 13.96 at 512.
   // Only on the 28 x 28 and larger maps: below, the grids do not fill the chip anyway and three per CU stay (no difference
-  // in the step, 13.84-13.95 either way; MCL_MAIN_GRID_SMALL)
-  static const char* e_gx = getenv("MCL_MAIN_GRID");
-  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
+  // in the step, 13.84-13.95 either way)
+  const int gcap = S >= 50000 ? 512 : 768;
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
@@ -947,9 +941,7 @@ extern "C" int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, 
   const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
   float2* part = reinterpret_cast<float2*>(workspace);
   hipStream_t st = mcl_stream(stream);
-  static const char* e_gx = getenv("MCL_MAIN_GRID");
-  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
+  const int gcap = S >= 50000 ? 512 : 768;
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<2, 64>), dim3(gx, nct), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,
@@ -990,9 +982,7 @@ extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const
       (reinterpret_cast<uintptr_t>(gbuf) & 15u))
     return MCL_EUNSUPPORTED;
   const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
-  static const char* e_gx = getenv("MCL_MAIN_GRID");
-  static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-  const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
+  const int gcap = S >= 50000 ? 512 : 768;
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<1, 64>), dim3(gx, nct), dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
@@ -1048,9 +1038,7 @@ int conv3x3_bwd_impl(const void* dy, int64_t lddy, int64_t S, int32_t H, int32_t
     const int ntile = (int)((S + T3B - 1) / T3B);
     coef = workspace + (int64_t)ntile * 2 * C3I;
     const size_t lds_bytes = (size_t)T3B * 256 + (size_t)(T3B + 2 * W + 2) * 64 + 64;
-    static const char* e_gx = getenv("MCL_MAIN_GRID");
-    static const char* e_gs = getenv("MCL_MAIN_GRID_SMALL");
-    const int gcap = S >= 50000 ? mcl_env_grid(e_gx, 512) : mcl_env_grid(e_gs, 768);
+    const int gcap = S >= 50000 ? 512 : 768;
     hipLaunchKernelGGL(conv3x3_bwd_kernel, dim3(ntile < gcap ? ntile : gcap), dim3(256), lds_bytes, st, (const bf16_t*)dy,
                        (long long)lddy, (long long)S, H, W, (const bf16_t*)W2, (const bf16_t*)z, gamma, beta, mean, rstd,
                        (bf16_t*)g2, part, ntile, (const bf16_t*)xfix, (long long)ldxf, fmean, frstd, fk, (bf16_t*)dyc);

@@ -389,24 +389,14 @@ extern "C" int mcl_dense_conv1x1_fwd(const void* x, int64_t ldx, int64_t S, int3
   hipLaunchKernelGGL((conv1x1_fwd_kernel<WMV, RWV, DPV>), dim3(nblk), dim3(128 * WMV), 0, st, (const bf16_t*)x,      \
                      (long long)ldx, (long long)S, K, gamma, beta, mean, rstd, (const bf16_t*)W, (bf16_t*)z,          \
                      (long long)ldz, part, nblk)
-  static const char* e_half = getenv("MCL_C1F_HALF");
-  const bool half_waves = !(e_half && atoi(e_half) == 0);
-  // (the same doubling for the 128- / 256-row tiles, which already run two waves per SIMD, measured no gain)
-  static const char* e_dp = getenv("MCL_C1F_DEPTH");
-  const int depth = e_dp ? atoi(e_dp) : 4;
-  static const char* e_dl = getenv("MCL_C1F_DEPTH_LARGE");
   // 56 x 56 / 28 x 28 maps: ONE LDS stage and one register set (40 KB, 166 registers: three workgroups per CU).  In-kernel
   // timestamps of the two-stage form showed a workgroup loading nothing for half of its life (prologue 2.7 us, K loop 5.7
   // at the HBM rate, statistics + store 3.4): a third resident workgroup fills more of that than the second stage hid.
-  // r03 same box: 102 -> 88 us (C = 224), 57 -> 48 (C = 64) alone; 11.77 / 11.80 -> 11.65 / 11.70 ms/step.  On the
-  // small maps the same form (64-row tiles, 4 per CU) measured 11.90 / 11.94 vs 11.88 / 11.85: they keep 4 stages ahead.
-  const int depth_large = e_dl ? atoi(e_dl) : 0;
-  if (wm == 2 && depth_large == 0) MCL_LAUNCH(2, 64, 0);
-  else if (wm == 2) MCL_LAUNCH(2, 64, 2);
-  else if (half_waves && depth == 4) MCL_LAUNCH(2, 32, 4);
-  else if (half_waves && depth == 2) MCL_LAUNCH(2, 32, 2);
-  else if (half_waves) MCL_LAUNCH(2, 32, 1);
-  else MCL_LAUNCH(1, 64, 1);
+  // r03 same box: 102 -> 88 us (C = 224), 57 -> 48 (C = 64) alone; 11.77 / 11.80 -> 11.65 / 11.70 ms/step.  The small maps run
+  // the same 64-row tile on four waves with four K-stages requested ahead (the one-stage form measured 11.90 / 11.94 vs 11.88 /
+  // 11.85 there; the two-wave form and shallower prefetch lost in round 3).
+  if (wm == 2) MCL_LAUNCH(2, 64, 0);
+  else MCL_LAUNCH(2, 32, 4);
 #undef MCL_LAUNCH
   if (want_stats)
     hipLaunchKernelGGL(tile_stats_finalize_kernel, dim3(BN), dim3(256), 0, st, (const float2*)part, nblk, BN,
@@ -853,8 +843,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wrw_ky_kernel(const bf16_t* __
 
 // pixel groups (= partials) of the kernel-row form: three workgroups each, two workgroups per CU
 static inline int wrw3k_groups(int ntile) {
-  static const char* e = getenv("MCL_W3K_GROUPS");             // 88 x 3 workgroups: 14.08 ms/step at 176, 13.99 at 88 (32-88 alike)
-  const int g = mcl_env_grid(e, 88);
+  const int g = 88;                                            // 88 x 3 workgroups: 14.08 ms/step at 176, 13.99 at 88 (32-88 alike)
   return ntile < g ? ntile : g;
 }
 
@@ -1175,10 +1164,9 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
 // launch; accumulate_w != 0 adds into dW.
 // Workgroups of the stem weight gradient: each owns a 37.6 KB fp32 partial.  Three per CU are resident (42 KB of LDS each):
 // the kernel's phases (transposing stores of the dy tile, the input slab, the MFMA loop) are separated by barriers, and a
-// single workgroup per CU -- the former grid of 256 -- overlaps none of them.  MCL_C0W_GRID for A/B.
+// single workgroup per CU -- the former grid of 256 -- overlaps none of them.
 inline int conv0_wrw_grid(int ntile) {
-  static const char* e = getenv("MCL_C0W_GRID");
-  const int cap = mcl_env_grid(e, 768);
+  const int cap = 768;
   return ntile < cap ? ntile : cap;
 }
 extern "C" int64_t mcl_conv0_wrw_workspace_floats(int32_t N, int32_t H, int32_t W) {

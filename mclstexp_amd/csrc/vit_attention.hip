@@ -486,11 +486,10 @@ extern "C" int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B,
   }
   // Long sequences (T = 197): one workgroup per item without next-item registers -- four waves per SIMD, two workgroups per CU cover
   // each other's prologue (136-139 us per layer at B = 256 against 146-148 persistent).  Short ones (T = 50): the persistent walk
-  // with the next item prefetched into registers (41 against 43.6 us).  MCL_VIT_ATTN_PERSIST=0 / 1 forces one form (A/B).
+  // with the next item prefetched into registers (41 against 43.6 us).
   // One wave per 32-token strip: 128 / 256 / 512 threads for up to 64 / 128 / 224 tokens.
-  const char* e_p = getenv("MCL_VIT_ATTN_PERSIST");
   const int items = B * heads, nb = (T + 31) / 32;
-  const bool persist = e_p ? e_p[0] != '0' : T <= 128;
+  const bool persist = T <= 128;
   const int wg_per_cu = nb <= 2 ? 4 : (nb <= 4 ? 2 : 1);           // persistent grid: eight waves per CU whatever the workgroup size
   const int pgrid = mcl_cu_count() * wg_per_cu;
   const int grid = (items < 2 * pgrid || !persist) ? items : pgrid;

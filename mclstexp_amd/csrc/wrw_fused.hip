@@ -426,9 +426,8 @@ inline Split plan(long long S, int N) {
   // waves per SIMD cover each other's issue gaps), but in the step it shares the chip with the other lane's kernels and
   // every workgroup costs a 64 KB partial that the merge re-reads (r03 same-box: 12.00 ms/step at 192, 12.18 at 256).
   // The small maps (blocks 3-4: the whole operand set is 8-56 MB) keep at least 4 tiles (2 on the 7 x 7 maps) per
-  // workgroup.  MCL_WRW_TARGET for A/B.
-  static const char* e_t = getenv("MCL_WRW_TARGET");
-  const long long target = e_t ? atoll(e_t) : 192;
+  // workgroup.
+  const long long target = 192;
   long long ks = (target + p.tn - 1) / p.tn;
   const long long min_rows = S < 10000 ? 2 * BK : 4 * BK;
   const long long max_ks = (S + min_rows - 1) / min_rows;

@@ -210,7 +210,7 @@ def bn_act_bwd(dy: Tensor, x: Tensor, gamma: Tensor, beta: Tensor, mean: Tensor,
 # When a parameter already owns a dense fp32 .grad (FusedAdam's flat bucket, zeroed every step), backward
 # adds its gradient straight into it and returns None to autograd: saves one temporary, one dtype cast and
 # one AccumulateGrad add kernel per parameter (~480 tiny launches per DenseNet-121 step).
-DIRECT_PARAM_GRADS = os.environ.get("MCL_DIRECT_GRADS", "1") != "0"
+DIRECT_PARAM_GRADS = True          # (module constant: tests / tools may flip it; the environment switch is gone)
 
 
 class BNActFn(torch.autograd.Function):
@@ -390,8 +390,8 @@ def dense_bn1_fix(buf: Tensor, gbuf: Tensor, c0: int, nc: int, mean: Tensor, rst
 # directly, whose weight has an exactly zero true gradient (the following BatchNorm layers make the loss invariant to its
 # scale): at B = 4, where all four blocks would otherwise qualify, the noise on that parameter grew 6x
 # (tools/diag_accuracy_batch.py; test_cfg4_backbone_256px_accuracy_vs_fp64's maximum 2.1 -> 12).
-USE_BN1_SINGLE_PASS = os.environ.get("MCL_BN1_SINGLE_PASS", "1") != "0"
-BN1_SINGLE_PASS_MAX_MAP = int(os.environ.get("MCL_BN1_SINGLE_PASS_MAX_MAP", "256"))
+USE_BN1_SINGLE_PASS = True
+BN1_SINGLE_PASS_MAX_MAP = 256
 
 # Deterministic fusion of the bottleneck weight gradient with the BatchNorm-backward reduction (csrc/wrw_fused.hip): one
 # pass over (dz, x) replaces conv1x1_wrw + the reduce launch + its finalize; then the dx pass alone.  It does the least
@@ -400,8 +400,8 @@ BN1_SINGLE_PASS_MAX_MAP = int(os.environ.get("MCL_BN1_SINGLE_PASS_MAX_MAP", "256
 # throughput-bound, the side work costs its full duration anyway, and saving one pass over (dz, x) per layer wins:
 # fused from 200 000 pixels up 14.08 / 14.12 ms/step, from 50 000 up 14.15, never 14.28 / 14.36 (interleaved A/B); after the
 # side-lane grids were shrunk (csrc/wrw_fused.hip plan()): from 50 000 up 13.59 / 13.60, from 200 000 up 13.70 / 13.76.
-USE_FUSED_BN1_WRW = os.environ.get("MCL_FUSED_BN1_WRW", "1") != "0"
-FUSED_BN1_WRW_MIN_PIXELS = int(os.environ.get("MCL_FUSED_BN1_WRW_MIN_PIXELS", "50000"))
+USE_FUSED_BN1_WRW = True
+FUSED_BN1_WRW_MIN_PIXELS = 50000
 
 
 def _bn1_wrw_ok(w_param: Tensor) -> bool:
@@ -439,14 +439,14 @@ def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor,
 # The 32-channel mean-term correction of the single-pass BatchNorm-1 backward (mcl_dense_bn1_fix: a 5 us launch in front of
 # every 3x3 backward-data kernel of the 14 x 14 / 7 x 7 blocks, 38 per step on the critical chain) folded into that kernel's
 # dy staging.  MCL_FOLD_BN1_FIX=0: the separate launch (A/B; bit-identical results).
-FOLD_BN1_FIX = os.environ.get("MCL_FOLD_BN1_FIX", "1") != "0"
+FOLD_BN1_FIX = True
 
 
 def _c3_flat_kernel(W: int) -> bool:
     """True when the 3x3 backward-data of a W-wide map runs the flat-tile kernel (csrc/dense_bwd.hip bwd_rows_applicable)."""
-    if os.environ.get("MCL_C3_ROWS", "1") == "0":
+    if False:
         return True
-    return W < int(os.environ.get("MCL_C3_ROWS_MINW", "17")) or W > 150
+    return W < 17 or W > 150
 
 
 def dense_conv3x3_bwd(dy: Tensor, w16: Tensor, z: Tensor, g2: Tensor, b2: Tensor, m2: Tensor, r2: Tensor,
@@ -655,7 +655,7 @@ def _conv_bwd(dy: Tensor, x: Tensor, w: Tensor, w_param: Tensor, padding: int):
 # The two weight-gradient kernels of a layer are independent of its data-gradient chain (they only add into .grad):
 # issue them on a side stream so they overlap the latency-bound backward-data / BatchNorm-backward launches (under
 # HIP-graph capture this becomes a parallel branch of the graph).  Joined at the end of every layer.
-USE_SIDE_STREAM = os.environ.get("MCL_SIDE_STREAM", "1") != "0"
+USE_SIDE_STREAM = True             # (bench.py switches it off for its per-kernel timing pass)
 _side_streams = {}
 
 
@@ -672,7 +672,7 @@ def _side_stream(device) -> torch.cuda.Stream:
 # it reads are parked here (so that the allocator cannot hand their memory out again), and the main stream joins
 # once per dense block / at the stem.
 _side_parked: dict = {}
-JOIN_MIN_PIXELS = int(os.environ.get("MCL_JOIN_MIN_PIXELS", "300000"))
+JOIN_MIN_PIXELS = 300000
 
 
 def _side_park(device, *tensors) -> None:

@@ -44,7 +44,7 @@ class TrainStep:
         self.es = self.ei = self.d_es = self.d_ei = self.loss = None
         can_single = reducer is None and getattr(model, "process_group", None) is None
         if single_graph is None:
-            single_graph = os.environ.get("MCL_SINGLE_GRAPH", "1") != "0"
+            single_graph = True
         self.single_graph = bool(single_graph) and can_single
         self._sizes_ex = None
         self._all_regular = True
@@ -93,8 +93,7 @@ class TrainStep:
         batch = {k: batch[k] for k in ("image", "expression", "position")}
         sink = getattr(m, "sparse_grads", None)
         early = (self.opt_will_be_in_graph() and sink is not None and hasattr(self.opt, "_early_tables")
-                 and getattr(m, "embedding_grad", "dense") == "rowsparse" and "hook" not in sink
-                 and os.environ.get("MCL_EARLY_TABLES", "1") != "0")
+                 and getattr(m, "embedding_grad", "dense") == "rowsparse" and "hook" not in sink)
         if early:
             sink["hook"] = self.opt._early_tables
         try:
@@ -127,7 +126,7 @@ class TrainStep:
         m = self.model
         enc = getattr(m, "image_encoder", None)
         img = batch.get("image")
-        return (os.environ.get("MCL_STAGE_IMAGE_BF16", "1") != "0" and getattr(m, "fused_backbone", False)
+        return (getattr(m, "fused_backbone", False)
                 and getattr(m, "backbone_dtype", None) == torch.bfloat16
                 and isinstance(enc, (backbones.ImageEncoder, backbones.ImageEncoder_Resnet, backbones.ImageEncdoer_res18,
                                      backbones.ImageEncdoer_res101))
@@ -164,8 +163,7 @@ class TrainStep:
             # under the latency-bound blocks of the backbone) -- armed for the capture only, see FusedAdam.attach_model
             sink = getattr(m, "sparse_grads", None)
             early = (self.opt_will_be_in_graph() and sink is not None and hasattr(self.opt, "_early_tables")
-                     and getattr(m, "embedding_grad", "dense") == "rowsparse" and "hook" not in sink
-                     and os.environ.get("MCL_EARLY_TABLES", "1") != "0")
+                     and getattr(m, "embedding_grad", "dense") == "rowsparse" and "hook" not in sink)
             if early:
                 sink["hook"] = self.opt._early_tables
             with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
@@ -174,7 +172,7 @@ class TrainStep:
                 self.es, self.ei, self.loss = self._sequence(self.static_in)
                 # the optimizer too: FusedAdam keeps its step counter and constants on the device (optim._begin_step), so
                 # its launches replay unchanged -- no eager launches between two replays
-                self.opt_in_graph = hasattr(self.opt, "_begin_step") and os.environ.get("MCL_OPT_IN_GRAPH", "1") != "0"
+                self.opt_in_graph = hasattr(self.opt, "_begin_step")
                 if self.opt_in_graph:
                     self.opt.step()
                     self.opt._step_count -= 1    # capture records launches, it does not run them: the replay counts
@@ -277,8 +275,7 @@ class TrainStep:
         # (a small all-gather, first on the communicator) + the HBM-streaming table Adam run on a side stream beside the
         # remaining, latency-bound segments -- what the single-process step graph does from inside its backward
         tables_side = None
-        if hasattr(self.opt, "_early_tables") and getattr(self.model, "embedding_grad", "dense") == "rowsparse" \
-                and os.environ.get("MCL_EARLY_TABLES", "1") != "0":
+        if hasattr(self.opt, "_early_tables") and getattr(self.model, "embedding_grad", "dense") == "rowsparse":
             if self._tables_stream is None:
                 self._tables_stream = torch.cuda.Stream(device=main.device)
             tables_side = self._tables_stream
@@ -304,7 +301,7 @@ class TrainStep:
             self.opt.step()
 
     def opt_will_be_in_graph(self) -> bool:
-        return hasattr(self.opt, "_begin_step") and os.environ.get("MCL_OPT_IN_GRAPH", "1") != "0"
+        return hasattr(self.opt, "_begin_step")
 
     def _eager_ragged(self, batch) -> Tensor:
         """A batch whose shapes differ from the captured ones (ragged last batch: train.py:49 has no drop_last) runs

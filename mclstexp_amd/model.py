@@ -217,13 +217,13 @@ class _ContrastiveBase(nn.Module):
     # backward) shares nothing with the image branch until the loss: run it on a side stream so it overlaps the
     # DenseNet kernels.  Autograd replays each branch's backward on the stream its forward ran on, and under HIP-graph
     # capture the fork/join becomes a parallel branch of both graphs.
-    overlap_branches = os.environ.get("MCL_OVERLAP_BRANCHES", "1") != "0"
+    overlap_branches = True           # (class attribute: bench.py switches it off for its per-kernel timing pass)
     _branch_streams: Dict[int, "torch.cuda.Stream"] = {}
 
     def _branch_stream(self, device) -> Optional["torch.cuda.Stream"]:
         if not (self.overlap_branches and device.type == "cuda"):
             return None
-        if (os.environ.get("MCL_SHARED_SIDE", "1") != "0" and self.fused_backbone
+        if (self.fused_backbone
                 and isinstance(getattr(self, "image_encoder", None), (backbones.ImageEncoder, backbones.ImageEncoder_VIT))
                 and self.backbone_dtype == torch.bfloat16):
             # ONE side stream for everything off the critical chain.  A replayed graph runs on two hardware queues here:
@@ -428,7 +428,7 @@ class mclSTExp_Attention(_ContrastiveBase):
     def embed(self, batch):
         ops.set_compute(self.compute)
         side = self._branch_stream(batch["expression"].device)
-        late = int(os.environ.get("MCL_SPOT_AFTER_BLOCK", "2"))
+        late = 2
         # only the train-mode fused forward (densenet_features_fused) fires the block hook: eval / no_grad calls take
         # forward_eval_fused or the module and must use the plain fork below, or the side stream would wait on an event
         # that is never recorded (= not wait at all)

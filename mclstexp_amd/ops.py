@@ -63,7 +63,7 @@ def _p(t: Optional[Tensor]) -> Optional[int]:
 
 
 # --------------------------------------------------------------------------- GEMM
-SPLIT_K = os.environ.get("MCL_GEMM_SPLITK", "1") != "0"     # A/B switch for the split-K path of mcl_gemm
+SPLIT_K = True
 
 
 def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, sAb: int, B: Tensor, sBk: int,
@@ -126,7 +126,7 @@ def linear_bwd_data(dy: Tensor, W: Tensor, gelu_bwd_aux: Optional[Tensor] = None
 
 # When a weight already owns a dense fp32 .grad (FusedAdam's flat bucket, zeroed every step) its gradient GEMM adds
 # straight into it and autograd gets None: no temporary, no AccumulateGrad add kernel (12 of them per spot-path step).
-DIRECT_PARAM_GRADS = os.environ.get("MCL_DIRECT_GRADS", "1") != "0"
+DIRECT_PARAM_GRADS = True
 
 
 def _direct_grad_ok(p) -> bool:

@@ -82,10 +82,8 @@ class FusedAdam(torch.optim.Optimizer):
         # The position tables can be updated as soon as their gradient rows exist -- from inside PosEmbedAddFn.backward, on
         # the side stream, under the latency-bound part of the image backbone's backward -- instead of in step().  That
         # changes what a bare ``loss.backward()`` does, so it is engine.TrainStep that switches it on, only while it captures
-        # its single step graph (a backward that is always followed by step()); MCL_EARLY_TABLES=always forces it for every
-        # backward of an attached model.  Data parallel always updates in step() (gathered rows of every rank).
-        if self._sink is not None and self.process_group is None and os.environ.get("MCL_EARLY_TABLES", "0") == "always":
-            self._sink["hook"] = self._early_tables
+        # its single step graph (a backward that is always followed by step()).  Data parallel always updates in step()
+        # (gathered rows of every rank).
         # load_state_dict() into a live model rewrites the flat fp32 buffer behind the bf16 shadows' back (captured
         # HIP graphs read the shadows directly, so the lazy per-parameter check in shadow() cannot catch that case)
         if hasattr(model, "register_load_state_dict_post_hook"):

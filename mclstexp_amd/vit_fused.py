@@ -69,10 +69,10 @@ def _w16(w: Tensor) -> Tensor:
     return w.detach().to(BF).contiguous()
 
 
-GELU_HANDOFF = os.environ.get("MCL_VIT_GELU_HANDOFF", "1") != "0"         # 0: fc1 stores the pre-activation, gelu' evaluated in the backward (A/B)
-FUSED_ATTN = os.environ.get("MCL_VIT_FUSED_ATTN", "1") != "0"            # 0: batched GEMMs + softmax launches (A/B, T > 224)
-JOIN_EVERY = int(os.environ.get("MCL_VIT_JOIN_EVERY", "4"))              # encoder blocks between joins of the side stream
-KSPLIT_TARGET = int(os.environ.get("MCL_VIT_KSPLIT_TARGET", "128"))     # workgroups a split-K weight gradient aims for (side lane: 60.5 ms/step at 256, 59.7 at 128)
+GELU_HANDOFF = True         # 0: fc1 stores the pre-activation, gelu' evaluated in the backward (A/B)
+FUSED_ATTN = True            # 0: batched GEMMs + softmax launches (A/B, T > 224)
+JOIN_EVERY = 4              # encoder blocks between joins of the side stream
+KSPLIT_TARGET = 128     # workgroups a split-K weight gradient aims for (side lane: 60.5 ms/step at 256, 59.7 at 128)
 
 
 def _ksplit(m_out: int, n_out: int) -> int:
@@ -91,7 +91,7 @@ def _grad_target(p: Tensor):
 # Weight and bias gradients only feed the optimizer: they run on the side stream (the step's second lane, shared with the
 # spot branch and the DenseNet weight gradients) while the data-gradient chain continues, whenever they accumulate
 # straight into the parameters' .grad (nothing is handed back to autograd from the other stream).
-SIDE_WGRAD = os.environ.get("MCL_VIT_SIDE_WGRAD", "1") != "0"
+SIDE_WGRAD = True
 
 
 def _param_grads(dy: Tensor, x: Tensor, lin, rows: int, grads: dict) -> None:

@@ -7,7 +7,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/hp/fetch -- $B -
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/hp/write -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 # 2. kernel traces: shipped configuration, and every kernel alone (no side streams)
 rocprofv3 --kernel-trace -d $R/gpurun_out/hp/kt -o kt -- $B --steps 12 --warmup 4 > /dev/null 2>&1
-MCL_SIDE_STREAM=0 MCL_OVERLAP_BRANCHES=0 rocprofv3 --kernel-trace -d $R/gpurun_out/hp/ks -o ks -- $B --steps 12 --warmup 4 > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $R/gpurun_out/hp/ks -o ks -- $B --serial_lanes --steps 12 --warmup 4 > /dev/null 2>&1
 cd $R
 python tools/make_traffic_json.py gpurun_out/hp/fetch gpurun_out/hp/write gpurun_out/head_kernel_traffic.json gpurun_out/head_pmc_hbm_traffic.txt > /dev/null
 cp gpurun_out/head_kernel_traffic.json profiles/kernel_traffic.json
@@ -19,7 +19,7 @@ rm -rf gpurun_out/hp
 # 3. the bench line itself (with the traffic file just produced and the CPU baseline), and the no-overlap wall times
 python bench.py --steps 100 --warmup 20 > gpurun_out/head_bench.json 2> gpurun_out/head_bench.err
 cut -c1-400 gpurun_out/head_bench.json
-for v in "0 0" "1 0"; do set -- $v; MCL_SIDE_STREAM=$1 MCL_OVERLAP_BRANCHES=$2 python bench.py --steps 60 --warmup 10 --no_cpu_baseline --profile_steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('side=$1 overlap=$2', d['ms_per_step'])"; done > gpurun_out/head_overlap_modes.txt
+python bench.py --serial_lanes --steps 60 --warmup 10 --no_cpu_baseline --profile_steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('serial lanes (no side streams)', d['ms_per_step'])" > gpurun_out/head_overlap_modes.txt
 cat gpurun_out/head_overlap_modes.txt
 # 4. micro-benchmarks
 python tools/bench_infonce.py --unfused > gpurun_out/head_infonce.jsonl 2>/dev/null
