@@ -120,6 +120,28 @@ def _adam_table_lazy(a):        # (p0, m0, v0, rs0, p1, ..., n_rows, cols, pos, 
     return tables * a[13] * a[9] * (24 + (4 if a[14] else 0))
 
 
+def _block_fwd(a):              # (buf, B, H, W, Ct, C0, L, ...): block input read once, z + the new channels written once, weights
+    B, HW, Ct, C0, L = a[1], a[2] * a[3], a[4], a[5], a[6]
+    w = sum(128 * (C0 + 32 * l) * 2 for l in range(L)) + L * 32 * 1152 * 2
+    return 2 * B * HW * C0 + L * 2 * B * HW * 128 + 2 * B * HW * 32 * L + w
+
+
+def _block_fwd_flops(a):
+    B, HW, C0, L = a[1], a[2] * a[3], a[5], a[6]
+    return sum(2 * B * HW * (128 * (C0 + 32 * l) + 1152 * 32) for l in range(L))
+
+
+def _block_bwd(a):              # (buf, gbuf, B, H, W, Ct, C0, L, ...): gbuf + buf read once, z read, dz + dy' written, dx written, weights
+    B, HW, Ct, C0, L = a[2], a[3] * a[4], a[5], a[6], a[7]
+    w = sum(128 * (C0 + 32 * l) * 2 for l in range(L)) + L * 32 * 1152 * 2
+    return 2 * 2 * B * HW * Ct + 2 * B * HW * C0 + L * 2 * B * HW * (128 + 128 + 32) + w
+
+
+def _block_bwd_flops(a):
+    B, HW, C0, L = a[2], a[3] * a[4], a[6], a[7]
+    return sum(2 * B * HW * (128 * (C0 + 32 * l) + 1152 * 32) for l in range(L))
+
+
 def _adam(a):                   # (p, g, m, v, n, ...): read p, g, m, v; write p, m, v
     return 28 * a[4]
 
@@ -160,6 +182,10 @@ TABLE = {
     "mcl_dense_conv3x3_fwd": _e("conv3x3_fwd_rows_kernel + sums_finalize_kernel (56x56, 28x28 maps) / conv3x3_fwd_kernel + "
                                 "tile_stats_finalize_kernel", _conv3x3_fwd, flops=_conv3x3_flops_S1, bound="mfma/lds"),
     "mcl_adam_table_step_dev": _e("adam_table_kernel", _adam_table, bound="hbm"),
+    "mcl_dense_block_fwd": _e("dense_block_fwd_kernel (a whole 7x7 dense block forward: one persistent launch, in-launch batch-statistics "
+                              "seams) + zero_words_kernel", _block_fwd, flops=_block_fwd_flops, bound="latency"),
+    "mcl_dense_block_bwd": _e("dense_block_bwd_kernel (the block's data-gradient chain: one persistent launch) + zero_words_kernel",
+                              _block_bwd, flops=_block_bwd_flops, bound="latency"),
     "mcl_adam_table_lazy": _e("adam_table_lazy_kernel (catch-up of gathered rows / update of the rows with a gradient)",
                               _adam_table_lazy, bound="latency"),
     "mcl_adam_step_dev": _e("adam_kernel", _adam, bound="hbm"),
