@@ -541,7 +541,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_stag_kernel(GemmB g) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (ht + 3 < nh) dma_half(ht + 3);                // into the slot of ht - 1, whose last reader finished before the last barrier
+    // into the slot of ht - 1.  Its last readers are the OTHER wave group's fragment reads of R(ht - 1), ISSUED before the barrier
+    // this group has just passed but only waited for (lgkmcnt(0)) in that group's M segment, after the barrier: formally those
+    // reads may still be outstanding here.  What keeps them ahead of the refill is latency, not a counted wait -- an LDS read
+    // returns in ~100 cycles, the LDS-DMA write lands after a global-memory round trip (> 1000) -- and tools/stress_gemm_stag.py
+    // (random problems, bit-compared with the lockstep kernel: 400 / 0 mismatches, kept in the profile scripts) screens it.
+    // Moving the lgkmcnt(0) in front of the R-segment barrier closes the window formally and was measured 2-3 % slower.
+    if (ht + 3 < nh) dma_half(ht + 3);
     __builtin_amdgcn_sched_barrier(0);                // (the 4 pieces spread among the MFMAs below instead: measured 2-5 % slower)
     __builtin_amdgcn_s_barrier();
     // ---- M segment

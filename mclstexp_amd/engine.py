@@ -30,12 +30,13 @@ Tensor = torch.Tensor
 
 class TrainStep:
     def __init__(self, model, optimizer, reducer=None, graphs: bool = True, warmup: int = 3,
-                 single_graph: Optional[bool] = None, equal_shards: bool = False):
+                 single_graph: Optional[bool] = None, equal_shards: bool = False, strict_shards: bool = False):
         """``equal_shards``: the caller guarantees that every rank sees the same per-rank batch size on every step
         (DistributedSampler with drop_last, synthetic data): the per-step host size exchange -- a blocking gloo
         all-gather that keeps the ranks' host threads in lock-step -- is skipped."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.equal_shards = bool(equal_shards)
+        self.strict_shards = bool(strict_shards)
         self.graphs = graphs and torch.cuda.is_available()
         self.warmup = max(2, warmup)
         self.calls = 0
@@ -260,6 +261,29 @@ class TrainStep:
         if bucket is None or starts != sorted(starts) or len(set(starts)) != len(starts):
             return None
         bounds = [0] + starts + [bucket.numel()]
+        # EVERY parameter a segment back-propagates must lie inside that segment's range (an optimizer group built in another
+        # order than the module tree would otherwise have a range reduced before the segment that fills it has replayed):
+        # children of the feature extractor in front of the first cut block -> the last segment (range 0), a cut block and what
+        # follows it up to the next cut -> its own range, everything outside the backbone (heads, spot branch) -> the tail range
+        seg_of = {}
+        k = 0
+        cut_names = [f"denseblock{i}" for i in range(first_cut_block, last_block + 1)]
+        for name, child in feats.named_children():
+            if name in cut_names:
+                k = cut_names.index(name) + 1
+            for p in child.parameters():
+                seg_of[id(p)] = k
+        tail = len(bounds) - 2
+        for group in self.opt.param_groups:
+            for p in group["params"]:
+                loc = self.opt.flat_location(p)
+                if loc is None:
+                    continue
+                if loc[0] != gi:
+                    return None
+                kk = seg_of.get(id(p), tail)
+                if not (bounds[kk] <= loc[1] and loc[1] + p.numel() <= bounds[kk + 1]):
+                    return None
         return [(bucket, bounds[k], bounds[k + 1]) for k in range(len(bounds) - 2, -1, -1)]
 
     def _replay_backward_dp(self) -> None:
@@ -337,15 +361,16 @@ class TrainStep:
         if self.reducer is None:
             return True
         if self.equal_shards:
-            # the caller promised equal per-rank batches: a different size on ONE rank would send the ranks down different
-            # paths (replay vs eager) with mismatched collective shapes -- a hang or silently wrong gathered embeddings.
-            # It cannot be detected across ranks without the exchange that equal_shards switches off, so it is an error here.
+            # the caller promised that every rank sees the SAME per-rank batch size on every step (a different size on ONE rank
+            # would send the ranks down different paths with mismatched collective shapes; it cannot be detected across ranks
+            # without the exchange this flag switches off).  A size that differs from the captured one -- a uniformly smaller last
+            # batch without drop_last -- takes the eager path on every rank; ``strict_shards`` turns it into an error instead.
             n = int(batch["expression"].shape[0])
             if self._first_size is None:
                 self._first_size = n
-            elif n != self._first_size:
-                raise RuntimeError(f"TrainStep(equal_shards=True): this step's per-rank batch has {n} pairs, the first one had "
-                                   f"{self._first_size}; use drop_last / equal shards, or equal_shards=False (host size exchange)")
+            elif n != self._first_size and self.strict_shards:
+                raise RuntimeError(f"TrainStep(equal_shards=True, strict_shards=True): this step's per-rank batch has {n} pairs, "
+                                   f"the first one had {self._first_size}")
             self._all_regular = (self.static_in is not None
                                  and batch["expression"].shape[0] == self.static_in["expression"].shape[0])
             return True

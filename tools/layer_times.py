@@ -10,8 +10,8 @@ import sys
 db, subs = sys.argv[1], sys.argv[2:]
 c = sqlite3.connect(db)
 rows = c.execute('select name, start, "end" from kernels order by start').fetchall()
-marks = [i for i, r in enumerate(rows) if "adam_table_kernel" in r[0]]
-lo, hi = marks[-3], marks[-1]            # the last complete step (two table launches per step)
+marks = [i for i, r in enumerate(rows) if "adam_consts_kernel" in r[0]]
+lo, hi = marks[-2], marks[-1]            # one complete step (one adam_consts_kernel launch per step)
 step = rows[lo + 1: hi + 1]
 print(f"step wall {(step[-1][2] - step[0][1]) / 1e3:.1f} us, {len(step)} launches")
 for s in subs:

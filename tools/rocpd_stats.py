@@ -25,8 +25,8 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--steady", type=int, default=None)
-    ap.add_argument("--marker", default="adam_table_kernel")
-    ap.add_argument("--per_step", type=int, default=2, help="marker launches per step")
+    ap.add_argument("--marker", default="adam_consts_kernel")
+    ap.add_argument("--per_step", type=int, default=1, help="marker launches per step")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     rows = c.execute('select name, start, "end" from kernels order by start').fetchall()

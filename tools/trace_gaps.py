@@ -10,8 +10,8 @@ db = sys.argv[1]
 K = int(sys.argv[sys.argv.index("--steady") + 1]) if "--steady" in sys.argv else 6
 c = sqlite3.connect(db)
 rows = c.execute('select name, start, "end" from kernels order by start').fetchall()
-marks = [i for i, r in enumerate(rows) if "adam_table_kernel" in r[0]]
-i0, i1 = marks[-2 * K - 1] + 1, marks[-1] + 1
+marks = [i for i, r in enumerate(rows) if "adam_consts_kernel" in r[0]]
+i0, i1 = marks[-K - 1] + 1, marks[-1] + 1
 rows = rows[i0:i1]
 t0, t1 = rows[0][1], max(r[2] for r in rows)
 busy_end = rows[0][1]
