@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 6
+#define MCL_ABI_VERSION 7
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -125,6 +125,14 @@ int mcl_attention_fwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, in
 int mcl_attention_bwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale, const float* out,
                       const float* dout, int64_t ldo, const float* lse, float* dvec, float* dqkv, int64_t ldq,
                       mcl_stream_t stream);
+/* The same core over nseq independent sequences of B tokens each (ABI 7): rows sequence-major, lse / dvec (nseq, heads, B).
+ * The fp32 ("reference numerics") ViT image encoder runs it with one sequence per image (/root/reference/model.py:104-116:
+ * timm's Attention inside vit_base_patch{16,32}_224, T = 197 / 50 tokens). */
+int mcl_attention_batched_fwd(const float* qkv, int64_t ld, int32_t B, int32_t nseq, int32_t heads, int32_t dim_head, float scale,
+                              float* out, int64_t ldo, float* lse, mcl_stream_t stream);
+int mcl_attention_batched_bwd(const float* qkv, int64_t ld, int32_t B, int32_t nseq, int32_t heads, int32_t dim_head, float scale,
+                              const float* out, const float* dout, int64_t ldo, const float* lse, float* dvec, float* dqkv,
+                              int64_t ldq, mcl_stream_t stream);
 /* ---------------------------------------------------------------- K4 attention softmax (model.py:53-54)
  * In place over n_rows rows of length cols (row stride ld):  p = softmax(scale * s).           */
 int mcl_softmax_rows_fwd(float* s, int64_t ld, int32_t n_rows, int32_t cols, float scale, mcl_stream_t stream);

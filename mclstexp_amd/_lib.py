@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib: Optional[C.CDLL] = None
 
@@ -62,6 +62,8 @@ PROTOTYPES = {
     "mcl_layernorm_bwd": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p],
     "mcl_attention_fwd": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
     "mcl_attention_bwd": [c_p, c_l, c_i, c_i, c_i, c_f, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p],
+    "mcl_attention_batched_fwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_p],
+    "mcl_attention_batched_bwd": [c_p, c_l, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p],
     "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],

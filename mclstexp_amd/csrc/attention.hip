@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ out, long long ldo, float* __restrict__ lse) {
   __shared__ float Ss[32 * LP];
   __shared__ float alpha_s[32], linv_s[32];
+  {                                                        // sequence blockIdx.z of a batch of independent sequences
+    const long long sq = blockIdx.z;
+    qkv += sq * Bn * ld;
+    out += sq * Bn * ldo;
+    lse += sq * heads * Bn;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, kk = lane >> 5;
   const int q0 = blockIdx.x * 32, hd = blockIdx.y, inner = heads * AD;
@@ -151,6 +157,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                                                           float* __restrict__ dqkv, long long ldq) {
   __shared__ float Ss[32 * LP];
   __shared__ float lse_s[32], d_s[32];
+  {
+    const long long sq = blockIdx.z;
+    qkv += sq * Bn * ld;
+    out += sq * Bn * ldo;
+    dout += sq * Bn * ldo;
+    lse += sq * heads * Bn;
+    dvec += sq * heads * Bn;
+    dqkv += sq * Bn * ldq;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, kk = lane >> 5;
   const int q0 = blockIdx.x * 32, hd = blockIdx.y, inner = heads * AD;
@@ -206,6 +221,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                                                            float* __restrict__ dqkv, long long ldq) {
   __shared__ float Ps[32 * LP];
   __shared__ float Ds[32 * LP];
+  {
+    const long long sq = blockIdx.z;
+    qkv += sq * Bn * ld;
+    dout += sq * Bn * ldo;
+    lse += sq * heads * Bn;
+    dvec += sq * heads * Bn;
+    dqkv += sq * Bn * ldq;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, kk = lane >> 5;
   const int j0 = blockIdx.x * 32, hd = blockIdx.y, inner = heads * AD;
@@ -250,32 +273,43 @@ inline bool attn_args_ok(const void* a, const void* b, int64_t ld, int64_t ldo, 
 }  // namespace
 
 // out (B, heads*64) = attention core of qkv (B, 3*heads*64; q | k | v, head-major inside each), lse (heads, B) fp32.
-extern "C" int mcl_attention_fwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale, float* out,
-                                 int64_t ldo, float* lse, mcl_stream_t stream) {
+// nseq > 1: nseq independent sequences of B tokens each, rows sequence-major (the fp32 ViT: one sequence per image,
+// /root/reference/model.py:104-116); lse / dvec are (nseq, heads, B).
+extern "C" int mcl_attention_batched_fwd(const float* qkv, int64_t ld, int32_t B, int32_t nseq, int32_t heads, int32_t dim_head,
+                                         float scale, float* out, int64_t ldo, float* lse, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!qkv || !out || !lse || B <= 0 || heads <= 0) return MCL_EINVAL;
-  if (!attn_args_ok(qkv, out, ld, ldo, B, heads, dim_head)) return MCL_EUNSUPPORTED;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((B + 31) / 32, heads), dim3(256), 0, mcl_stream(stream), qkv, (long long)ld, B, heads,
-                     scale, out, (long long)ldo, lse);
+  if (!qkv || !out || !lse || B <= 0 || heads <= 0 || nseq <= 0) return MCL_EINVAL;
+  if (!attn_args_ok(qkv, out, ld, ldo, B, heads, dim_head) || nseq > 65535) return MCL_EUNSUPPORTED;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((B + 31) / 32, heads, nseq), dim3(256), 0, mcl_stream(stream), qkv, (long long)ld, B,
+                     heads, scale, out, (long long)ldo, lse);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }
+extern "C" int mcl_attention_fwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale, float* out,
+                                 int64_t ldo, float* lse, mcl_stream_t stream) {
+  return mcl_attention_batched_fwd(qkv, ld, B, 1, heads, dim_head, scale, out, ldo, lse, stream);
+}
 
 // dqkv (B, 3*heads*64, row stride ldq) from dout, qkv, out and lse of the forward; dvec: (heads, B) fp32 scratch.
-extern "C" int mcl_attention_bwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale,
-                                 const float* out, const float* dout, int64_t ldo, const float* lse, float* dvec, float* dqkv,
-                                 int64_t ldq, mcl_stream_t stream) {
+extern "C" int mcl_attention_batched_bwd(const float* qkv, int64_t ld, int32_t B, int32_t nseq, int32_t heads, int32_t dim_head,
+                                         float scale, const float* out, const float* dout, int64_t ldo, const float* lse,
+                                         float* dvec, float* dqkv, int64_t ldq, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!qkv || !out || !dout || !lse || !dvec || !dqkv || B <= 0 || heads <= 0) return MCL_EINVAL;
+  if (!qkv || !out || !dout || !lse || !dvec || !dqkv || B <= 0 || heads <= 0 || nseq <= 0) return MCL_EINVAL;
   if (!attn_args_ok(qkv, out, ld, ldo, B, heads, dim_head) || (reinterpret_cast<uintptr_t>(dout) & 15u) ||
-      ldq < 3LL * heads * AD)
+      ldq < 3LL * heads * AD || nseq > 65535)
     return MCL_EUNSUPPORTED;
   hipStream_t st = mcl_stream(stream);
-  const dim3 grid((B + 31) / 32, heads);
+  const dim3 grid((B + 31) / 32, heads, nseq);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, qkv, (long long)ld, B, heads, scale, out, dout, (long long)ldo, lse,
                      dvec, dqkv, (long long)ldq);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, st, qkv, (long long)ld, B, heads, scale, dout, (long long)ldo, lse, dvec,
                      dqkv, (long long)ldq);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
+}
+extern "C" int mcl_attention_bwd(const float* qkv, int64_t ld, int32_t B, int32_t heads, int32_t dim_head, float scale,
+                                 const float* out, const float* dout, int64_t ldo, const float* lse, float* dvec, float* dqkv,
+                                 int64_t ldq, mcl_stream_t stream) {
+  return mcl_attention_batched_bwd(qkv, ld, B, 1, heads, dim_head, scale, out, dout, ldo, lse, dvec, dqkv, ldq, stream);
 }

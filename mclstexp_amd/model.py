@@ -265,11 +265,13 @@ class _ContrastiveBase(nn.Module):
                                    "inference in torch.no_grad()")
             return encoder.forward_fused(image, self.backbone_dtype or torch.float32)
         if self.fused_backbone and isinstance(encoder, backbones.ImageEncoder_VIT) and image.is_cuda:
+            if self.backbone_dtype is None or self.backbone_dtype == torch.float32:
+                # "reference numerics": the whole encoder in fp32 on mcl_gemm (exact-fp32 MFMA), the fp32 LayerNorm / GELU
+                # kernels and the fp32 attention core (csrc/attention.hip, one sequence per image)
+                from .vit_fused import vit_features_fp32
+                return vit_features_fp32(encoder.model, image)
             if self.backbone_dtype != torch.bfloat16:
-                # no silent detour through the stock modules (SDPA / ATen): the ViT runs on this library's bf16 kernels only
-                raise RuntimeError("the ViT image encoder runs on the hand-written bf16 kernels: construct the model with "
-                                   "backbone_dtype=torch.bfloat16 (an fp32 ViT path on own kernels does not exist; fused_backbone="
-                                   "False selects the plain torch modules explicitly)")
+                raise RuntimeError(f"the ViT image encoder runs in bf16 or fp32 (backbone_dtype={self.backbone_dtype})")
             from .vit_fused import vit_features_fused           # ViT on the hand-written bf16 kernels (csrc/gemm_bf16.hip)
             return vit_features_fused(encoder.model, image)
         if self.fused_backbone and image.is_cuda and isinstance(encoder, tuple(backbones.ENCODERS.values())):

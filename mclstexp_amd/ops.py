@@ -33,6 +33,25 @@ def get_compute() -> str:
     return "bf16" if _compute_mode == COMPUTE_BF16 else "f32"
 
 
+class forced_compute:
+    """``with forced_compute(COMPUTE_F32):`` -- every mcl_gemm inside runs in that mode whatever set_compute() says (the fp32
+    "reference numerics" image encoders: /root/reference/model.py:104-116 computes in fp32)."""
+
+    def __init__(self, mode: Optional[int]):
+        self.mode = mode
+
+    def __enter__(self):
+        global _compute_mode
+        self.old = _compute_mode
+        if self.mode is not None:
+            _compute_mode = self.mode
+
+    def __exit__(self, *exc):
+        global _compute_mode
+        _compute_mode = self.old
+        return False
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -132,6 +151,8 @@ DIRECT_PARAM_GRADS = True
 def _direct_grad_ok(p) -> bool:
     """Pure predicate (this path never creates a .grad).  A parameter with tensor / post-accumulate-grad hooks is excluded:
     the hooks fire from autograd's AccumulateGrad node, which a kernel-side accumulation never reaches."""
+    if not getattr(p, "is_leaf", True):       # a view of a parameter (reshaped patch-embedding weight): autograd routes it
+        return False
     g = getattr(p, "grad", None)
     if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
         return False
@@ -231,34 +252,42 @@ def _attention_fusable(qkv: Tensor, dim_head: int) -> bool:
             and qkv.data_ptr() % 16 == 0)
 
 
-def attention_core_fwd(qkv: Tensor, heads: int, dim_head: int) -> Tuple[Tensor, Tensor]:
+def attention_core_fwd(qkv: Tensor, heads: int, dim_head: int, nseq: int = 1) -> Tuple[Tensor, Tensor]:
     """model.py:52-56 on the (B, 3*h*d) to_qkv output: returns (out (B, h*d), aux) where aux is what the backward needs:
     the row log-sum-exp (h, B) of the fused kernel (csrc/attention.hip: head dimension 64, no (h, B, B) tensor in HBM), or
-    the probabilities P (h, B, B) of the GEMM + softmax sequence (any head dimension, unaligned views)."""
+    the probabilities P (h, B, B) of the GEMM + softmax sequence (any head dimension, unaligned views).
+    ``nseq`` > 1: the rows are nseq independent sequences of B / nseq tokens (the fp32 ViT, one sequence per image; fused
+    kernel only)."""
     if _attention_fusable(qkv, dim_head):
-        B, inner = qkv.shape[0], heads * dim_head
-        out = torch.empty((B, inner), device=qkv.device, dtype=torch.float32)
-        lse = torch.empty((heads, B), device=qkv.device, dtype=torch.float32)
-        check(_lib.lib().mcl_attention_fwd(qkv.data_ptr(), qkv.stride(0), B, heads, dim_head, dim_head ** -0.5, out.data_ptr(),
-                                           inner, lse.data_ptr(), _stream()), "mcl_attention_fwd")
+        rows, inner = qkv.shape[0], heads * dim_head
+        if rows % nseq:
+            raise RuntimeError(f"attention: {rows} rows are not {nseq} sequences")
+        T = rows // nseq
+        out = torch.empty((rows, inner), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((nseq * heads, T), device=qkv.device, dtype=torch.float32)
+        check(_lib.lib().mcl_attention_batched_fwd(qkv.data_ptr(), qkv.stride(0), T, nseq, heads, dim_head, dim_head ** -0.5,
+                                                   out.data_ptr(), inner, lse.data_ptr(), _stream()), "mcl_attention_batched_fwd")
         return out, lse
+    if nseq != 1:
+        raise RuntimeError("attention: several sequences need the fused kernel (head dimension 64, fp32, aligned rows)")
     return attention_core_fwd_unfused(qkv, heads, dim_head)
 
 
-def attention_core_bwd(dout: Tensor, qkv: Tensor, out: Tensor, aux: Tensor, heads: int, dim_head: int) -> Tensor:
+def attention_core_bwd(dout: Tensor, qkv: Tensor, out: Tensor, aux: Tensor, heads: int, dim_head: int, nseq: int = 1) -> Tensor:
     """Returns dqkv (B, 3*h*d); ``aux`` as returned by attention_core_fwd."""
     if aux.dim() == 3:
         return attention_core_bwd_unfused(dout, qkv, aux, heads, dim_head)
-    B, inner = qkv.shape[0], heads * dim_head
+    rows, inner = qkv.shape[0], heads * dim_head
+    T = rows // nseq
     dout = _rowmajor(dout, "dout")
     if dout.data_ptr() % 16 or dout.stride(0) != inner or out.stride(0) != inner:
         dout = dout.contiguous()
         out = out.contiguous()
-    dqkv = torch.empty((B, 3 * inner), device=qkv.device, dtype=torch.float32)
-    dvec = torch.empty((heads, B), device=qkv.device, dtype=torch.float32)
-    check(_lib.lib().mcl_attention_bwd(qkv.data_ptr(), qkv.stride(0), B, heads, dim_head, dim_head ** -0.5, out.data_ptr(),
-                                       dout.data_ptr(), inner, aux.data_ptr(), dvec.data_ptr(), dqkv.data_ptr(), 3 * inner,
-                                       _stream()), "mcl_attention_bwd")
+    dqkv = torch.empty((rows, 3 * inner), device=qkv.device, dtype=torch.float32)
+    dvec = torch.empty((nseq * heads, T), device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().mcl_attention_batched_bwd(qkv.data_ptr(), qkv.stride(0), T, nseq, heads, dim_head, dim_head ** -0.5,
+                                               out.data_ptr(), dout.data_ptr(), inner, aux.data_ptr(), dvec.data_ptr(),
+                                               dqkv.data_ptr(), 3 * inner, _stream()), "mcl_attention_batched_bwd")
     return dqkv
 
 
@@ -302,49 +331,80 @@ def attention_core_bwd_unfused(dout: Tensor, qkv: Tensor, P: Tensor, heads: int,
 
 # --------------------------------------------------------------------------- attn_block (model.py:60-69)
 class AttnBlockFn(torch.autograd.Function):
-    """One spot-Transformer layer over the batch-as-sequence:
+    """One pre-norm Transformer layer:
         x1 = to_out(attn(LN1(x))) + x ;  x2 = W2 gelu(W1 LN2(x1) + b1) + b2 + x1
-    model.py:66-69 (PreNorm 17, Attention 49-57, FeedForward 31-32; both dropouts p=0)."""
+    The spot Transformer over the batch-as-sequence, model.py:66-69 (PreNorm 17, Attention 49-57, FeedForward 31-32; both
+    dropouts p=0): ``bqkv`` None, one sequence.  The same arithmetic is a timm ViT block (model.py:104-116; qkv bias, LayerNorm
+    eps 1e-6, one sequence per image): ``bqkv`` given, ``nseq`` = images, ``compute`` pins the GEMM mode (fp32)."""
 
     @staticmethod
-    def forward(ctx, x, g1, be1, wqkv, wo, bo, g2, be2, w1, b1, w2, b2, heads, dim_head):
-        x = _rowmajor(x, "x")
-        u1, mean1, rstd1 = layernorm_fwd(x, g1, be1)
-        qkv, _ = linear_fwd(u1, wqkv)
-        o, P = attention_core_fwd(qkv, heads, dim_head)
-        x1, _ = linear_fwd(o, wo, bo, resid=x)
-        u2, mean2, rstd2 = layernorm_fwd(x1, g2, be2)
-        h, pre = linear_fwd(u2, w1, b1, gelu=True, save_pre=True)
-        x2, _ = linear_fwd(h, w2, b2, resid=x1)
+    def forward(ctx, x, g1, be1, wqkv, wo, bo, g2, be2, w1, b1, w2, b2, heads, dim_head, bqkv=None, nseq=1, eps=LN_EPS,
+                compute=None):
+        with forced_compute(compute):
+            x = _rowmajor(x, "x")
+            u1, mean1, rstd1 = layernorm_fwd(x, g1, be1, eps)
+            qkv, _ = linear_fwd(u1, wqkv, bqkv)
+            o, P = attention_core_fwd(qkv, heads, dim_head, nseq)
+            x1, _ = linear_fwd(o, wo, bo, resid=x)
+            u2, mean2, rstd2 = layernorm_fwd(x1, g2, be2, eps)
+            h, pre = linear_fwd(u2, w1, b1, gelu=True, save_pre=True)
+            x2, _ = linear_fwd(h, w2, b2, resid=x1)
         ctx.save_for_backward(x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h)
-        ctx.heads, ctx.dim_head = heads, dim_head
+        ctx.heads, ctx.dim_head, ctx.nseq, ctx.compute = heads, dim_head, nseq, compute
         ctx.wparams = (wqkv, wo, w1, w2)   # the Parameter objects themselves: their .grad may be written directly
-        ctx.bparams = (bo, b1, b2, g1, be1, g2, be2)
+        ctx.bparams = (bo, b1, b2, g1, be1, g2, be2, bqkv)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
         (x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h) = ctx.saved_tensors
-        dx2 = _rowmajor(dx2, "dx2")
-        # ff: x2 = h W2^T + b2 + x1
         p_qkv, p_o, p_1, p_2 = ctx.wparams
-        q_bo, q_b1, q_b2, q_g1, q_be1, q_g2, q_be2 = ctx.bparams
-        dw2 = linear_bwd_weight(dx2, h, p_2)
-        db2 = colsum(dx2, q_b2)
-        dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
-        dw1 = linear_bwd_weight(dpre, u2, p_1)
-        db1 = colsum(dpre, q_b1)
-        du2 = linear_bwd_data(dpre, w1)
-        dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2, params=(q_g2, q_be2))
-        # attn: x1 = o Wo^T + bo + x
-        dwo = linear_bwd_weight(dx1, o, p_o)
-        dbo = colsum(dx1, q_bo)
-        do = linear_bwd_data(dx1, wo)
-        dqkv = attention_core_bwd(do, qkv, o, P, ctx.heads, ctx.dim_head)
-        dwqkv = linear_bwd_weight(dqkv, u1, p_qkv)
-        du1 = linear_bwd_data(dqkv, wqkv)
-        dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, params=(q_g1, q_be1))
-        return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None
+        q_bo, q_b1, q_b2, q_g1, q_be1, q_g2, q_be2, q_bqkv = ctx.bparams
+        with forced_compute(ctx.compute):
+            dx2 = _rowmajor(dx2, "dx2")
+            # ff: x2 = h W2^T + b2 + x1
+            dw2 = linear_bwd_weight(dx2, h, p_2)
+            db2 = colsum(dx2, q_b2)
+            dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
+            dw1 = linear_bwd_weight(dpre, u2, p_1)
+            db1 = colsum(dpre, q_b1)
+            du2 = linear_bwd_data(dpre, w1)
+            dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2, params=(q_g2, q_be2))
+            # attn: x1 = o Wo^T + bo + x
+            dwo = linear_bwd_weight(dx1, o, p_o)
+            dbo = colsum(dx1, q_bo)
+            do = linear_bwd_data(dx1, wo)
+            dqkv = attention_core_bwd(do, qkv, o, P, ctx.heads, ctx.dim_head, ctx.nseq)
+            dwqkv = linear_bwd_weight(dqkv, u1, p_qkv)
+            dbqkv = colsum(dqkv, q_bqkv) if q_bqkv is not None else None
+            du1 = linear_bwd_data(dqkv, wqkv)
+            dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, params=(q_g1, q_be1))
+        return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None, dbqkv, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b over 2-D rows (the fp32 ViT's patch embedding: timm PatchEmbed's stride-p convolution is this product on
+    the unfolded patches, model.py:104-116)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, compute=None):
+        with forced_compute(compute):
+            y, _ = linear_fwd(_rowmajor(x, "x"), w, b)
+        ctx.save_for_backward(x, w)
+        ctx.params = (w, b)
+        ctx.compute = compute
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        pw, pb = ctx.params
+        with forced_compute(ctx.compute):
+            dy = _rowmajor(dy, "dy")
+            dw = linear_bwd_weight(dy, x, pw)
+            db = colsum(dy, pb) if pb is not None else None
+            dx = linear_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
 
 
 # --------------------------------------------------------------------------- ProjectionHead (model.py:151-168)

@@ -305,6 +305,40 @@ class ViTFn(torch.autograd.Function):
         return (None, None, *[grads.get(prm) for prm in _param_list(vit)])
 
 
+def vit_features_fp32(vit, image: Tensor) -> Tensor:
+    """``VisionTransformer.forward`` in fp32 ("reference numerics": /root/reference/model.py:104-116 computes in fp32) on this
+    library's fp32 kernels: every contraction is ``mcl_gemm`` in exact-fp32 MFMA mode, LayerNorm / GELU / bias gradients the
+    spot branch's kernels, the attention core csrc/attention.hip with one sequence per image (no (B, heads, T, T) tensor).
+    Token assembly (unfold of the patches, class token, position embedding, final token mean) stays a handful of elementwise
+    torch ops, differentiated by autograd.  (B, D) fp32."""
+    if not image.is_cuda:
+        raise RuntimeError("vit_features_fp32: input is on the CPU; the ViT kernels are GPU-only")
+    F32 = _lib.COMPUTE_F32
+    pe = vit.patch_embed.proj
+    p = pe.kernel_size[0]
+    B, Cin, H, W = image.shape
+    nph, npw = H // p, W // p
+    npatch, T = nph * npw, nph * npw + 1
+    D = pe.out_channels
+    heads = vit.blocks[0].attn.num_heads
+    dh = D // heads
+    if dh != 64:
+        raise RuntimeError(f"vit_features_fp32: head dimension {dh} (the fp32 attention kernel is built for 64)")
+    img = image.float()
+    # (B, npatch, c*p*p) with timm's (c, iy, ix) order inside a patch: one strided copy
+    patches = img.reshape(B, Cin, nph, p, npw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * npatch, Cin * p * p)
+    tok = ops.LinearFn.apply(patches, pe.weight.reshape(D, Cin * p * p), pe.bias, F32).view(B, npatch, D)
+    x = torch.cat([vit.cls_token.expand(B, 1, D), tok], dim=1) + vit.pos_embed
+    x = x.reshape(B * T, D)
+    for blk in vit.blocks:
+        a, m = blk.attn, blk.mlp
+        x = ops.AttnBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.proj.weight, a.proj.bias,
+                                  blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                  heads, dh, a.qkv.bias, B, float(blk.norm1.eps), F32)
+    feat = x.view(B, T, D)[:, 1:].mean(dim=1)                      # global_pool='avg' over the patch tokens
+    return ops.LayerNormFn.apply(feat, vit.fc_norm.weight, vit.fc_norm.bias, vit.fc_norm.eps)
+
+
 def _param_list(vit) -> List[Tensor]:
     """The encoder's trainable parameters in module order, without fc_norm (which runs outside ViTFn)."""
     skip = {id(vit.fc_norm.weight), id(vit.fc_norm.bias)}

@@ -297,3 +297,62 @@ def test_vit_fused_matches_fp64_module(name, B, fused_attn, monkeypatch):
           f"({names[int(devs.argmax())]})")
     assert err <= 3e-2, err
     assert np.median(devs) <= 3e-2 and devs.max() <= 0.25, (np.median(devs), devs.max(), names[int(devs.argmax())])
+
+
+@pytest.mark.parametrize("name,B", [("vit_base_patch32_224", 5), ("vit_base_patch16_224", 2)])
+def test_vit_fp32_matches_fp64_module(name, B):
+    """The fp32 ("reference numerics", /root/reference/model.py:104-116) encoder on this library's fp32 kernels -- mcl_gemm in
+    exact-fp32 MFMA mode, fp32 LayerNorm / GELU, the fp32 attention core with one sequence per image -- forward + backward vs an
+    fp64 run of the same module: 2e-5 of max on the features, 2e-4 on every parameter gradient (fp32 rounding only)."""
+    from mclstexp_amd.backbones import ImageEncoder_VIT
+    from mclstexp_amd.vit_fused import vit_features_fp32
+    torch.manual_seed(0)
+    enc = ImageEncoder_VIT(name)
+    with torch.no_grad():
+        for p in enc.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    x = _r(B, 3, 224, 224, seed=5).abs().to(DEV)
+    dy = _r(B, 768, seed=6).to(DEV)
+    ref64 = copy.deepcopy(enc).double().to(DEV).train()
+    y64 = ref64(x.double())
+    y64.backward(dy.double())
+    own = copy.deepcopy(enc).to(DEV).train()
+    y = vit_features_fp32(own.model, x)
+    y.backward(dy)
+    err = ((y.double() - y64).abs().max() / y64.abs().max()).item()
+    devs, names = [], []
+    for (n, p64), (_, q) in zip(ref64.named_parameters(), own.named_parameters()):
+        assert q.grad is not None, n
+        devs.append(((q.grad.double() - p64.grad).abs().max() / (p64.grad.abs().max() + 1e-30)).item())
+        names.append(n)
+    devs = np.array(devs)
+    print(f"{name} B={B} fp32: feature err {err:.2e}; grad rel-dev median {np.median(devs):.2e} max {devs.max():.2e} "
+          f"({names[int(devs.argmax())]})")
+    assert err <= 2e-5, err
+    assert devs.max() <= 2e-4, (devs.max(), names[int(devs.argmax())])
+
+
+def test_vit_fp32_selector_and_direct_grads():
+    """mclSTExp_Attention('vit', backbone_dtype=None) takes the fp32 own-kernel path in train and eval mode, and with dense
+    .grad tensors present (FusedAdam's bucket) the gradients accumulate in place to the same values."""
+    from mclstexp_amd.model import mclSTExp_Attention
+    torch.manual_seed(0)
+    m = mclSTExp_Attention("vit", 1.0, 768, 171, 256, 8, 64, 2, backbone_dtype=None).to(DEV).train()
+    x = _r(3, 3, 224, 224, seed=9).abs().to(DEV)
+    seed = _r(3, 768, seed=10).to(DEV)
+    enc = m.image_encoder if hasattr(m, "image_encoder") else m.image_ecode
+    m.encode_image(x).backward(seed)
+    g1 = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    for p in enc.parameters():
+        p.grad.zero_()                                     # dense .grad present: the kernels add straight into it
+    m.encode_image(x).backward(seed)
+    for n, p in enc.named_parameters():
+        assert torch.allclose(p.grad, g1[n], rtol=1e-5, atol=1e-6 * float(g1[n].abs().max()) + 1e-12), n
+    m.eval()
+    with torch.no_grad():
+        y_eval = m.encode_image(x)
+    m.train()
+    with torch.no_grad():
+        y_train = m.encode_image(x)
+    assert torch.equal(y_eval, y_train)                    # no dropout / BatchNorm in the encoder: same arithmetic
