@@ -143,6 +143,15 @@ int mcl_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int32_t n_rows, 
 /* ---------------------------------------------------------------- bias gradient
  * out[n] = sum_m x[m,n]  (nn.Linear bias backward).                                           */
 int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate, mcl_stream_t stream);
+/* ABI 7: the two column reductions above for MANY rows (the fp32 ViT's 6 400 - 25 216 token rows).  With a workspace of
+ * mcl_rowred_workspace_floats(rows, cols) floats and rows > 1024 the rows are reduced in 128-row chunks on a 2-D grid and the
+ * chunk partials added in chunk order by a second launch (deterministic); otherwise exactly the calls above. */
+int64_t mcl_rowred_workspace_floats(int32_t rows, int32_t cols);
+int mcl_colsum_ws(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate, float* workspace,
+                  mcl_stream_t stream);
+int mcl_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                         const float* rstd, const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma,
+                         float* dbeta, int32_t accumulate_params, int32_t rows, int32_t cols, float* workspace, mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- K8 symmetric InfoNCE (model.py:242-247)
  * Works on a logits strip S (R x C, already divided by T): this rank's rows are global rows

@@ -67,6 +67,9 @@ PROTOTYPES = {
     "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "mcl_colsum_ws": [c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p],
+    "mcl_rowred_workspace_floats": [c_i, c_i],
+    "mcl_layernorm_bwd_ws": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_lse": [c_p, c_l, c_i, c_i, c_p, c_p, c_p],
     "mcl_infonce_loss": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "mcl_infonce_dlogits": [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
@@ -179,7 +182,7 @@ _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_dense_block_fwd_workspace_byte
              "mcl_wrw_workspace_floats": C.c_int64, "mcl_dense_conv3x3_wrw_workspace_floats": C.c_int64,
              "mcl_conv0_wrw_workspace_floats": C.c_int64, "mcl_infonce_fp8_workspace_bytes": C.c_int64,
              "mcl_gemm_bf16_workspace_floats": C.c_int64, "mcl_colred_workspace_floats": C.c_int64,
-             "mcl_gemm_workspace_floats": C.c_int64}
+             "mcl_gemm_workspace_floats": C.c_int64, "mcl_rowred_workspace_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

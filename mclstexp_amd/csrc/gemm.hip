@@ -12,10 +12,11 @@
 // (contiguous along K, or along M/N), vectorised to 16-byte loads when base and leading dimension
 // allow and falling back to dword loads for the odd gene counts (785, 171, 685, 3467).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32, LDT = 65, NT = 256;
+constexpr int BM = 64, BN = 64, BK = 32, NT = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -80,7 +81,7 @@ __device__ __forceinline__ void load_slice(float (&reg)[8], const float* __restr
 }
 
 // Write the staged registers into the LDS slice T[k][r] (row stride LDT words).
-template <bool KC>
+template <bool KC, int LDT>
 __device__ __forceinline__ void store_slice(const float (&reg)[8], float* __restrict__ T, int tid) {
   if (KC) {
 #pragma unroll
@@ -99,91 +100,127 @@ __device__ __forceinline__ void store_slice(const float (&reg)[8], float* __rest
   }
 }
 
-template <bool AKC, bool BKC, bool VEC, bool BF16>
+// TM = 1: the 64 x 64 tile (each wave one 32 x 32 block).  TM = 2: a 128 x 128 tile for problems with many tiles (the fp32
+// "reference numerics" image encoders: M = 25 216 token rows, im2col rows of the generic convolutions) -- each wave a 64 x 64 block as
+// 2 x 2 MFMA tiles: two A and two B operand reads feed four products, and a tile's operand traffic per flop halves (the 64 x 64
+// form asks L2 for 16 KB per 262 kflop: ~10 TB/s with every CU busy).
+template <bool AKC, bool BKC, bool VEC, bool BF16, int TM>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
-  __shared__ float As[BK * LDT];
-  __shared__ float Bs[BK * LDT];
+  constexpr int BMT = BM * TM, BNT = BN * TM, LD = BMT + 1;
+  __shared__ float As[BK * LD];
+  __shared__ float Bs[BK * LD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BMT, n0 = blockIdx.x * BNT;
   const int bz = blockIdx.z % p.batch, ksl = blockIdx.z / p.batch;
   const int kbeg = ksl * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   const float* __restrict__ A = p.A + (long long)bz * p.sAb;
   const float* __restrict__ B = p.B + (long long)bz * p.sBb;
 
-  f32x16 acc;
+  f32x16 acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  float ra[8], rb[8];
+  float ra[TM][8], rb[TM][8];
   const int nk = (kend - kbeg + BK - 1) / BK;
-  load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, kbeg, p.M, kend, tid);
-  load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, kbeg, p.N, kend, tid);
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    load_slice<AKC, VEC>(ra[t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg, p.M, kend, tid);
+    load_slice<BKC, VEC>(rb[t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg, p.N, kend, tid);
+  }
 
-  const int arow = wm * 32 + (lane & 31);
-  const int brow = wn * 32 + (lane & 31);
+  const int arow = wm * 32 * TM + (lane & 31);
+  const int brow = wn * 32 * TM + (lane & 31);
   const int khalf = lane >> 5;
 
   for (int kt = 0; kt < nk; ++kt) {
-    store_slice<AKC>(ra, As, tid);
-    store_slice<BKC>(rb, Bs, tid);
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      store_slice<AKC, LD>(ra[t], As + 64 * t, tid);
+      store_slice<BKC, LD>(rb[t], Bs + 64 * t, tid);
+    }
     __syncthreads();
     if (kt + 1 < nk) {
-      load_slice<AKC, VEC>(ra, A, p.sAm, p.sAk, m0, kbeg + (kt + 1) * BK, p.M, kend, tid);
-      load_slice<BKC, VEC>(rb, B, p.sBn, p.sBk, n0, kbeg + (kt + 1) * BK, p.N, kend, tid);
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        load_slice<AKC, VEC>(ra[t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + (kt + 1) * BK, p.M, kend, tid);
+        load_slice<BKC, VEC>(rb[t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + (kt + 1) * BK, p.N, kend, tid);
+      }
     }
     if (!BF16) {
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 2) {
-        const float a = As[(ks + khalf) * LDT + arow];
-        const float b = Bs[(ks + khalf) * LDT + brow];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        float a[TM], b[TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          a[t] = As[(ks + khalf) * LD + arow + 32 * t];
+          b[t] = Bs[(ks + khalf) * LD + brow + 32 * t];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     } else {
       // 32x32x16 bf16: lane l holds A[i = l&31][k = 8*(l>>5) .. +7] (8 consecutive k)
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 16) {
-        bf16x8 a, b;
+        bf16x8 a[TM], b[TM];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          a[i] = (short)f2bf(As[(ks + khalf * 8 + i) * LDT + arow]);
-          b[i] = (short)f2bf(Bs[(ks + khalf * 8 + i) * LDT + brow]);
-        }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a[t][i] = (short)f2bf(As[(ks + khalf * 8 + i) * LD + arow + 32 * t]);
+            b[t][i] = (short)f2bf(Bs[(ks + khalf * 8 + i) * LD + brow + 32 * t]);
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
   }
 
-  // epilogue: acc[r] -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the wave's 32x32 block
-  const int col = n0 + wn * 32 + (lane & 31);
-  if (col >= p.N) return;
-  if (p.ksplit > 1) {   // raw partial of this K slice; the epilogue runs in gemm_splitk_epilogue_kernel
-    float* __restrict__ W = p.ws + ((long long)ksl * p.batch + bz) * p.M * p.N;
+  // epilogue: acc[i][j][r] -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the wave's (i, j) 32x32 block
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < p.M) W[(long long)row * p.N + col] = acc[r];
+  for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TM; ++tj) {
+      const int col = n0 + (wn * TM + tj) * 32 + (lane & 31);
+      const int rbase = m0 + (wm * TM + ti) * 32 + 4 * (lane >> 5);
+      if (col >= p.N) continue;
+      if (p.ksplit > 1) {   // raw partial of this K slice; the epilogue runs in gemm_splitk_epilogue_kernel
+        float* __restrict__ W = p.ws + ((long long)ksl * p.batch + bz) * p.M * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < p.M) W[(long long)row * p.N + col] = acc[ti][tj][r];
+        }
+        continue;
+      }
+      float* __restrict__ C = p.C + (long long)bz * p.sCb;
+      const float* __restrict__ R = p.resid ? p.resid + (long long)bz * p.sRb : nullptr;
+      const float bias = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row >= p.M) continue;
+        float v = p.alpha * acc[ti][tj][r] + bias;
+        if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
+        if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
+        if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
+        if (R) v += R[(long long)row * p.ldr + col];
+        if (p.flags & MCL_EPI_ACCUM) v += C[(long long)row * p.ldc + col];
+        C[(long long)row * p.ldc + col] = v;
+      }
     }
-    return;
-  }
-  float* __restrict__ C = p.C + (long long)bz * p.sCb;
-  const float* __restrict__ R = p.resid ? p.resid + (long long)bz * p.sRb : nullptr;
-  const float bias = p.bias ? p.bias[col] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row >= p.M) continue;
-    float v = p.alpha * acc[r] + bias;
-    if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
-    if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
-    if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
-    if (R) v += R[(long long)row * p.ldr + col];
-    if (p.flags & MCL_EPI_ACCUM) v += C[(long long)row * p.ldc + col];
-    C[(long long)row * p.ldc + col] = v;
-  }
 }
 
 // Split-K second pass: fixed-order sum of the K slices + the same epilogue as the one-pass kernel (deterministic).
@@ -208,9 +245,22 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmP p
 
 template <bool AKC, bool BKC, bool VEC>
 void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
+  // 128 x 128 tiles once they alone fill the chip twice over (and no split-K: that is the skinny-problem form)
+  const long long big_tiles = (long long)((p.N + 2 * BN - 1) / (2 * BN)) * ((p.M + 2 * BM - 1) / (2 * BM)) * batch;
+  // ... or a long reduction cut into K slices over a mid-sized output (mcl_gemm_auto_ksplit's second rule)
+  const long long tiles64 = (long long)((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * batch;
+  // (only where a 128-wide tile is not mostly padding: the generic convolutions' N = 32 / 128 outputs stay on 64 x 64 tiles --
+  //  fp32 DenseNet step 105 vs 115 ms with 128 x 128 tiles there)
+  const bool wide = p.N >= 640 && p.M >= 256 && ((p.N + 127) / 128) * 128 - p.N <= p.N / 8;
+  if (wide && ((p.ksplit == 1 && big_tiles >= 512) || (p.ksplit > 1 && tiles64 >= 128 && p.K >= 8192 && big_tiles * p.ksplit >= 256))) {
+    dim3 grid((p.N + 2 * BN - 1) / (2 * BN), (p.M + 2 * BM - 1) / (2 * BM), batch * p.ksplit), block(NT);
+    if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 2>), grid, block, 0, st, p);
+    else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 2>), grid, block, 0, st, p);
+    return;
+  }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch * p.ksplit), block(NT);
-  if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true>), grid, block, 0, st, p);
-  else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false>), grid, block, 0, st, p);
+  if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 1>), grid, block, 0, st, p);
+  else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 1>), grid, block, 0, st, p);
 }
 
 template <bool AKC, bool BKC>
@@ -273,6 +323,22 @@ extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
 extern "C" int32_t mcl_gemm_auto_ksplit(int32_t M, int32_t N, int32_t K, int32_t batch) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 1;
   const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+  if (tiles >= 128 && tiles < 1024 && K >= 2048) {
+    // a mid-sized output over a LONG reduction (weight gradients of the fp32 image encoders: 768 x 768 ... 3072 outputs over 6 400 -
+    // 25 216 token rows): a few hundred workgroups would each walk thousands of k
+    long long ks;
+    if (K >= 8192) {      // 128 x 128 tiles (launch2): slices for ~384 of them
+      const long long big = (long long)((M + 2 * BM - 1) / (2 * BM)) * ((N + 2 * BN - 1) / (2 * BN)) * batch;
+      ks = (384 + big - 1) / big;
+      if (ks > K / 512) ks = K / 512;
+    } else {              // 64 x 64 tiles: slices for ~1024 of them (measured on ViT-B/32, 6 400 rows: 40.5 vs 43.3 ms/step)
+      ks = 1024 / tiles;
+      if (ks > K / 1024) ks = K / 1024;
+    }
+    if (ks > 8) ks = 8;
+    if (ks * batch > 65535) ks = 65535 / batch;
+    return ks < 1 ? 1 : (int32_t)ks;
+  }
   if (tiles >= 128 || K < 256) return 1;
   long long ks = 256 / tiles;
   if (ks > K / 128) ks = K / 128;

@@ -110,6 +110,52 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// The same column reductions over MANY rows (the fp32 ViT: 6 400 - 25 216 token rows; the one-block-per-64-columns forms above
+// are written for the spot branch's 128 rows and serialise everything else on a dozen workgroups): blockIdx.y owns RCHUNK rows
+// and writes a partial per column; a second launch adds the partials in chunk order (deterministic).  HAS_X: the LayerNorm
+// parameter gradients (two outputs), else plain column sums.
+constexpr int RCHUNK = 128;
+template <bool HAS_X>
+__global__ __launch_bounds__(256) void colred_chunk_kernel(const float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                           long long ldx, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ part, int rows,
+                                                           int cols) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * RCHUNK, r1 = min(rows, r0 + RCHUNK);
+  float ag = 0.0f, ab = 0.0f;
+  if (c < cols) {
+    for (int r = r0 + grp; r < r1; r += 4) {
+      const float d = dy[(long long)r * lddy + c];
+      if (HAS_X) ag += d * (x[(long long)r * ldx + c] - mean[r]) * rstd[r];
+      ab += d;
+    }
+  }
+  sg[grp][lane] = ag;
+  sb[grp][lane] = ab;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+    const long long nch = gridDim.y;
+    part[(long long)blockIdx.y * cols + c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+    if (HAS_X) part[(nch + blockIdx.y) * cols + c] = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+  }
+}
+
+// out_b[c] (+)= sum over chunks of part[chunk][c]; with out_g also the second plane
+__global__ __launch_bounds__(256) void colred_merge_kernel(const float* __restrict__ part, int nch, int cols, float* __restrict__ out_b,
+                                                           float* __restrict__ out_g, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float b = 0.0f, g = 0.0f;
+  for (int k = 0; k < nch; ++k) {
+    b += part[(long long)k * cols + c];
+    if (out_g) g += part[((long long)nch + k) * cols + c];
+  }
+  out_b[c] = accumulate ? out_b[c] + b : b;
+  if (out_g) out_g[c] = accumulate ? out_g[c] + g : g;
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ s, long long ld, int n_rows,
                                                                int cols, float scale) {
   const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -144,6 +190,13 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 
 }  // namespace
 
+extern "C" int mcl_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                                    const float* rstd, const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma,
+                                    float* dbeta, int32_t accumulate_params, int32_t rows, int32_t cols, float* workspace,
+                                    mcl_stream_t stream);
+extern "C" int mcl_colsum_ws(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate, float* workspace,
+                             mcl_stream_t stream);
+
 extern "C" int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                                  int64_t ldy, float* mean, float* rstd, int32_t rows, int32_t cols, float eps,
                                  mcl_stream_t stream) {
@@ -161,9 +214,34 @@ extern "C" int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
                                  int32_t rows, int32_t cols, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || cols <= 0) return MCL_EINVAL;
+  return mcl_layernorm_bwd_ws(dy, lddy, x, ldx, gamma, mean, rstd, dx_add, ldadd, dx, lddx, dgamma, dbeta, accumulate_params, rows,
+                              cols, nullptr, stream);
+}
+
+extern "C" int64_t mcl_rowred_workspace_floats(int32_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 0) return -1;
+  return (int64_t)2 * ((rows + RCHUNK - 1) / RCHUNK) * cols;
+}
+
+// as mcl_layernorm_bwd; with a workspace (>= mcl_rowred_workspace_floats(rows, cols) floats) and more than 1024 rows the
+// parameter gradients are reduced over row chunks in parallel (the workspace-free form walks all rows on cols / 64 workgroups)
+extern "C" int mcl_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                    const float* mean, const float* rstd, const float* dx_add, int64_t ldadd, float* dx,
+                                    int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate_params, int32_t rows,
+                                    int32_t cols, float* workspace, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipStream_t st = mcl_stream(stream);
-  hipLaunchKernelGGL(layernorm_bwd_dgb_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd,
-                     dgamma, dbeta, rows, cols, accumulate_params);
+  if (workspace && rows > 1024) {
+    const int nch = (rows + RCHUNK - 1) / RCHUNK;
+    hipLaunchKernelGGL(colred_chunk_kernel<true>, dim3((cols + 63) / 64, nch), dim3(256), 0, st, dy, (long long)lddy, x,
+                       (long long)ldx, mean, rstd, workspace, rows, cols);
+    hipLaunchKernelGGL(colred_merge_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)workspace, nch, cols, dbeta,
+                       dgamma, accumulate_params);
+  } else {
+    hipLaunchKernelGGL(layernorm_bwd_dgb_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd,
+                       dgamma, dbeta, rows, cols, accumulate_params);
+  }
   hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, st, dy,
                      lddy, x, ldx, gamma, mean, rstd, dx_add, ldadd, dx, lddx, rows, cols);
   MCL_CHECK_LAUNCH();
@@ -174,8 +252,23 @@ extern "C" int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows,
                           mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!x || !out || rows <= 0 || cols <= 0) return MCL_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, mcl_stream(stream), x, ldx, out, rows, cols,
-                     accumulate);
+  return mcl_colsum_ws(x, ldx, out, rows, cols, accumulate, nullptr, stream);
+}
+
+extern "C" int mcl_colsum_ws(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate,
+                             float* workspace, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!x || !out || rows <= 0 || cols <= 0) return MCL_EINVAL;
+  hipStream_t st = mcl_stream(stream);
+  if (workspace && rows > 1024) {
+    const int nch = (rows + RCHUNK - 1) / RCHUNK;
+    hipLaunchKernelGGL(colred_chunk_kernel<false>, dim3((cols + 63) / 64, nch), dim3(256), 0, st, x, (long long)ldx,
+                       (const float*)nullptr, 0LL, (const float*)nullptr, (const float*)nullptr, workspace, rows, cols);
+    hipLaunchKernelGGL(colred_merge_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, (const float*)workspace, nch, cols, out,
+                       (float*)nullptr, accumulate);
+  } else {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, x, ldx, out, rows, cols, accumulate);
+  }
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -178,14 +178,22 @@ def colsum(x: Tensor, param: Optional[Tensor] = None) -> Optional[Tensor]:
     """Column sums (nn.Linear bias gradient).  With ``param`` (the bias Parameter) owning a dense fp32 .grad the sums are
     ADDED straight into it and None is returned to autograd (no temporary, no AccumulateGrad add launch)."""
     x = _rowmajor(x, "x")
+    ws = _rowred_ws(x.shape[0], x.shape[1], x.device)
     if param is not None and param.shape == (x.shape[1],) and _direct_grad_ok(param):
-        check(_lib.lib().mcl_colsum(x.data_ptr(), x.stride(0), param.grad.data_ptr(), x.shape[0], x.shape[1], 1, _stream()),
-              "mcl_colsum")
+        check(_lib.lib().mcl_colsum_ws(x.data_ptr(), x.stride(0), param.grad.data_ptr(), x.shape[0], x.shape[1], 1, _p(ws),
+                                       _stream()), "mcl_colsum")
         return None
     out = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
-    check(_lib.lib().mcl_colsum(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], 0, _stream()),
+    check(_lib.lib().mcl_colsum_ws(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], 0, _p(ws), _stream()),
           "mcl_colsum")
     return out
+
+
+def _rowred_ws(rows: int, cols: int, device) -> Optional[Tensor]:
+    """Chunk-partial workspace of the many-row column reductions (None for the spot branch's few rows: the one-launch forms)."""
+    if rows <= 1024:
+        return None
+    return torch.empty(_lib.lib().mcl_rowred_workspace_floats(rows, cols), device=device, dtype=torch.float32)
 
 
 # --------------------------------------------------------------------------- LayerNorm
@@ -218,11 +226,11 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
         db = torch.empty((cols,), device=x.device, dtype=torch.float32)
     if dx_add is not None:
         dx_add = _rowmajor(dx_add, "dx_add")
-    check(_lib.lib().mcl_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
-                                       mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
-                                       dx_add.stride(0) if dx_add is not None else 0, dx.data_ptr(), cols,
-                                       dg.data_ptr(), db.data_ptr(), int(direct), rows, cols, _stream()),
-          "mcl_layernorm_bwd")
+    check(_lib.lib().mcl_layernorm_bwd_ws(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+                                          dx_add.stride(0) if dx_add is not None else 0, dx.data_ptr(), cols,
+                                          dg.data_ptr(), db.data_ptr(), int(direct), rows, cols,
+                                          _p(_rowred_ws(rows, cols, x.device)), _stream()), "mcl_layernorm_bwd")
     return (dx, None, None) if direct else (dx, dg, db)
 
 
