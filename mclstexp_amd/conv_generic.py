@@ -103,9 +103,15 @@ def _weight_khwc(w: Tensor, dt: torch.dtype) -> Tensor:
     return _weight(w, dt)
 
 
-def conv_fwd(x: Tensor, wk: Tensor, stride: int, pad: int, out: Optional[Tensor] = None) -> Tensor:
+# The unfolded patches of a k > 1 convolution are kept from the forward for the weight gradient (one im2col launch per convolution
+# and step instead of two: 17 % of the ResNet-18 step, 8 % of the fp32 DenseNet step) when they fit this many bytes -- HBM is
+# 288 GB: the fp32 DenseNet's 58 unfolded 3 x 3 inputs are 20 GB at batch 128.
+KEEP_COLS_MAX_BYTES = 3 << 30
+
+
+def conv_fwd(x: Tensor, wk: Tensor, stride: int, pad: int, out: Optional[Tensor] = None, want_cols: bool = False):
     """y = conv2d(x, w, stride, pad) (no bias).  x (B, Ci, H, W) channels-last view, wk (Co, Ci, k, k) channels-last storage in
-    x's dtype; ``out``: optional channels-last (sliced) destination."""
+    x's dtype; ``out``: optional channels-last (sliced) destination.  ``want_cols``: returns (y, unfolded patches or None)."""
     B, Ci, H, W = x.shape
     Co, _, k, _ = wk.shape
     OH, OW = _out_hw(H, W, k, stride, pad)
@@ -119,6 +125,9 @@ def conv_fwd(x: Tensor, wk: Tensor, stride: int, pad: int, out: Optional[Tensor]
         A = im2col(x, k, stride, pad)
         pa, lda = A.data_ptr(), k * k * Ci
     _gemm(A, pa, lda, False, wk, wk.data_ptr(), k * k * Ci, False, y, py, ldy, B * OH * OW, Co, k * k * Ci)
+    if want_cols:
+        keep = A is not x and A.numel() * A.element_size() <= KEEP_COLS_MAX_BYTES
+        return y, (A if keep else None)
     return y
 
 
@@ -137,9 +146,11 @@ def conv_bwd_data(dy: Tensor, wk: Tensor, x_shape, stride: int, pad: int) -> Ten
     return col2im(dcols, (B, Ci, H, W), k, stride, pad)
 
 
-def conv_bwd_weight(dy: Tensor, x: Tensor, w_param: Tensor, stride: int, pad: int) -> Optional[Tensor]:
+def conv_bwd_weight(dy: Tensor, x: Tensor, w_param: Tensor, stride: int, pad: int, cols: Optional[Tensor] = None
+                    ) -> Optional[Tensor]:
     """dW (Co, kh, kw, Ci) = dy^T . cols.  Added straight into ``w_param.grad`` when it is a dense fp32 tensor of
-    (Co, kh, kw, Ci) storage (returns None), else returned as a fresh fp32 tensor shaped like the parameter."""
+    (Co, kh, kw, Ci) storage (returns None), else returned as a fresh fp32 tensor shaped like the parameter.  ``cols``: the
+    forward's unfolded patches, when it kept them."""
     from .densenet_fused import DIRECT_PARAM_GRADS, _direct_grad_ok
     Co, Ci, k, _ = w_param.shape
     pd, S, Cd, ldd = _rows(dy)
@@ -149,7 +160,7 @@ def conv_bwd_weight(dy: Tensor, x: Tensor, w_param: Tensor, stride: int, pad: in
         pa, _, _, lda = _rows(x)
         A = x
     else:
-        A = im2col(x, k, stride, pad)
+        A = cols if cols is not None else im2col(x, k, stride, pad)
         pa, lda = A.data_ptr(), K
     direct = (DIRECT_PARAM_GRADS and _direct_grad_ok(w_param) and w_param.grad.permute(0, 2, 3, 1).is_contiguous())
     if direct:
@@ -178,8 +189,14 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad):
         wk = _weight_khwc(w, x.dtype)
-        y = conv_fwd(x, wk, stride, pad)
-        ctx.save_for_backward(x, wk)
+        y, cols = conv_fwd(x, wk, stride, pad, want_cols=True)
+        if not ctx.needs_input_grad[1]:
+            cols = None
+        ctx.has_cols = cols is not None
+        if cols is not None:
+            ctx.save_for_backward(x, wk, cols)
+        else:
+            ctx.save_for_backward(x, wk)
         ctx.w, ctx.geo = w, (stride, pad)
         ctx.cap = None
         if CAPTURE_CONVS is not None:
@@ -189,14 +206,15 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, wk = ctx.saved_tensors
+        x, wk = ctx.saved_tensors[:2]
+        cols = ctx.saved_tensors[2] if ctx.has_cols else None
         stride, pad = ctx.geo
         if not dy.is_contiguous(memory_format=CL):
             dy = dy.contiguous(memory_format=CL)
         g_before = None
         if ctx.cap is not None and getattr(ctx.w, "grad", None) is not None:
             g_before = ctx.w.grad.detach().clone()
-        dw = conv_bwd_weight(dy, x, ctx.w, stride, pad) if ctx.needs_input_grad[1] else None
+        dw = conv_bwd_weight(dy, x, ctx.w, stride, pad, cols) if ctx.needs_input_grad[1] else None
         dx = conv_bwd_data(dy, wk, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
         if ctx.cap is not None:
             ctx.cap.update({"dy": dy, "dx": dx})

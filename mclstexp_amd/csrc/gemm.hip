@@ -340,6 +340,15 @@ extern "C" int32_t mcl_gemm_auto_ksplit(int32_t M, int32_t N, int32_t K, int32_t
     return ks < 1 ? 1 : (int32_t)ks;
   }
   if (tiles >= 128 || K < 256) return 1;
+  if (K >= 16384) {
+    // a handful of output tiles over a reduction of 10^4 - 10^6 (weight gradients of the generic fp32 convolutions: C_out x C_in k^2
+    // over every pixel of the batch): up to 64 slices -- eight of them left 8 - 288 workgroups walking 50 000 pixels each
+    long long ks = 1024 / tiles;
+    if (ks > K / 1024) ks = K / 1024;
+    if (ks > 64) ks = 64;
+    if (ks * batch > 65535) ks = 65535 / batch;
+    return ks < 1 ? 1 : (int32_t)ks;
+  }
   long long ks = 256 / tiles;
   if (ks > K / 128) ks = K / 128;
   if (ks > 8) ks = 8;

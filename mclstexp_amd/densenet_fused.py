@@ -642,12 +642,13 @@ def _weight(w: Tensor, dt: torch.dtype) -> Tensor:
     return w.to(dtype=dt, memory_format=CL)
 
 
-def _conv_bwd(dy: Tensor, x: Tensor, w: Tensor, w_param: Tensor, padding: int):
+def _conv_bwd(dy: Tensor, x: Tensor, w: Tensor, w_param: Tensor, padding: int, cols: Optional[Tensor] = None):
     """(dx, dw) of a stride-1 convolution on the generic path (conv_generic.py: GEMM + col2im, split-K weight gradient);
-    dw is None when it was accumulated straight into ``w_param.grad``, else an fp32 tensor shaped like the parameter."""
+    dw is None when it was accumulated straight into ``w_param.grad``, else an fp32 tensor shaped like the parameter.
+    ``cols``: the forward's unfolded patches when it kept them."""
     from . import conv_generic as cg
     dy = dy if dy.is_contiguous(memory_format=CL) else dy.contiguous(memory_format=CL)
-    dw = cg.conv_bwd_weight(dy, x, w_param, 1, padding)
+    dw = cg.conv_bwd_weight(dy, x, w_param, 1, padding, cols)
     dx = cg.conv_bwd_data(dy, w, x.shape, 1, padding)
     return dx, dw
 
@@ -899,6 +900,7 @@ class DenseBlockFn(torch.autograd.Function):
             bn_stats(x0, stats.mean[:C0], stats.var[:C0], stats.rstd[:C0], eps1[0], copy_out=buf[:, :C0])
         saved = []
         wcast = []
+        kept_cols = {}                 # layer -> unfolded 3x3 input of the generic (fp32) path, kept for the weight gradient
         ctx.persistent = False
         if _block_persistent_ok(buf, params, growth, L, C0, dt):
             # 7 x 7 maps: the whole block as ONE persistent launch (csrc/dense_block.hip) -- one workgroup per image, the
@@ -936,11 +938,13 @@ class DenseBlockFn(torch.autograd.Function):
                 from . import conv_generic as cg
                 a2 = torch.empty_like(z, memory_format=CL)
                 bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-                cg.conv_fwd(a2, w2c, 1, 1, out=buf[:, cin:c1])            # written straight into the concat buffer
+                _, cols2 = cg.conv_fwd(a2, w2c, 1, 1, out=buf[:, cin:c1], want_cols=True)   # written straight into the concat buffer
+                kept_cols[l] = cols2
                 bn_stats(buf[:, cin:c1], stats.mean[cin:c1], stats.var[cin:c1], stats.rstd[cin:c1], eps1[min(l + 1, L - 1)])
             saved += [a if a is not None else buf.new_empty(0), z, a2 if a2 is not None else buf.new_empty(0)]
             wcast += [w1c, w2c]
         ctx.save_for_backward(buf, *saved, *wcast)
+        ctx.kept_cols = kept_cols
         ctx.params = params             # Parameter objects (for direct .grad accumulation)
         ctx.meta = (stats, growth, bn2_stats, L, C0)
         ctx.cap = None
@@ -1113,7 +1117,7 @@ class DenseBlockFn(torch.autograd.Function):
                 if a2.numel() == 0:
                     a2 = torch.empty_like(z, memory_format=CL)
                     bn_act_fwd(z, g2, b2, m2, r2, True, a2)
-                da2, dw2 = _conv_bwd(dy, a2, w2c, w2, 1)
+                da2, dw2 = _conv_bwd(dy, a2, w2c, w2, 1, ctx.kept_cols.pop(l, None))
                 dz = torch.empty_like(z, memory_format=CL)
                 dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
                                       into_param_grads=d2)
