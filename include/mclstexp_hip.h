@@ -153,6 +153,16 @@ int mcl_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* x, int64_t 
                          const float* rstd, const float* dx_add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma,
                          float* dbeta, int32_t accumulate_params, int32_t rows, int32_t cols, float* workspace, mcl_stream_t stream);
 
+/* ---------------------------------------------------------------- f4: soft-target contrastive loss, elementwise middle (ABI 7)
+ * /root/reference/baselines/Bleep/models.py:34-43,66-76,228-234.  Given S = E_s E_i^T / T, the soft targets Tg (row softmax),
+ * the row / column log-sum-exp of S (mcl_infonce_lse) and the column sums of Tg (mcl_colsum), ONE pass writes
+ * dS = c (softmax_row(S) + softmax_col(S) tcol - 2 Tg), dA = -c (logsoftmax_row(S) + logsoftmax_col(S)) and, per row, the loss
+ * partial loss_rows[i] = -c sum_j Tg_ij (logsoftmax_row + logsoftmax_col)_ij (their sum is the loss; c = 1 / (2B)).  All (B, B)
+ * row-major fp32.  mcl_symmetrize: out = (a + a^T) / 2 (out != a). */
+int mcl_soft_clip_mid(const float* S, const float* Tg, const float* lse_row, const float* lse_col, const float* tcol, int32_t B,
+                      float c, float* dS, float* dA, float* loss_rows, mcl_stream_t stream);
+int mcl_symmetrize(const float* a, int32_t B, float* out, mcl_stream_t stream);
+
 /* ---------------------------------------------------------------- K8 symmetric InfoNCE (model.py:242-247)
  * Works on a logits strip S (R x C, already divided by T): this rank's rows are global rows
  * [row0,row0+R) and its columns are global columns [col0,col0+C); the target (identity) entry of

@@ -67,6 +67,8 @@ PROTOTYPES = {
     "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
+    "mcl_soft_clip_mid": [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
+    "mcl_symmetrize": [c_p, c_i, c_p, c_p],
     "mcl_colsum_ws": [c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p],
     "mcl_rowred_workspace_floats": [c_i, c_i],
     "mcl_layernorm_bwd_ws": [c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p, c_p],

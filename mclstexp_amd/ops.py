@@ -876,16 +876,19 @@ def soft_clip_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, targets
     check(L.mcl_softmax_rows_fwd(Tg.data_ptr(), B, B, B, k, _stream()), "mcl_softmax_rows_fwd")      # Tg in place
     lse = torch.empty((2, B), device=dev, dtype=torch.float32)
     check(L.mcl_infonce_lse(S.data_ptr(), B, B, B, lse[0].data_ptr(), lse[1].data_ptr(), _stream()), "mcl_infonce_lse")
-    ls = S - lse[0][:, None]                                     # log-softmax over rows
-    lc = S - lse[1][None, :]                                     # log-softmax over columns
-    lsum = ls + lc
     c = 1.0 / (2.0 * B)
-    loss = -(Tg * lsum).sum() * c
-    # backward
-    dS = (torch.exp(ls) + torch.exp(lc) * Tg.sum(0)[None, :] - 2.0 * Tg) * c
-    dA = lsum.mul_(-c)                                           # d loss / d Tg
+    # the elementwise middle in one pass (csrc/soft_clip.hip): loss partials, dS, d loss / d Tg
+    tcol = colsum(Tg)
+    dS = torch.empty((B, B), device=dev, dtype=torch.float32)
+    dA = torch.empty((B, B), device=dev, dtype=torch.float32)
+    loss_rows = torch.empty((B, 1), device=dev, dtype=torch.float32)
+    check(L.mcl_soft_clip_mid(S.data_ptr(), Tg.data_ptr(), lse[0].data_ptr(), lse[1].data_ptr(), tcol.data_ptr(), B, c,
+                              dS.data_ptr(), dA.data_ptr(), loss_rows.data_ptr(), _stream()), "mcl_soft_clip_mid")
+    loss = colsum(loss_rows)[0]
+    # backward through the soft targets
     check(L.mcl_softmax_rows_bwd(Tg.data_ptr(), dA.data_ptr(), B, B, B, k, _stream()), "mcl_softmax_rows_bwd")
-    dsym = (dA + dA.t()).mul_(0.5).contiguous()                  # A = (II + SS)/2 and both Gram matrices are symmetric
+    dsym = torch.empty((B, B), device=dev, dtype=torch.float32)  # A = (II + SS)/2 and both Gram matrices are symmetric
+    check(L.mcl_symmetrize(dA.data_ptr(), B, dsym.data_ptr(), _stream()), "mcl_symmetrize")
     d_es = torch.empty_like(es)
     d_ei = torch.empty_like(ei)
     gemm_raw(B, P, B, 1, dS, B, 1, 0, ei, ei.stride(0), 1, 0, d_es, P, 0, alpha=inv_t, compute=COMPUTE_F32)

@@ -568,6 +568,20 @@ def test_soft_clip_loss_large_batch_vs_oracle(ops):
     assert_close_scaled(d_ei.cpu(), b.grad, 5e-5, what="d_ei")
 
 
+def test_soft_clip_loss_launches_own_kernels_only(ops):
+    """the loss was four own GEMMs stitched by a dozen ATen elementwise launches; now every launch
+    between the embeddings and the gradients is this library's (csrc/soft_clip.hip for the elementwise middle)."""
+    from mclstexp_amd import kernel_audit
+    g = torch.Generator().manual_seed(1)
+    es = (torch.randn(256, 256, generator=g) * 0.05).to(DEV)
+    ei = (torch.randn(256, 256, generator=g) * 0.05).to(DEV)
+    ops.soft_clip_fwd_bwd(es, ei, 0.8)
+    ks = kernel_audit.step_kernels(lambda: ops.soft_clip_fwd_bwd(es, ei, 0.8))
+    bad = kernel_audit.foreign(ks)
+    assert not bad, bad
+    assert any("soft_clip_mid_kernel" in k for k in ks) and any("symmetrize_kernel" in k for k in ks)
+
+
 def test_out_of_range_position_raises_like_nn_embedding(ops):
     """positions outside the tables are clamped by the kernel but must not train the wrong rows silently:
     the device flag turns into nn.Embedding's IndexError at the next check; integer position tensors are accepted."""
