@@ -141,6 +141,16 @@ def conv_bwd_data(dy: Tensor, wk: Tensor, x_shape, stride: int, pad: int) -> Ten
         dx = torch.empty((B, Ci, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         _gemm(dy, pd, ldd, False, wk, wk.data_ptr(), K, True, dx, dx.data_ptr(), Ci, S, K, Co)
         return dx
+    if stride == 1 and 2 * pad == k - 1 and 2 * Co <= Ci and dy.is_contiguous(memory_format=CL):
+        # a "same" convolution with fewer outputs than inputs (DenseNet's 3 x 3: 128 -> 32): the data gradient is itself a same
+        # convolution of dy with the kernel rotated by 180 degrees and its channel roles swapped.  Unfolding dy costs k*k*Co columns
+        # per pixel instead of the k*k*Ci of the column-gradient buffer (a quarter here), and there is no col2im pass at all
+        # (fp32 DenseNet step: 11.1 + 4.7 ms of column-gradient GEMMs and col2im).
+        dyc = im2col(dy, k, 1, pad)                                       # (S, k*k*Co), columns (ky, kx, co)
+        wf = wk.permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()   # (Ci, k, k, Co): wf[ci,ky,kx,co] = w[co,k-1-ky,k-1-kx,ci]
+        dx = torch.empty((B, Ci, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
+        _gemm(dyc, dyc.data_ptr(), k * k * Co, False, wf, wf.data_ptr(), k * k * Co, False, dx, dx.data_ptr(), Ci, S, Ci, k * k * Co)
+        return dx
     dcols = torch.empty((S, K), device=dy.device, dtype=dy.dtype)
     _gemm(dy, pd, ldd, False, wk, wk.data_ptr(), K, True, dcols, dcols.data_ptr(), K, S, K, Co)
     return col2im(dcols, (B, Ci, H, W), k, stride, pad)

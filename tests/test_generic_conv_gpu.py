@@ -43,7 +43,10 @@ def test_im2col_col2im_vs_unfold(dtype, B, C, H, W, k, stride, pad):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,Ci,Co,H,W,k,stride,pad", [(4, 64, 128, 14, 14, 1, 1, 0), (3, 64, 64, 15, 13, 3, 1, 1),
                                                       (2, 128, 256, 16, 16, 3, 2, 1), (2, 256, 512, 8, 8, 1, 2, 0),
-                                                      (2, 3, 64, 32, 32, 7, 2, 3), (5, 32, 32, 7, 7, 3, 1, 1)])
+                                                      (2, 3, 64, 32, 32, 7, 2, 3), (5, 32, 32, 7, 7, 3, 1, 1),
+                                                      # data gradient as a same-convolution of dy (C_out <= C_in / 2)
+                                                      (3, 128, 32, 14, 14, 3, 1, 1), (2, 64, 16, 9, 11, 5, 1, 2),
+                                                      (2, 96, 48, 7, 7, 3, 1, 1)])
 def test_conv_fn_vs_fp64(dtype, B, Ci, Co, H, W, k, stride, pad):
     """ConvFn forward / backward-data / weight gradient (direct accumulation into a channels-last fp32 .grad AND the autograd
     hand-over) against fp64 conv2d on the same (rounded) operands."""
