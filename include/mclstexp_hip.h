@@ -73,6 +73,11 @@ typedef struct mcl_gemm_args {
                             `workspace` and a second launch adds them in fixed order and applies the epilogue
                             (deterministic; for skinny problems such as the spot path's M = batch of 128 spots) */
   float* workspace;      /* >= mcl_gemm_workspace_floats(M, N, batch, ksplit) floats when ksplit > 1, else unused */
+  /* ABI 7: threshold FILTER instead of the C store (fused similarity + top-k, /root/reference/evel_her2st.py:74-84).
+   * flt_thr != NULL: nothing is written to C (may be NULL); every product alpha * (A B)[i][j] >= flt_thr[i] is appended to row i's
+   * candidate list: pos = atomic flt_cnt[i]++ (zero on entry), flt_val[i * flt_cap + pos] = value, flt_idx[...] = j when
+   * pos < flt_cap (flt_cnt keeps counting past the capacity: the caller sees the overflow).  batch 1, no split-K, no epilogue. */
+  const float* flt_thr; int32_t* flt_cnt; float* flt_val; int32_t* flt_idx; int32_t flt_cap;
 } mcl_gemm_args;
 
 int mcl_gemm(const mcl_gemm_args* args, mcl_stream_t stream);
@@ -658,6 +663,12 @@ int mcl_l2_normalize_rows(const float* x, int64_t ldx, float* y, int64_t ldy, in
 int mcl_topk_rows_max_k(void);
 int mcl_topk_rows(const float* sim, int64_t ld, int32_t rows, int32_t n, int32_t k, float* values, int64_t* indices,
                   mcl_stream_t stream);
+/* top-k of CANDIDATE LISTS (mcl_gemm's threshold filter): row i holds n (value, original column) pairs in arbitrary order, unused
+ * slots -inf.  Returns the original columns, equal values ordered by original column like mcl_topk_rows.  A row whose k-th value is
+ * an exact tie that would have to be cut by original column sets tie_flag[i] = 1 (its output is then unspecified: recompute that
+ * row with mcl_topk_rows on the materialised similarities). */
+int mcl_topk_rows_indexed(const float* cand_val, int64_t ld, const int32_t* cand_idx, int64_t ld_idx, int rows, int n, int k,
+                          float* values, int64_t* indices, int32_t* tie_flag, mcl_stream_t stream);
 int mcl_knn_weighted_average(const float* spot_key, int64_t ldk, const float* expression_key, int64_t lde,
                              const float* query, int64_t ldq, const int64_t* indices, int32_t n_query, int32_t k,
                              int32_t dim, int32_t genes, int32_t ord, float* emb_pred, float* expr_pred,

@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("aux", c_p), ("ldaux", c_l),
         ("compute", c_i), ("ksplit", c_i),
         ("workspace", c_p),
+        ("flt_thr", c_p), ("flt_cnt", c_p), ("flt_val", c_p), ("flt_idx", c_p), ("flt_cap", c_i),
     ]
 
 
@@ -175,6 +176,7 @@ PROTOTYPES = {
     "mcl_l2_normalize_rows": [c_p, c_l, c_p, c_l, c_i, c_i, c_p],
     "mcl_topk_rows_max_k": [],
     "mcl_topk_rows": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
+    "mcl_topk_rows_indexed": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "mcl_knn_weighted_average": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
 }
 _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_dense_block_fwd_workspace_bytes": C.c_int64, "mcl_dense_block_bwd_workspace_bytes": C.c_int64, "mcl_bn_workspace_floats": C.c_int64,

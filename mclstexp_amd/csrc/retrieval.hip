@@ -68,9 +68,15 @@ __device__ __forceinline__ void wave_append(bool flag, unsigned key, unsigned id
   }
 }
 
+// idx_in (optional): the rows are CANDIDATE LISTS in arbitrary order (mcl_gemm's threshold filter) and idx_in[row][i] is the
+// element's original column: it is what gets returned and what orders equal values.  Exact ties AT the k-th value would have to
+// be cut by original index, which the position-ordered compaction below cannot do on a scrambled list: such a row raises
+// tie_flag[row] and the caller recomputes it on the materialised path.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_rows_kernel(const float* __restrict__ sim, long long ld, int n,
                                                                  int k, float* __restrict__ values,
-                                                                 long long* __restrict__ indices) {
+                                                                 long long* __restrict__ indices,
+                                                                 const int* __restrict__ idx_in, long long ld_idx,
+                                                                 int* __restrict__ tie_flag) {
   __shared__ unsigned hist[RADIX_BINS];
   __shared__ unsigned long long sel[TOPK_KMAX];
   __shared__ unsigned red_min[TOPK_THREADS / 64], red_max[TOPK_THREADS / 64];
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_rows_kernel(const float* __
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = sim + (long long)blockIdx.x * ld;
+  const int* irow = idx_in ? idx_in + (long long)blockIdx.x * ld_idx : nullptr;
 
   // ---- pass 0: key range of the row
   unsigned kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -176,8 +183,9 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_rows_kernel(const float* __
       win = hi > pref;
       tie = (hi == pref) && (inbin == need);
     }
-    wave_append(win || tie, key, (unsigned)i, sel, &s_cnt, (unsigned)k);
+    wave_append(win || tie, key, (unsigned)((irow && i < n) ? irow[i] : i), sel, &s_cnt, (unsigned)k);
   }
+  if (inbin != need && tie_flag && tid == 0) tie_flag[blockIdx.x] = 1;
   if (inbin != need) {
     // exact ties at the k-th value: take the lowest indices (ordered compaction, chunk by chunk)
     __syncthreads();
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_rows_kernel(const float* __
       }
       if (tie) {
         const unsigned r = taken + before + lanes_below(mask);
-        if (r < need) sel[base + r] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        if (r < need)
+          sel[base + r] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(irow ? irow[i] : i));
       }
       taken += total;
       __syncthreads();
@@ -326,7 +335,21 @@ extern "C" int mcl_topk_rows(const float* sim, int64_t ld, int rows, int n, int 
   if (k > TOPK_KMAX) return MCL_EUNSUPPORTED;
   MCL_CLEAR_ERROR();
   hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, mcl_stream(stream), sim, (long long)ld, n, k,
-                     values, reinterpret_cast<long long*>(indices));
+                     values, reinterpret_cast<long long*>(indices), (const int*)nullptr, 0LL, (int*)nullptr);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+// top-k of candidate lists: row i holds n (value, original column) pairs in arbitrary order (unused slots: -inf); see the kernel
+extern "C" int mcl_topk_rows_indexed(const float* cand_val, int64_t ld, const int32_t* cand_idx, int64_t ld_idx, int rows, int n,
+                                     int k, float* values, int64_t* indices, int32_t* tie_flag, mcl_stream_t stream) {
+  if (rows == 0) return MCL_OK;
+  if (!cand_val || !cand_idx || !values || !indices || !tie_flag || rows < 0 || n <= 0 || k <= 0 || k > n || ld < n || ld_idx < n)
+    return MCL_EINVAL;
+  if (k > TOPK_KMAX) return MCL_EUNSUPPORTED;
+  MCL_CLEAR_ERROR();
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, mcl_stream(stream), cand_val, (long long)ld, n, k,
+                     values, reinterpret_cast<long long*>(indices), (const int*)cand_idx, (long long)ld_idx, (int*)tie_flag);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

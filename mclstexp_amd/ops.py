@@ -89,20 +89,27 @@ def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, 
              sBn: int, sBb: int, Cmat: Tensor, ldc: int, sCb: int, alpha: float = 1.0, flags: int = 0,
              bias: Optional[Tensor] = None, resid: Optional[Tensor] = None, ldr: int = 0, sRb: int = 0,
              pre_out: Optional[Tensor] = None, ldp: int = 0, aux: Optional[Tensor] = None, ldaux: int = 0,
-             a_off: int = 0, b_off: int = 0, c_off: int = 0, compute: Optional[int] = None) -> None:
-    """mcl_gemm with explicit strides; *_off are element offsets into A/B/C's storage views."""
+             a_off: int = 0, b_off: int = 0, c_off: int = 0, compute: Optional[int] = None, filt=None) -> None:
+    """mcl_gemm with explicit strides; *_off are element offsets into A/B/C's storage views.  ``filt`` = (thr (M,), cnt (M,)
+    int32 zeroed, cand_val (M, cap), cand_idx (M, cap) int32): nothing is stored to C (pass None); products >= thr[row] are
+    appended to the row's candidate list (retrieval's fused similarity + top-k)."""
     a = GemmArgs()
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.A, a.sAm, a.sAk, a.sAb = A.data_ptr() + 4 * a_off, sAm, sAk, sAb
     a.B, a.sBk, a.sBn, a.sBb = B.data_ptr() + 4 * b_off, sBk, sBn, sBb
-    a.C, a.ldc, a.sCb = Cmat.data_ptr() + 4 * c_off, ldc, sCb
+    if filt is not None:
+        thr, cnt, cval, cidx = filt
+        a.flt_thr, a.flt_cnt, a.flt_val, a.flt_idx, a.flt_cap = thr.data_ptr(), cnt.data_ptr(), cval.data_ptr(), cidx.data_ptr(), cval.shape[1]
+        a.C, a.ldc, a.sCb = None, N, 0
+    else:
+        a.C, a.ldc, a.sCb = Cmat.data_ptr() + 4 * c_off, ldc, sCb
     a.alpha, a.flags = alpha, flags
     a.bias = _p(bias)
     a.resid, a.ldr, a.sRb = _p(resid), ldr, sRb
     a.pre_out, a.ldp = _p(pre_out), ldp
     a.aux, a.ldaux = _p(aux), ldaux
     a.compute = _compute_mode if compute is None else compute
-    ks = _lib.lib().mcl_gemm_auto_ksplit(M, N, K, batch) if SPLIT_K else 1
+    ks = _lib.lib().mcl_gemm_auto_ksplit(M, N, K, batch) if (SPLIT_K and filt is None) else 1
     if ks > 1:    # skinny problem (M = a batch of spots): K slices + fixed-order merge fill the chip
         ws = torch.empty(ks * batch * M * N, device=Cmat.device, dtype=torch.float32)
         a.ksplit, a.workspace = ks, ws.data_ptr()

@@ -10,7 +10,9 @@ Reference (paths relative to /root/reference/):
 The reference works on numpy arrays on the host (``torch.tensor(...)`` on CPU, a Python loop over queries);
 here the arrays are moved to the GPU once and stay there: L2 normalisation, the (Q, N) cosine similarity as an fp32
 MFMA GEMM, an exact per-row radix-select top-k and the weighted neighbour average are four launches per query
-chunk.  No CPU fallback: without a GPU / the HIP library these functions raise ``RuntimeError``.
+chunk; for large problems (>= 1e8 similarities) the similarity matrix is never written (``find_matches_filtered``: a per-query threshold from a key
+sample, the GEMM's filter epilogue, top-k of the candidate lists -- exact, with a materialised recomputation of any row the
+threshold missed).  No CPU fallback: without a GPU / the HIP library these functions raise ``RuntimeError``.
 """
 from __future__ import annotations
 
@@ -78,6 +80,51 @@ def topk_rows(sim: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     return values, indices
 
 
+# The fused similarity + top-k path (find_matches_filtered) is taken when the similarity matrix would be large (its extra
+# launches and the host look at the counters cost ~0.2 ms: at the reference's fold sizes, 1e7 similarities, the materialised
+# path is faster -- tools/bench_retrieval.py) and k is a small part of the keys
+FUSED_MIN_KEYS = 8192
+FUSED_MIN_SIMS = 100_000_000
+FUSED_SAMPLE = 4096
+
+
+def find_matches_filtered(query: Tensor, keys: Tensor, top_k: int) -> Tuple[Tensor, Tensor, int]:
+    """Cosine top-k WITHOUT the (Q, N) similarity matrix in HBM (evel_her2st.py:74-84), exact:
+      1. a strided sample of FUSED_SAMPLE keys gives every query a threshold -- the value at rank ~1.5 k N_s / N of its sample
+         similarities (small GEMM + mcl_topk_rows);
+      2. the full similarity GEMM runs with mcl_gemm's FILTER epilogue: products >= the row's threshold are appended to the row's
+         candidate list, nothing else is stored;
+      3. mcl_topk_rows_indexed selects the top-k of every list (original key indices, equal values ordered by index).
+    A row whose list holds fewer than k or more than its capacity, or whose k-th value is an exact tie, is recomputed on the
+    materialised path -- the result is the same as ``topk_rows(cosine_similarity_matrix(...))`` for every input.  Returns
+    (values, indices, number of recomputed rows)."""
+    q, p = query.shape
+    n = keys.shape[0]
+    dev = query.device
+    L = _lib.lib()
+    ns = min(n, FUSED_SAMPLE)
+    step = n // ns
+    sample = keys[::step][:ns]                                   # strided view: rows stay unit-stride
+    r = min(ns, int(1.5 * top_k * ns / n) + 32)
+    thr = topk_rows(cosine_similarity_matrix(query, sample), r)[0][:, r - 1].contiguous()
+    cap = max(2048, 4 * top_k)
+    cnt = torch.zeros((q,), device=dev, dtype=torch.int32)
+    cval = torch.full((q, cap), float("-inf"), device=dev, dtype=torch.float32)
+    cidx = torch.zeros((q, cap), device=dev, dtype=torch.int32)
+    ops.gemm_raw(q, n, p, 1, query, query.stride(0), 1, 0, keys, 1, keys.stride(0), 0, None, n, 0,
+                 compute=_lib.COMPUTE_F32, filt=(thr, cnt, cval, cidx))
+    values = torch.empty((q, top_k), device=dev, dtype=torch.float32)
+    indices = torch.empty((q, top_k), device=dev, dtype=torch.int64)
+    tie = torch.zeros((q,), device=dev, dtype=torch.int32)
+    check(L.mcl_topk_rows_indexed(cval.data_ptr(), cap, cidx.data_ptr(), cap, q, cap, top_k, values.data_ptr(), indices.data_ptr(),
+                                  tie.data_ptr(), ops._stream()), "mcl_topk_rows_indexed")
+    bad = ((cnt < top_k) | (cnt > cap) | (tie != 0)).nonzero().flatten()      # (host sync: the retrieval returns to the host anyway)
+    if bad.numel():
+        v, i = topk_rows(cosine_similarity_matrix(query[bad].contiguous(), keys), top_k)
+        values[bad], indices[bad] = v, i
+    return values, indices, int(bad.numel())
+
+
 def find_matches_device(spot_embeddings: ArrayLike, query_embeddings: ArrayLike, top_k: int = 1
                         ) -> Tuple[Tensor, Tensor]:
     """(values, indices) as device tensors, shapes (Q, top_k): cosine top-k of every query against all keys."""
@@ -86,6 +133,9 @@ def find_matches_device(spot_embeddings: ArrayLike, query_embeddings: ArrayLike,
     if keys.shape[1] != query.shape[1]:
         raise RuntimeError(f"embedding widths differ: keys {tuple(keys.shape)}, queries {tuple(query.shape)}")
     q, n = query.shape[0], keys.shape[0]
+    if n >= FUSED_MIN_KEYS and q * n >= FUSED_MIN_SIMS and 16 * top_k <= n and top_k <= 1024:
+        v, i, _ = find_matches_filtered(query, keys, top_k)
+        return v, i
     values = torch.empty((q, top_k), device=keys.device, dtype=torch.float32)
     indices = torch.empty((q, top_k), device=keys.device, dtype=torch.int64)
     chunk = max(1, min(q, SIM_WORKSPACE_BYTES // (4 * n)))

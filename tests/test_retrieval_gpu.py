@@ -165,8 +165,9 @@ def test_duplicate_keys_tie_order(rt):
 
 
 # ------------------------------------------------------------------ size-independent properties at full size
-def test_topk_properties_at_scale(rt):
-    n, q, k, p = 65536, 512, 600, 256
+def test_topk_properties_at_scale(rt, monkeypatch):
+    monkeypatch.setattr(rt, "FUSED_MIN_SIMS", 1)                     # through the filtered path (find_matches_device's own
+    n, q, k, p = 65536, 512, 600, 256                                   # threshold is 1e8 similarities)
     g = torch.Generator(device=DEV).manual_seed(3)
     keys = torch.randn(n, p, device=DEV, generator=g)
     query = torch.randn(q, p, device=DEV, generator=g) + 0.5 * keys[:q]
@@ -189,6 +190,49 @@ def test_topk_properties_at_scale(rt):
     assert_close(ex.cpu().numpy(), np.full((q, 40), 2.5), 1e-6, what="constant expression")
     nb = keys[i[:4]]                                                               # (4, k, p)
     assert (emb[:4] <= nb.max(1).values + 1e-5).all() and (emb[:4] >= nb.min(1).values - 1e-5).all()
+
+
+# ------------------------------------------------------------------ fused similarity + top-k (no (Q, N) matrix in HBM)
+def _materialised(rt, query, keys, k):
+    return rt.topk_rows(rt.cosine_similarity_matrix(query, keys), k)
+
+
+@pytest.mark.parametrize("n,q,k", [(20000, 300, 200), (65536, 257, 600), (8192, 64, 1), (100000, 128, 50)])
+def test_find_matches_filtered_equals_materialised(rt, n, q, k):
+    """mcl_gemm's threshold-filter epilogue + mcl_topk_rows_indexed against the materialised similarity + mcl_topk_rows:
+    the same values bit for bit and the same indices, no row recomputed on well-mixed data."""
+    g = torch.Generator(device=DEV).manual_seed(n + k)
+    keys = rt.l2_normalize(torch.randn(n, 256, device=DEV, generator=g))
+    query = rt.l2_normalize(torch.randn(q, 256, device=DEV, generator=g) + 0.3 * keys[torch.randint(0, n, (q,), device=DEV, generator=g)])
+    v1, i1, redo = rt.find_matches_filtered(query, keys, k)
+    v0, i0 = _materialised(rt, query, keys, k)
+    assert torch.equal(v1, v0) and torch.equal(i1, i0)
+    assert redo == 0
+    v2, i2, _ = rt.find_matches_filtered(query, keys, k)
+    assert torch.equal(v2, v1) and torch.equal(i2, i1)                      # run to run (the candidate order is not fixed)
+
+
+def test_find_matches_filtered_recomputes_rows_the_threshold_missed(rt):
+    """Exactness does not depend on the sample: (a) the sampled keys are the query's BEST ones (threshold too high: fewer than k
+    candidates), (b) a cluster of near-duplicates overflows a list, (c) exact duplicates tie at the k-th value (the cut must
+    follow the key index) -- those rows are recomputed on the materialised path and every result equals it."""
+    n, q, k = 16384, 48, 100
+    g = torch.Generator(device=DEV).manual_seed(7)
+    keys = torch.randn(n, 256, device=DEV, generator=g)
+    query = torch.randn(q, 256, device=DEV, generator=g)
+    step = n // min(n, rt.FUSED_SAMPLE)
+    keys[::step][: rt.FUSED_SAMPLE] += 3.0 * query[0]                      # (a) every sampled key is close to query 0
+    keys[5000:5000 + 9000:1] = keys[5000:5000 + 9000] * 0.05 + query[1]    # (b) 9000 near-copies of query 1: list overflow
+    keys[200:260] = keys[200]                                              # (c) 60 exact duplicates ...
+    query[2] = keys[200] + 0.01 * torch.randn(256, device=DEV, generator=g)   # ... that are query 2's best matches, cut at k = 100? no:
+    keys[300:420] = keys[300]                                              #     120 duplicates: the k-th value IS inside the tie
+    query[3] = keys[300]
+    kn, qn = rt.l2_normalize(keys), rt.l2_normalize(query)
+    v1, i1, redo = rt.find_matches_filtered(qn, kn, k)
+    v0, i0 = _materialised(rt, qn, kn, k)
+    assert redo >= 2
+    assert torch.equal(v1, v0) and torch.equal(i1, i0)
+    assert i1[3].tolist() == list(range(300, 400))                          # ties cut by key index, as the materialised path does
 
 
 # ------------------------------------------------------------------ embedding extraction (evel_her2st.py:41-69)

@@ -55,11 +55,19 @@ def main():
         t_avg = timeit(lambda: rt.weighted_average_device(key, expr, qry, idx, ord_))
         t_all = timeit(lambda: rt.weighted_average_device(key, expr, qry, rt.find_matches_device(key, qry, k)[1], ord_))
         t_torch = timeit(lambda: torch.topk(sim, k), iters=5)
+        # similarity + top-k without the (Q, N) matrix in HBM (retrieval.find_matches_filtered) against GEMM + top-k on it
+        t_fused = redo = None
+        if n >= rt.FUSED_MIN_KEYS and 16 * k <= n:
+            redo = rt.find_matches_filtered(qn, kn, k)[2]
+            t_fused = timeit(lambda: rt.find_matches_filtered(qn, kn, k))
         rec = {"shape": name, "N": n, "Q": q, "G": g, "top_k": k, "ord": ord_,
                "normalize_ms": round(t_norm, 4), "similarity_gemm_ms": round(t_gemm, 4),
                "similarity_TFs_fp32": round(2.0 * q * n * 256 / t_gemm / 1e9, 1),
                "topk_ms": round(t_topk, 4), "topk_row_GBs": round(4.0 * q * n / t_topk / 1e6, 1),
                "torch_topk_ms": round(t_torch, 4),
+               "similarity_plus_topk_materialised_ms": round(t_gemm + t_topk, 4),
+               "similarity_plus_topk_filtered_ms": None if t_fused is None else round(t_fused, 4),
+               "filtered_rows_recomputed": redo,
                "weighted_average_ms": round(t_avg, 4),
                "gather_GBs": round(4.0 * q * k * (g + 2 * 256) / t_avg / 1e6, 1),
                "end_to_end_ms": round(t_all, 4), "queries_per_s": round(q / t_all * 1e3, 0)}
