@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 7
+#define MCL_ABI_VERSION 8
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -58,6 +58,10 @@ const char* mcl_error_string(int code);
 #define MCL_COMPUTE_BF16 1
 
 typedef struct mcl_gemm_args {
+  uint32_t struct_size;  /* ABI 8: sizeof(mcl_gemm_args) AS THE CALLER COMPILED / DECLARED IT.  The struct travels by pointer and
+                            has grown (ABI 7 appended the flt_* block): mcl_gemm copies min(struct_size, its own sizeof) bytes and
+                            reads every field beyond the caller's size as zero / NULL, so a binding written against a shorter
+                            layout stays valid; a size below the end of `workspace` (the ABI-6 fields) is MCL_EINVAL.  */
   int32_t M, N, K, batch;
   const float* A; int64_t sAm, sAk, sAb;
   const float* B; int64_t sBk, sBn, sBb;
@@ -81,6 +85,10 @@ typedef struct mcl_gemm_args {
 } mcl_gemm_args;
 
 int mcl_gemm(const mcl_gemm_args* args, mcl_stream_t stream);
+/* sizeof(mcl_gemm_args) of THIS library build and the smallest struct_size it accepts (the fields up to `workspace`): a binding
+ * in a language without the header (ctypes, cgo, JNI) checks its own struct declaration against these at load time. */
+uint32_t mcl_gemm_args_size(void);
+uint32_t mcl_gemm_args_min_size(void);
 /* Slices that give a problem with few 64x64 output tiles ~256 workgroups (1 = do not split). */
 int32_t mcl_gemm_auto_ksplit(int32_t M, int32_t N, int32_t K, int32_t batch);
 int64_t mcl_gemm_workspace_floats(int32_t M, int32_t N, int32_t batch, int32_t ksplit);
@@ -555,18 +563,19 @@ int mcl_add_relu(const void* a, const void* b, void* y, int64_t n, int32_t backw
  *              for the backward), norm2 batch mean / biased var / rstd out (fp32 [128] each);
  *   mean / var / rstd  fp32 [Ct] batch statistics of the concat channels: [0, C0) given (mean, rstd read), [C0, Ct) written;
  *   workspace  mcl_dense_block_fwd_workspace_bytes(B, L) bytes, 256-byte aligned; err_flag: device int32, set to 1 if a seam
- *              wait timed out (results invalid; never hangs).
+ *              wait timed out (results invalid; never hangs).  The HOST must read it at its next synchronisation and discard
+ *              the step (mclstexp_amd.ops.check_device_errors raises SeamTimeoutError);
+ *   max_spins  bound of every seam poll loop (0 = the default, 2^19 polls ~ 0.5 s); a test passes 1 to force the timeout path;
+ *   stamps     NULL, or a device buffer of B*L*8 uint64 that the launch fills with in-kernel phase stamps (100 MHz wall
+ *              clock) per image and layer -- per call: the library keeps no state between calls.
  * Algorithmic bytes: the block input read once, z and the new channels written once (+ the weights).                      */
 /* conv1 weights (bf16 [128][C_in_l], C_in_l = C0 + 32*l, k-contiguous rows) of the L layers -> the packed order (same sizes);
  * w1_ptrs / out_ptrs: HOST arrays of L device pointers.  One launch; run it whenever the weights have changed. */
 int mcl_dense_block_pack_w1(const void* const* w1_ptrs, void* const* out_ptrs, int32_t L, int32_t C0, mcl_stream_t stream);
 int64_t mcl_dense_block_fwd_workspace_bytes(int32_t B, int32_t L);
-/* debugging aid: a device buffer of B*L*8 uint64 that later mcl_dense_block_fwd launches fill with in-kernel phase stamps
- * (100 MHz wall clock) per image and layer; NULL switches it off (the default). */
-int mcl_dense_block_debug_stamps(void* stamps);
 int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, int32_t Ct, int32_t C0, int32_t L,
                         const void* const* layer_ptrs, float eps1, float eps2, float* mean, float* var, float* rstd,
-                        void* workspace, int32_t* err_flag, mcl_stream_t stream);
+                        void* workspace, int32_t* err_flag, uint32_t max_spins, void* stamps, mcl_stream_t stream);
 
 /* The same dense block BACKWARD (7 x 7 maps) as one persistent launch: replaces, per layer, mcl_dense_conv3x3_bwd_fix and
  * mcl_dense_bn1_dx_sums (+ their finalize launches and bn2_dz) with the same arithmetic; the two weight gradients of a layer
@@ -578,13 +587,13 @@ int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, int32_t Ct, 
  *              norm2 batch mean, norm2 batch rstd, dz out (B,7,7,128), dyc out (B,7,7,32: the gradient of the layer's output as
  *              consumed), then the fp32 gradients of norm1.weight, norm1.bias, norm2.weight, norm2.bias (ACCUMULATED into);
  *   mean / rstd  fp32 [Ct] batch statistics of the concat channels (forward);
- *   workspace  mcl_dense_block_bwd_workspace_bytes(B, L) bytes, 256-byte aligned; err_flag as in the forward.            */
+ *   workspace  mcl_dense_block_bwd_workspace_bytes(B, L) bytes, 256-byte aligned; err_flag / max_spins / stamps as in the forward. */
 int mcl_dense_block_pack_bwd(const void* const* w1_ptrs, const void* const* w2_ptrs, void* const* w1t_ptrs,
                              void* const* w2t_ptrs, int32_t L, int32_t C0, mcl_stream_t stream);
 int64_t mcl_dense_block_bwd_workspace_bytes(int32_t B, int32_t L);
 int mcl_dense_block_bwd(const void* buf, void* gbuf, int32_t B, int32_t H, int32_t W, int32_t Ct, int32_t C0, int32_t L,
                         const void* const* layer_ptrs, const float* mean, const float* rstd, void* workspace,
-                        int32_t* err_flag, mcl_stream_t stream);
+                        int32_t* err_flag, uint32_t max_spins, void* stamps, mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- K9 Adam with L2 weight decay
  * torch.optim.Adam(lr, betas, eps, weight_decay) as used by train.py:118-120, one fused pass:

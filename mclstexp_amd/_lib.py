@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib: Optional[C.CDLL] = None
 
@@ -31,6 +31,7 @@ c_p = C.c_void_p
 class GemmArgs(C.Structure):
     """struct mcl_gemm_args (include/mclstexp_hip.h)."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("M", c_i), ("N", c_i), ("K", c_i), ("batch", c_i),
         ("A", c_p), ("sAm", c_l), ("sAk", c_l), ("sAb", c_l),
         ("B", c_p), ("sBk", c_l), ("sBn", c_l), ("sBb", c_l),
@@ -46,6 +47,15 @@ class GemmArgs(C.Structure):
     ]
 
 
+
+
+def gemm_args(**kw) -> GemmArgs:
+    """A zeroed ``mcl_gemm_args`` with ``struct_size`` filled in (the library ignores fields beyond it)."""
+    a = GemmArgs(**kw)
+    a.struct_size = C.sizeof(GemmArgs)
+    return a
+
+
 EPI_GELU, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 
@@ -54,6 +64,8 @@ PROTOTYPES = {
     "mcl_abi_version": [],
     "mcl_error_string": [c_i],
     "mcl_gemm": [C.POINTER(GemmArgs), c_p],
+    "mcl_gemm_args_size": [],
+    "mcl_gemm_args_min_size": [],
     "mcl_gemm_auto_ksplit": [c_i, c_i, c_i, c_i],
     "mcl_gemm_workspace_floats": [c_i, c_i, c_i, c_i],
     "mcl_pos_embed_add_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p],
@@ -153,12 +165,11 @@ PROTOTYPES = {
     "mcl_adam_table_step_dev": [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_l, c_p, c_p],
     "mcl_row_slot_update": [c_p, c_p, c_i, c_i, c_p],
     "mcl_dense_block_fwd_workspace_bytes": [c_i, c_i],
-    "mcl_dense_block_debug_stamps": [c_p],
     "mcl_dense_block_pack_w1": [c_p, c_p, c_i, c_i, c_p],
     "mcl_dense_block_pack_bwd": [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "mcl_dense_block_bwd_workspace_bytes": [c_i, c_i],
-    "mcl_dense_block_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
-    "mcl_dense_block_fwd": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p],
+    "mcl_dense_block_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, C.c_uint32, c_p, c_p],
+    "mcl_dense_block_fwd": [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, C.c_uint32, c_p, c_p],
     "mcl_adam_consts_update_hist": [c_p, c_p, c_p, c_p, c_i, c_p],
     "mcl_adam_table_lazy": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_p, c_p, c_i,
                             c_p],
@@ -179,7 +190,7 @@ PROTOTYPES = {
     "mcl_topk_rows_indexed": [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "mcl_knn_weighted_average": [c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
 }
-_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_dense_block_fwd_workspace_bytes": C.c_int64, "mcl_dense_block_bwd_workspace_bytes": C.c_int64, "mcl_bn_workspace_floats": C.c_int64,
+_RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_gemm_args_size": C.c_uint32, "mcl_gemm_args_min_size": C.c_uint32, "mcl_dense_block_fwd_workspace_bytes": C.c_int64, "mcl_dense_block_bwd_workspace_bytes": C.c_int64, "mcl_bn_workspace_floats": C.c_int64,
              "mcl_infonce_fused_workspace_bytes": C.c_int64, "mcl_dense_conv1x1_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_workspace_floats": C.c_int64, "mcl_dense_bn1_bwd_workspace_floats": C.c_int64,
              "mcl_dense_conv3x3_bwd_workspace_floats": C.c_int64, "mcl_conv0_workspace_floats": C.c_int64,
@@ -206,6 +217,9 @@ def load(path: str = LIB_PATH) -> C.CDLL:
     v = lib.mcl_abi_version()
     if v != ABI_VERSION:
         raise RuntimeError(f"{path} has ABI version {v}, host expects {ABI_VERSION}; rebuild")
+    if lib.mcl_gemm_args_size() != C.sizeof(GemmArgs):
+        raise RuntimeError(f"{path}: sizeof(mcl_gemm_args) = {lib.mcl_gemm_args_size()}, the ctypes declaration in "
+                           f"mclstexp_amd/_lib.py has {C.sizeof(GemmArgs)}; the binding and include/mclstexp_hip.h drifted")
     return lib
 
 

@@ -63,6 +63,7 @@ struct DBArgs {
   u64* xch;             // [2L][B][128] (sum, M2) records
   unsigned* flags;      // [2L][B], zero before the launch
   int* err;
+  unsigned max_spins;   // bound of every seam poll loop
   unsigned long long* dbg;   // optional in-kernel phase stamps [B][L][8] (wall clock, 10 ns); nullptr in production
   DBLayer ly[DB_MAXL];
 };
@@ -99,11 +100,11 @@ __device__ __forceinline__ u64 load_rec(const u64* p) {
 }
 
 // One wave polls the B flags of a seam; bounded.  `dead` (LDS) is sticky: after a timeout nobody waits again.
-__device__ __forceinline__ void seam_wait(const unsigned* flags, int B, int tid, int* dead, int* err) {
+__device__ __forceinline__ void seam_wait(const unsigned* flags, int B, int tid, int* dead, int* err, unsigned max_spins) {
   if (tid < 64) {
     if (*dead == 0) {
       bool ok = false;
-      for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+      for (unsigned spins = 0; spins < max_spins; ++spins) {
         ok = true;
         for (int i = tid; i < B; i += 64) ok &= __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         if (__all(ok)) break;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_fwd_kernel(DBArgs a) {
         gsl = ly.g1[cin - 32 + tid];
         bsl = ly.b1[cin - 32 + tid];
       }
-      seam_wait(a.flags + (2 * l - 1) * B, B, tid, dead, a.err);
+      seam_wait(a.flags + (2 * l - 1) * B, B, tid, dead, a.err, a.max_spins);
       DB_STAMP(6);
       {
         const int cp = tid & 15, part = tid >> 4;               // 16 channel pairs x 16 image groups
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_fwd_kernel(DBArgs a) {
     }
 
     // ---------------------------------------------------------------- seam 1: batch statistics of z
-    seam_wait(a.flags + (2 * l) * B, B, tid, dead, a.err);
+    seam_wait(a.flags + (2 * l) * B, B, tid, dead, a.err, a.max_spins);
     DB_STAMP(3);
     {
       const int cp = tid & 63, part = tid >> 6;                  // 64 channel pairs x 4 image groups
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_fwd_kernel(DBArgs a) {
   {
     const int l = a.L;                                            // (seam index 2L - 1)
     const int cin = a.C0 + 32 * l;
-    seam_wait(a.flags + (2 * l - 1) * B, B, tid, dead, a.err);
+    seam_wait(a.flags + (2 * l - 1) * B, B, tid, dead, a.err, a.max_spins);
     const int cp = tid & 15, part = tid >> 4;
     const int per = (B + 15) >> 4, i0 = part * per, i1 = min(B, i0 + per);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -758,6 +759,7 @@ struct DBBArgs {
   unsigned* fb1;        // [L][B]
   unsigned* fb2;        // [L][128] slices (8 channels each)
   int* err;
+  unsigned max_spins;
   unsigned long long* dbg;
   DBBLayer ly[DB_MAXL];
 };
@@ -905,7 +907,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_bwd_kernel(DBBArgs a) {
     __syncthreads();
     if (tid == 0) __hip_atomic_store(a.fa + l * B + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     DBB_STAMP(1);
-    seam_wait(a.fa + l * B, B, tid, dead, a.err);
+    seam_wait(a.fa + l * B, B, tid, dead, a.err, a.max_spins);
     DBB_STAMP(2);
     {
       const int cp = tid & 63, part = tid >> 6;                      // 64 channel pairs x 4 image groups
@@ -1077,7 +1079,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_bwd_kernel(DBBArgs a) {
     DBB_STAMP(4);
     // ------------------------------------------------------------ seam B, hop 1: slice s = channels [8s, 8s+8), owner s % B
     const int nslice = cin >> 3;
-    if (img < nslice) seam_wait(a.fb1 + l * B, B, tid, dead, a.err);
+    if (img < nslice) seam_wait(a.fb1 + l * B, B, tid, dead, a.err, a.max_spins);
     DBB_STAMP(5);
     for (int s = img; s < nslice; s += B) {
       __syncthreads();
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(256, 1) void dense_block_bwd_kernel(DBBArgs a) {
       if (tid == 0) __hip_atomic_store(a.fb2 + l * 128 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ------------------------------------------------------------ hop 2: every slice of this pass is published
-    seam_wait(a.fb2 + l * 128, nslice, tid, dead, a.err);
+    seam_wait(a.fb2 + l * 128, nslice, tid, dead, a.err, a.max_spins);
     DBB_STAMP(6);
   }
 
@@ -1200,15 +1202,18 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(PackBArgs p) {
 
 constexpr size_t DBB_LDS = 49 * 2048 + 49 * 256 + 64 * 256 + 82 * 64 + 4 * 49 * 64 + 5 * 128 * 4 + 64 + 128;
 
-static unsigned long long* g_db_stamps = nullptr;
+constexpr unsigned DB_DEFAULT_SPINS = 1u << 19;   // x (B flag loads + s_sleep 8) ~ 0.5 s
+
+// Every workgroup of a persistent launch must be resident at once (the seams are all-to-all): one image per CU at most.  Asked of
+// the runtime on every call -- a host-side query, no device work; no process-global cache (the library keeps no state).
+template <typename K>
+static bool db_fits(K kernel, size_t lds, int B) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, lds) != hipSuccess) return false;
+  return per_cu >= 1 && B <= mcl_cu_count();
+}
 
 }  // namespace
-
-// debugging aid (tools/bench_dense_block.py): device buffer of B*L*8 uint64 that later launches fill with in-kernel phase stamps
-extern "C" int mcl_dense_block_debug_stamps(void* stamps) {
-  g_db_stamps = reinterpret_cast<unsigned long long*>(stamps);
-  return MCL_OK;
-}
 
 extern "C" int mcl_dense_block_pack_w1(const void* const* w1_ptrs, void* const* out_ptrs, int32_t L, int32_t C0,
                                        mcl_stream_t stream) {
@@ -1237,7 +1242,7 @@ extern "C" int64_t mcl_dense_block_fwd_workspace_bytes(int32_t B, int32_t L) {
 
 extern "C" int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, int32_t Ct, int32_t C0, int32_t L,
                                    const void* const* layer_ptrs, float eps1, float eps2, float* mean, float* var, float* rstd,
-                                   void* workspace, int32_t* err_flag, mcl_stream_t stream) {
+                                   void* workspace, int32_t* err_flag, uint32_t max_spins, void* stamps, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!buf || !layer_ptrs || !mean || !var || !rstd || !workspace || !err_flag || B <= 0 || L <= 0) return MCL_EINVAL;
   if (H != MAPW || W != MAPW || L > DB_MAXL || (C0 % 32) || C0 <= 0 || Ct != C0 + 32 * L || Ct > 1024 ||
@@ -1249,13 +1254,7 @@ extern "C" int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, i
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_block_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)DB_LDS);
   }
-  // every workgroup must be resident at once (the seams are all-to-all): one image per CU at most
-  static int per_cu = -1;
-  if (per_cu < 0 &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dense_block_fwd_kernel), 256, DB_LDS) !=
-          hipSuccess)
-    per_cu = 0;
-  if (per_cu < 1 || B > mcl_cu_count()) return MCL_EUNSUPPORTED;
+  if (!db_fits(dense_block_fwd_kernel, DB_LDS, B)) return MCL_EUNSUPPORTED;
   DBArgs a;
   a.buf = reinterpret_cast<bf16_t*>(buf);
   a.Ct = Ct;
@@ -1271,7 +1270,8 @@ extern "C" int mcl_dense_block_fwd(void* buf, int32_t B, int32_t H, int32_t W, i
   const size_t flag_bytes = ((size_t)2 * L * B * 4 + 255) & ~(size_t)255;
   a.xch = reinterpret_cast<u64*>(reinterpret_cast<unsigned char*>(workspace) + flag_bytes);
   a.err = err_flag;
-  a.dbg = g_db_stamps;
+  a.max_spins = max_spins ? max_spins : DB_DEFAULT_SPINS;
+  a.dbg = reinterpret_cast<unsigned long long*>(stamps);
   for (int l = 0; l < L; ++l) {
     const void* const* p = layer_ptrs + 10 * l;
     for (int k = 0; k < 10; ++k)
@@ -1329,7 +1329,7 @@ extern "C" int64_t mcl_dense_block_bwd_workspace_bytes(int32_t B, int32_t L) {
 
 extern "C" int mcl_dense_block_bwd(const void* buf, void* gbuf, int32_t B, int32_t H, int32_t W, int32_t Ct, int32_t C0,
                                    int32_t L, const void* const* layer_ptrs, const float* mean, const float* rstd,
-                                   void* workspace, int32_t* err_flag, mcl_stream_t stream) {
+                                   void* workspace, int32_t* err_flag, uint32_t max_spins, void* stamps, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
   if (!buf || !gbuf || !layer_ptrs || !mean || !rstd || !workspace || !err_flag || B <= 0 || L <= 0) return MCL_EINVAL;
   if (H != MAPW || W != MAPW || L > DB_MAXL || (C0 % 32) || C0 <= 0 || Ct != C0 + 32 * L || Ct > 1024 ||
@@ -1342,12 +1342,7 @@ extern "C" int mcl_dense_block_bwd(const void* buf, void* gbuf, int32_t B, int32
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_block_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)DBB_LDS);
   }
-  static int per_cu = -1;
-  if (per_cu < 0 &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dense_block_bwd_kernel), 256, DBB_LDS) !=
-          hipSuccess)
-    per_cu = 0;
-  if (per_cu < 1 || B > mcl_cu_count()) return MCL_EUNSUPPORTED;
+  if (!db_fits(dense_block_bwd_kernel, DBB_LDS, B)) return MCL_EUNSUPPORTED;
   DBBArgs a;
   a.buf = (const bf16_t*)buf;
   a.gbuf = (bf16_t*)gbuf;
@@ -1369,7 +1364,8 @@ extern "C" int mcl_dense_block_bwd(const void* buf, void* gbuf, int32_t B, int32
   w += (size_t)L * B * 1024 * 8;
   a.kacc = reinterpret_cast<u64*>(w);
   a.err = err_flag;
-  a.dbg = g_db_stamps;
+  a.max_spins = max_spins ? max_spins : DB_DEFAULT_SPINS;
+  a.dbg = reinterpret_cast<unsigned long long*>(stamps);
   for (int l = 0; l < L; ++l) {
     const void* const* p = layer_ptrs + 15 * l;
     for (int k = 0; k < 15; ++k)

@@ -12,6 +12,8 @@
 // (contiguous along K, or along M/N), vectorised to 16-byte loads when base and leading dimension
 // allow and falling back to dword loads for the odd gene counts (785, 171, 685, 3467).
 #include "common.h"
+#include <cstddef>
+#include <cstring>
 #include <stdlib.h>
 
 namespace {
@@ -323,9 +325,21 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 
 }  // namespace
 
-extern "C" int mcl_gemm(const mcl_gemm_args* a, mcl_stream_t stream) {
+// The struct travels by pointer and grows between ABI versions: never read past what the caller declared.
+static constexpr uint32_t kGemmArgsMin = (uint32_t)(offsetof(mcl_gemm_args, workspace) + sizeof(float*));
+extern "C" uint32_t mcl_gemm_args_size(void) { return (uint32_t)sizeof(mcl_gemm_args); }
+extern "C" uint32_t mcl_gemm_args_min_size(void) { return kGemmArgsMin; }
+
+extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!a || !a->A || !a->B || (!a->C && !a->flt_thr)) return MCL_EINVAL;
+  if (!caller_args) return MCL_EINVAL;
+  const uint32_t sz = caller_args->struct_size;
+  if (sz < kGemmArgsMin) return MCL_EINVAL;
+  mcl_gemm_args local;
+  memset(&local, 0, sizeof(local));
+  memcpy(&local, caller_args, sz < sizeof(local) ? sz : sizeof(local));   // fields beyond the caller's size stay zero / NULL
+  const mcl_gemm_args* a = &local;
+  if (!a->A || !a->B || (!a->C && !a->flt_thr)) return MCL_EINVAL;
   if (a->flt_thr && (!a->flt_cnt || !a->flt_val || !a->flt_idx || a->flt_cap <= 0 || a->batch != 1 || a->ksplit > 1 || a->bias ||
                      a->resid || a->pre_out || a->flags))
     return MCL_EINVAL;

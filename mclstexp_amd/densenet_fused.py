@@ -728,13 +728,29 @@ CAPTURE_MISC: Optional[list] = None
 
 
 USE_BLOCK_PERSISTENT = os.environ.get("MCL_BLOCK_PERSIST", "1") != "0"
-_block_err: dict = {}
+# test hook (tests/test_dense_block_gpu.py): bound of the seam polls of the persistent kernels; 0 = the library's default (2^19)
+SEAM_MAX_SPINS = 0
+# profiling hook (tools/bench_dense_block.py): a uint64 device tensor of B*L*8 words the persistent launches fill with in-kernel
+# phase stamps; None (the default) = off.  Passed per call: the library keeps no state.
+BLOCK_STAMPS: Optional[Tensor] = None
+
+
+def _stamps_ptr():
+    return BLOCK_STAMPS.data_ptr() if BLOCK_STAMPS is not None else None
+_cu_count: dict = {}
+
+
+def _cus(device) -> int:
+    n = _cu_count.get(device.index)
+    if n is None:
+        n = _cu_count[device.index] = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    return n
 
 
 def _block_persistent_ok(buf: Tensor, params, growth: int, L: int, C0: int, dt: torch.dtype) -> bool:
     B, Ct, H, W = buf.shape
     if not (USE_BLOCK_PERSISTENT and H == 7 and W == 7 and growth == 32 and dt == torch.bfloat16 and L <= 24 and Ct <= 1024
-            and C0 % 32 == 0 and B <= 256 and buf.is_cuda):
+            and C0 % 32 == 0 and buf.is_cuda and B <= _cus(buf.device)):
         return False
     for l in range(L):
         w1, w2 = params[6 * l + 2], params[6 * l + 5]
@@ -744,10 +760,10 @@ def _block_persistent_ok(buf: Tensor, params, growth: int, L: int, C0: int, dt: 
 
 
 def block_persistent_error(device) -> bool:
-    """True if a persistent dense-block launch on ``device`` gave up waiting at a seam since the last call (host sync)."""
-    t = _block_err.get(device.index)
-    if t is None:
-        return False
+    """True if a persistent dense-block launch on ``device`` gave up waiting at a seam since the last check (host sync).  The
+    production path raises instead: ``ops.check_device_errors`` (train.train, TrainStep.check_errors / its polling)."""
+    from . import ops as _ops
+    t = _ops.block_seam_error_flag(device)
     bad = int(t.item()) != 0
     if bad:
         t.zero_()
@@ -804,16 +820,14 @@ def dense_block_bwd_persistent(buf: Tensor, gbuf: Tensor, params, wcast, zs, sta
     nbytes = Lb.mcl_dense_block_bwd_workspace_bytes(B, L)
     ws = _ws((nbytes + 255 + 3) // 4 + 64, dev)
     base = (ws.data_ptr() + 255) & ~255
-    err = _block_err.get(dev.index)
-    if err is None:
-        err = torch.zeros(1, device=dev, dtype=torch.int32)
-        _block_err[dev.index] = err
+    from . import ops as _ops
+    err = _ops.block_seam_error_flag(dev)
     px, S, C_, ld = _rows(buf)
     pg, S2, C2, ldg = _rows(gbuf)
     if ld != Ct or ldg != Ct:
         raise RuntimeError("dense_block_bwd_persistent: the concat and gradient buffers must be dense channels-last")
     check(Lb.mcl_dense_block_bwd(px, pg, B, H, W, Ct, C0, L, arr, stats.mean.data_ptr(), stats.rstd.data_ptr(), base,
-                                 err.data_ptr(), _stream()), "mcl_dense_block_bwd")
+                                 err.data_ptr(), SEAM_MAX_SPINS, _stamps_ptr(), _stream()), "mcl_dense_block_bwd")
     return dzs, dycs
 
 
@@ -851,15 +865,13 @@ def dense_block_fwd_persistent(buf: Tensor, params, wcast, stats: "_BlockStats",
     nbytes = Lb.mcl_dense_block_fwd_workspace_bytes(B, L)
     ws = _ws((nbytes + 255 + 3) // 4 + 64, dev)
     base = (ws.data_ptr() + 255) & ~255
-    err = _block_err.get(dev.index)
-    if err is None:
-        err = torch.zeros(1, device=dev, dtype=torch.int32)
-        _block_err[dev.index] = err
+    from . import ops as _ops
+    err = _ops.block_seam_error_flag(dev)
     px, S, C_, ld = _rows(buf)
     if ld != Ct:
         raise RuntimeError("dense_block_fwd_persistent: the concat buffer must be dense channels-last")
     check(Lb.mcl_dense_block_fwd(px, B, H, W, Ct, C0, L, arr, eps1, eps2, stats.mean.data_ptr(), stats.var.data_ptr(),
-                                 stats.rstd.data_ptr(), base, err.data_ptr(), _stream()), "mcl_dense_block_fwd")
+                                 stats.rstd.data_ptr(), base, err.data_ptr(), SEAM_MAX_SPINS, _stamps_ptr(), _stream()), "mcl_dense_block_fwd")
     return zs
 
 

@@ -56,6 +56,9 @@ class TrainStep:
         self._tables_stream = None
         self._img_bf16 = False
         self._in_sig = {}
+        self.error_poll_every = int(os.environ.get("MCL_ERROR_POLL_EVERY", "16"))
+        self._err_host = None
+        self._err_event = None
 
     # ------------------------------------------------------------------ eager (reference order, train.py:36-39)
     def _eager(self, batch) -> Tensor:
@@ -386,7 +389,46 @@ class TrainStep:
             v == self.static_in["expression"].shape[0] for v in sizes)
         return len(set(sizes)) == 1
 
+    # ------------------------------------------------------------------ device error words (ops.device_error_words)
+    def _device(self):
+        return next(self.model.parameters()).device
+
+    def check_errors(self) -> None:
+        """Host sync: raises IndexError (position outside the tables) / ops.SeamTimeoutError (a persistent dense-block launch
+        timed out at a BatchNorm seam: that step is invalid) if any step since the last check flagged one."""
+        from . import ops
+        self._err_event = None
+        ops.check_device_errors(self._device())
+
+    def _poll_errors(self) -> None:
+        """The same check WITHOUT a host sync: every ``error_poll_every`` calls the device's error words are copied to pinned
+        host memory behind the step; a later call finds the copy finished and raises -- at most ``error_poll_every`` + 1 steps
+        after the faulty one (the step that timed out and its successors are invalid: the caller restores a checkpoint or
+        rebuilds the model).  ``error_poll_every = 0`` switches the polling off (``check_errors`` remains)."""
+        if not self.error_poll_every or not torch.cuda.is_available():
+            return
+        from . import ops
+        dev = self._device()
+        if dev.type != "cuda":
+            return
+        if self._err_event is not None and self._err_event.query():
+            self._err_event = None
+            words = self._err_host.tolist()
+            ops.raise_for_error_words(words, ops.device_error_words(dev).zero_)
+        if self._err_event is None and self.calls % self.error_poll_every == 0:
+            if self._err_host is None:
+                self._err_host = torch.zeros(ops._ERR_WORDS, dtype=torch.int32).pin_memory()
+            self._err_host.copy_(ops.device_error_words(dev), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._err_event = ev
+
     def __call__(self, batch: Dict[str, Tensor]) -> Tensor:
+        out = self._step(batch)
+        self._poll_errors()
+        return out
+
+    def _step(self, batch: Dict[str, Tensor]) -> Tensor:
         batch = {k: batch[k] for k in ("image", "expression", "position")}
         self.calls += 1
         equal = self._agree_sizes(batch)

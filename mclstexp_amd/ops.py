@@ -93,7 +93,7 @@ def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, 
     """mcl_gemm with explicit strides; *_off are element offsets into A/B/C's storage views.  ``filt`` = (thr (M,), cnt (M,)
     int32 zeroed, cand_val (M, cap), cand_idx (M, cap) int32): nothing is stored to C (pass None); products >= thr[row] are
     appended to the row's candidate list (retrieval's fused similarity + top-k)."""
-    a = GemmArgs()
+    a = _lib.gemm_args()
     a.M, a.N, a.K, a.batch = M, N, K, batch
     a.A, a.sAm, a.sAk, a.sAb = A.data_ptr() + 4 * a_off, sAm, sAk, sAb
     a.B, a.sBk, a.sBn, a.sBb = B.data_ptr() + 4 * b_off, sBk, sBn, sBb
@@ -479,29 +479,62 @@ def embed_rowgrad(d_out: Tensor, idx: Tensor) -> RowSparseGrad:
     return RowSparseGrad(owner, rows)
 
 
-# Positions outside [0, table rows) are clamped by the kernel and flagged in a device word instead of raising in the middle
-# of an enqueue-only step; ``check_position_errors`` turns the flag into nn.Embedding's IndexError at a point where the
-# host synchronises anyway (train() does it with the loss.item() of its meter).
-_pos_err = {}
+# Device-side error words.  The kernels never raise in the middle of an enqueue-only step: a position outside [0, table rows)
+# is clamped and flagged (word 0: nn.Embedding would raise IndexError), a persistent dense-block launch that gave up waiting at
+# a BatchNorm seam flags word 1 (its results are invalid: csrc/dense_block.hip).  ``check_device_errors`` turns the words into
+# exceptions at a point where the host synchronises anyway (train() does it with the loss.item() of its meter, TrainStep polls
+# them without a sync); SURVEY 8(b): no exceptions cross the ABI, the Python wrapper raises.
+ERR_POSITION, ERR_BLOCK_SEAM, _ERR_WORDS = 0, 1, 4
+_err_words = {}
 
 
-def position_error_flag(device) -> Tensor:
-    t = _pos_err.get(device.index)
+class SeamTimeoutError(RuntimeError):
+    """A persistent dense-block kernel timed out at a BatchNorm seam: that step's activations / gradients are invalid."""
+
+
+def device_error_words(device) -> Tensor:
+    t = _err_words.get(device.index)
     if t is None:
-        t = torch.zeros(1, device=device, dtype=torch.int32)
-        _pos_err[device.index] = t
+        t = torch.zeros(_ERR_WORDS, device=device, dtype=torch.int32)
+        _err_words[device.index] = t
     return t
 
 
-def check_position_errors(device=None) -> None:
-    """Raises IndexError if any batch since the last check held a position outside the tables (host sync)."""
-    for idx, t in list(_pos_err.items()):
+def position_error_flag(device) -> Tensor:
+    return device_error_words(device)[ERR_POSITION:ERR_POSITION + 1]
+
+
+def block_seam_error_flag(device) -> Tensor:
+    return device_error_words(device)[ERR_BLOCK_SEAM:ERR_BLOCK_SEAM + 1]
+
+
+def raise_for_error_words(words, clear=None) -> None:
+    """``words``: the host copy of a device's error words; ``clear``: called before raising (resets the device words)."""
+    if not any(words):
+        return
+    if clear is not None:
+        clear()
+    if words[ERR_BLOCK_SEAM]:
+        raise SeamTimeoutError(
+            "a persistent dense-block launch (csrc/dense_block.hip) timed out waiting for the other images' BatchNorm records: "
+            "its workgroups were not co-resident (GPU shared with another process, CU masking, a long concurrent kernel). "
+            "The step that contained it produced invalid activations and gradients -- discard it; MCL_BLOCK_PERSIST=0 / "
+            "MCL_BLOCK_PERSIST_BWD=0 select the per-layer kernels")
+    if words[ERR_POSITION]:
+        raise IndexError("index out of range in self: a batch held a position outside [0, 65536) "
+                         "(the reference's nn.Embedding raises here, model.py:232-233)")
+
+
+def check_device_errors(device=None) -> None:
+    """Raises IndexError (a position outside the tables) / SeamTimeoutError (a persistent dense-block seam timed out) if any
+    step since the last check flagged one (host sync)."""
+    for idx, t in list(_err_words.items()):
         if device is not None and device.index != idx:
             continue
-        if int(t.item()) != 0:
-            t.zero_()
-            raise IndexError("index out of range in self: a batch held a position outside [0, 65536) "
-                             "(the reference's nn.Embedding raises here, model.py:232-233)")
+        raise_for_error_words(t.tolist(), t.zero_)
+
+
+check_position_errors = check_device_errors      # the name train.py has used since round 1
 
 
 class PosEmbedAddFn(torch.autograd.Function):

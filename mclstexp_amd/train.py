@@ -105,7 +105,9 @@ def train(model, train_dataLoader: Iterable, optimizer, epoch: int, log_every: i
         if step % log_every == 0:
             count = batch["image"].size(0)
             loss_meter.update(loss.item(), count)
-            ops.check_position_errors()          # nn.Embedding's IndexError, at the sync point the meter forces anyway
+            # device error words, at the sync point the meter forces anyway: nn.Embedding's IndexError for a position outside
+            # the tables, SeamTimeoutError if a persistent dense-block launch gave up at a BatchNorm seam (step invalid)
+            ops.check_device_errors()
     return loss_meter
 
 

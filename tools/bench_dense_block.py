@@ -47,12 +47,12 @@ for mode in (True, False, True, False):
 from mclstexp_amd import _lib
 L = 16
 st = torch.zeros(B * L * 8 + 64, device=DEV, dtype=torch.int64)
-_lib.lib().mcl_dense_block_debug_stamps(st.data_ptr())
+dn.BLOCK_STAMPS = st
 dn.USE_BLOCK_PERSISTENT = True
 fwd(); torch.cuda.synchronize()
 st.zero_()
 fwd(); torch.cuda.synchronize()
-_lib.lib().mcl_dense_block_debug_stamps(None)
+dn.BLOCK_STAMPS = None
 cs = st[B * L * 8:].cpu().view(16, 4)
 t = st[:B * L * 8].view(B, L, 8).double().cpu() * 0.01          # us
 def med(x):
@@ -101,10 +101,10 @@ print(json.dumps({"forward(persistent)+backward eager, us": res}))
 st = torch.zeros(B * L * 8 + 64, device=DEV, dtype=torch.int64)
 dn.USE_BLOCK_PERSISTENT_BWD = True
 fwd_bwd(); torch.cuda.synchronize()
-_lib.lib().mcl_dense_block_debug_stamps(st.data_ptr())
+dn.BLOCK_STAMPS = st
 # (the forward kernel writes the same buffer first; the backward's stamps overwrite them)
 fwd_bwd(); torch.cuda.synchronize()
-_lib.lib().mcl_dense_block_debug_stamps(None)
+dn.BLOCK_STAMPS = None
 t = st[:B * L * 8].view(B, L, 8).double().cpu() * 0.01
 print("BACKWARD phase medians over images, per layer l = 15 .. 0 (us)")
 order = list(range(L - 1, -1, -1))
