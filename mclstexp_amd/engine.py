@@ -30,13 +30,18 @@ Tensor = torch.Tensor
 
 class TrainStep:
     def __init__(self, model, optimizer, reducer=None, graphs: bool = True, warmup: int = 3,
-                 single_graph: Optional[bool] = None, equal_shards: bool = False, strict_shards: bool = False):
+                 single_graph: Optional[bool] = None, equal_shards: bool = False, strict_shards: Optional[bool] = None,
+                 allow_short_last_batch: bool = False):
         """``equal_shards``: the caller guarantees that every rank sees the same per-rank batch size on every step
         (DistributedSampler with drop_last, synthetic data): the per-step host size exchange -- a blocking gloo
-        all-gather that keeps the ranks' host threads in lock-step -- is skipped."""
+        all-gather that keeps the ranks' host threads in lock-step -- is skipped.  A step whose per-rank size differs from
+        the first one then RAISES (a different size on ONE rank would send the ranks down different paths with mismatched
+        collective shapes, and without the exchange that cannot be detected across ranks); ``allow_short_last_batch=True``
+        is the explicit promise that such a step is a uniformly smaller last batch on EVERY rank (no drop_last with a
+        dataset size that leaves the same remainder everywhere): it then takes the eager path on all of them."""
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.equal_shards = bool(equal_shards)
-        self.strict_shards = bool(strict_shards)
+        self.strict_shards = (not allow_short_last_batch) if strict_shards is None else bool(strict_shards)
         self.graphs = graphs and torch.cuda.is_available()
         self.warmup = max(2, warmup)
         self.calls = 0
@@ -367,13 +372,14 @@ class TrainStep:
             # the caller promised that every rank sees the SAME per-rank batch size on every step (a different size on ONE rank
             # would send the ranks down different paths with mismatched collective shapes; it cannot be detected across ranks
             # without the exchange this flag switches off).  A size that differs from the captured one -- a uniformly smaller last
-            # batch without drop_last -- takes the eager path on every rank; ``strict_shards`` turns it into an error instead.
+            # batch without drop_last -- is an error unless the caller passed allow_short_last_batch=True (then: eager on every rank).
             n = int(batch["expression"].shape[0])
             if self._first_size is None:
                 self._first_size = n
             elif n != self._first_size and self.strict_shards:
-                raise RuntimeError(f"TrainStep(equal_shards=True, strict_shards=True): this step's per-rank batch has {n} pairs, "
-                                   f"the first one had {self._first_size}")
+                raise RuntimeError(f"TrainStep(equal_shards=True): this step's per-rank batch has {n} pairs, the first one had "
+                                   f"{self._first_size}; pass allow_short_last_batch=True if EVERY rank sees the same smaller "
+                                   "last batch, or equal_shards=False for the per-step size exchange")
             self._all_regular = (self.static_in is not None
                                  and batch["expression"].shape[0] == self.static_in["expression"].shape[0])
             return True

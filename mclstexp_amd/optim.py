@@ -56,6 +56,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._dev: Dict[int, dict] = {}
         self._began = False                       # this step's constants are already on the device (early table update)
         self._group_of: Dict[int, int] = {}       # id(param) -> group index
+        self._hook_handles: list = []             # what attach_model() registered on the model (detach_model removes them)
+        self._model_ref = None
 
     # ------------------------------------------------------------------ wiring
     def attach_model(self, model) -> "FusedAdam":
@@ -70,15 +72,26 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 self._group_of[id(p)] = gi
+        prev = getattr(model, "_mcl_table_owner", None)
+        if prev is not None and prev is not self:
+            # a second optimizer for the same model: the first one's pending replays must land in the tables before this
+            # one declares every row current, and its hooks must not pile up on the model
+            prev.materialize_tables()
+            prev.detach_model()
+        self._model_ref = model
         if self._tables and self.lazy_tables:
             # the forward brings the rows it gathers up to date (model._spot_features); whoever reads a whole table
-            # through the module API gets it materialised first
+            # through the module API gets it materialised first.  Bound methods (picklable with the optimizer), handles
+            # kept for detach_model().
             model._table_catchup = self.catch_up
-            model.register_state_dict_pre_hook(lambda mod, prefix, keep_vars: self.materialize_tables())
+            model._mcl_table_owner = self
+            hs = self._hook_handles
+            hs.append(model.register_state_dict_pre_hook(self._hook_state_dict_pre))
             if hasattr(model, "register_load_state_dict_pre_hook"):
-                model.register_load_state_dict_pre_hook(lambda *a, **k: self.materialize_tables())
+                hs.append(model.register_load_state_dict_pre_hook(self._hook_any))
             for emb in (model.x_embed, model.y_embed):
-                emb.register_forward_pre_hook(lambda mod, inp: self.materialize_tables())
+                hs.append(emb.register_forward_pre_hook(self._hook_any))
+                hs.append(emb.register_state_dict_pre_hook(self._hook_state_dict_pre))   # model.x_embed.state_dict()
         # The position tables can be updated as soon as their gradient rows exist -- from inside PosEmbedAddFn.backward, on
         # the side stream, under the latency-bound part of the image backbone's backward -- instead of in step().  That
         # changes what a bare ``loss.backward()`` does, so it is engine.TrainStep that switches it on, only while it captures
@@ -87,11 +100,35 @@ class FusedAdam(torch.optim.Optimizer):
         # load_state_dict() into a live model rewrites the flat fp32 buffer behind the bf16 shadows' back (captured
         # HIP graphs read the shadows directly, so the lazy per-parameter check in shadow() cannot catch that case)
         if hasattr(model, "register_load_state_dict_post_hook"):
-            model.register_load_state_dict_post_hook(lambda mod, incompatible: self._refresh_shadows())
+            self._hook_handles.append(model.register_load_state_dict_post_hook(self._hook_loaded))
         # bf16 shadow weights for the fused backbone: one flat cast per step instead of ~120 per-weight casts
         from . import densenet_fused
         densenet_fused.set_weight_provider(self.shadow)
         return self
+
+    def _hook_state_dict_pre(self, module, prefix, keep_vars):
+        self.materialize_tables()
+
+    def _hook_any(self, *args, **kwargs):
+        self.materialize_tables()
+
+    def _hook_loaded(self, module, incompatible):
+        self._refresh_shadows()
+
+    def detach_model(self) -> None:
+        """Removes every hook attach_model() registered (the tables are materialised first)."""
+        if self._lazy_active():
+            self.materialize_tables()
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        m = self._model_ref
+        if m is not None:
+            if getattr(m, "_mcl_table_owner", None) is self:
+                m._mcl_table_owner = None
+            if getattr(m, "_table_catchup", None) == self.catch_up:
+                m._table_catchup = None
+        self._model_ref = None
 
     # ------------------------------------------------------------------ flat buffers
     def _build_flat(self, gi: int, group) -> None:
@@ -121,8 +158,15 @@ class FusedAdam(torch.optim.Optimizer):
             p.data = vp
             p.grad = vg
             self._where[id(p)] = (gi, o)
-        self._flat[gi] = {"params": ps, "n": n, "p": flat_p, "g": flat_g,
-                          "m": torch.zeros_like(flat_p), "v": torch.zeros_like(flat_p)}
+        flat_m, flat_v = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+        for p, o in zip(ps, offs):
+            # moments that load_state_dict() parked in self.state before the flat buffers existed (a resumed run)
+            stt = self.state.get(p)
+            if stt and "exp_avg" in stt:
+                flat_m.as_strided(p.shape, p.stride(), o).copy_(stt["exp_avg"])
+                flat_v.as_strided(p.shape, p.stride(), o).copy_(stt["exp_avg_sq"])
+                del self.state[p]
+        self._flat[gi] = {"params": ps, "n": n, "p": flat_p, "g": flat_g, "m": flat_m, "v": flat_v}
 
     def ensure_flat(self) -> None:
         for gi, group in enumerate(self.param_groups):
@@ -229,9 +273,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._begin_step()
         if skipped_tables:
             for t in self._tables.values():
-                stt = self.state.get(t["param"])
-                if stt:
-                    stt["row_step"].fill_(self._step_count + 1)
+                if self.state.get(t["param"]):
+                    self._row_step(t["param"]).fill_(self._step_count + 1)
             self._lazy_flushed_at = self._step_count + 1
         tables_done = self._sink is not None and self._sink.pop("tables_done", False)
         if lazy and tables_pending and not tables_done:
@@ -395,10 +438,20 @@ class FusedAdam(torch.optim.Optimizer):
         if not state:
             state["exp_avg"] = torch.zeros_like(p)
             state["exp_avg_sq"] = torch.zeros_like(p)
-        if "row_step" not in state:
-            # "valid through step" per row: everything is current as of now
-            state["row_step"] = torch.full((p.shape[0],), self._step_count, device=p.device, dtype=torch.int32)
+        self._row_step(p)
         return state
+
+    def _row_step(self, p) -> Tensor:
+        """The int32 "valid through step" stamp per table row.  Kept OUTSIDE ``self.state``: torch's
+        ``Optimizer.load_state_dict`` casts every state tensor of a floating-point parameter to the parameter's dtype, and
+        the kernel would read a float's bits as a step number.  After ``materialize_tables()`` -- which
+        ``state_dict()`` runs -- every row is current, so the stamps carry no information a checkpoint needs."""
+        tab = self._tables[id(p)]
+        rs = tab.get("row_step")
+        if rs is None or rs.device != p.device:
+            # everything is current as of now
+            rs = tab["row_step"] = torch.full((p.shape[0],), self._step_count, device=p.device, dtype=torch.int32)
+        return rs
 
     def _lazy_groups(self):
         """[(group index, [table params])] -- the tables of one param group share its step counter and history."""
@@ -422,8 +475,8 @@ class FusedAdam(torch.optim.Optimizer):
             def ptr(t):
                 return t.data_ptr() if t is not None else None
             check(L.mcl_adam_table_lazy(p0.data_ptr(), s0["exp_avg"].data_ptr(), s0["exp_avg_sq"].data_ptr(),
-                                        s0["row_step"].data_ptr(), ptr(p1), ptr(s1["exp_avg"]) if two else None,
-                                        ptr(s1["exp_avg_sq"]) if two else None, ptr(s1["row_step"]) if two else None,
+                                        self._row_step(p0).data_ptr(), ptr(p1), ptr(s1["exp_avg"]) if two else None,
+                                        ptr(s1["exp_avg_sq"]) if two else None, ptr(self._row_step(p1)) if two else None,
                                         p0.shape[0], p0.shape[1], ptr(pos), ptr(own[0]), ptr(own[1]) if two else None,
                                         n_owner if n_owner is not None else p0.shape[0], ptr(gr[0]),
                                         ptr(gr[1]) if two else None, ld_rg, d["step"].data_ptr(), d["hist"].data_ptr(),
@@ -472,25 +525,69 @@ class FusedAdam(torch.optim.Optimizer):
             self.materialize_tables()
 
     def state_dict(self):
+        """torch.optim.Optimizer.state_dict() layout (``exp_avg`` / ``exp_avg_sq`` per parameter, snapshots) + ``mcl_step_count``.
+        The flat-managed parameters' moments live in the flat buffers, not in ``self.state``: they are exported here."""
         self.materialize_tables()
-        sd = super().state_dict()
+        added = []
+        for f in self._flat.values():
+            for p in f.get("params", []):
+                _, o = self._where[id(p)]
+                self.state[p] = {"exp_avg": f["m"].as_strided(p.shape, p.stride(), o).clone(),
+                                 "exp_avg_sq": f["v"].as_strided(p.shape, p.stride(), o).clone()}
+                added.append(p)
+        try:
+            sd = super().state_dict()
+        finally:
+            for p in added:
+                del self.state[p]
         sd["mcl_step_count"] = self._step_count
         return sd
 
     def load_state_dict(self, state_dict):
+        """Resume: the checkpoint's tables are materialised as of its step count (``state_dict()`` does that), so every row is
+        stamped current at that count and the replay only ever needs constants recorded after the resume.  Tensors that a
+        captured step graph may already point to (table moments, row stamps, flat moments) are overwritten IN PLACE."""
         state_dict = dict(state_dict)
         n = state_dict.pop("mcl_step_count", None)
+        if self._lazy_active():
+            self.materialize_tables()            # pending replays belong to the state that is about to be overwritten
+        live = {}
+        for tab in self._tables.values():
+            stt = self.state.get(tab["param"])
+            if stt:
+                live[id(tab["param"])] = dict(stt)
         super().load_state_dict(state_dict)
+        for tab in self._tables.values():
+            p = tab["param"]
+            stt = self.state.get(p)
+            if not stt:
+                continue
+            for k in ("row_step", "row_slot"):      # checkpoints written while these still lived in the state
+                stt.pop(k, None)
+            for k, old in live.get(id(p), {}).items():
+                if k in stt and torch.is_tensor(old) and old.shape == stt[k].shape:
+                    old.copy_(stt[k])
+                    stt[k] = old
+        for f in self._flat.values():               # flat buffers already built: the loaded moments go into them
+            for q in f.get("params", []):
+                stt = self.state.get(q)
+                if stt and "exp_avg" in stt:
+                    _, o = self._where[id(q)]
+                    f["m"].as_strided(q.shape, q.stride(), o).copy_(stt["exp_avg"])
+                    f["v"].as_strided(q.shape, q.stride(), o).copy_(stt["exp_avg_sq"])
+                    del self.state[q]
+        # (not built yet -- a fresh optimizer: the moments stay parked in self.state until _build_flat() adopts them)
         if n is not None:
             self._step_count = int(n)
-            for d in self._dev.values():
-                d["step"].fill_(self._step_count)
-            for tab in self._tables.values():
-                stt = self.state.get(tab["param"])
-                if stt and "row_step" in stt:
-                    stt["row_step"].fill_(self._step_count)
-            self._lazy_flushed_at = self._step_count
-            self._lazy_dirty = False
+        for d in self._dev.values():
+            d["step"].fill_(self._step_count)
+            d["hyper_host"] = None                  # the loaded param_groups' hyper-parameters are uploaded again
+        for tab in self._tables.values():
+            if tab.get("row_step") is not None:
+                tab["row_step"].fill_(self._step_count)
+        self._lazy_flushed_at = self._step_count
+        self._lazy_dirty = False
+        self._began = False
 
     # ------------------------------------------------------------------ tables
     def _gathered(self):
@@ -511,11 +608,13 @@ class FusedAdam(torch.optim.Optimizer):
         if not state:
             state["exp_avg"] = torch.zeros_like(p)
             state["exp_avg_sq"] = torch.zeros_like(p)
-            state["row_slot"] = torch.full((p.shape[0],), -1, device=p.device, dtype=torch.int32)
+        if tab.get("row_slot") is None or tab["row_slot"].device != p.device:
+            # (outside self.state: load_state_dict would cast the int32 map to the parameter's dtype)
+            tab["row_slot"] = torch.full((p.shape[0],), -1, device=p.device, dtype=torch.int32)
         dout, ix, iy = self._gathered()
         rs = ops.embed_rowgrad(dout, ix if tab["key"] == "ix" else iy)
         B = rs.rows.shape[0]
-        slot = state["row_slot"]
+        slot = tab["row_slot"]
         check(L.mcl_row_slot_update(slot.data_ptr(), rs.owner_idx.data_ptr(), B, 1, st), "mcl_row_slot_update")
         check(L.mcl_adam_table_step_dev(p.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
                                         p.shape[0], p.shape[1], slot.data_ptr(), rs.rows.data_ptr(), rs.rows.stride(0),

@@ -85,44 +85,68 @@ def topk_rows(sim: Tensor, k: int) -> Tuple[Tensor, Tensor]:
 # path is faster -- tools/bench_retrieval.py) and k is a small part of the keys
 FUSED_MIN_KEYS = 8192
 FUSED_MIN_SIMS = 100_000_000
-FUSED_SAMPLE = 4096
+FUSED_SAMPLE = 4096          # smallest key sample
+FUSED_MAX_STRIDE = 64        # ... and the sample grows with N so that it is never sparser than every 64th key
+FUSED_RANK_SLACK = 32        # sample ranks of safety below the expected rank of the k-th best
+
+
+def _filter_plan(n: int, top_k: int) -> Tuple[int, int, int, int]:
+    """(sample size ns, sample stride, threshold rank r in the sample, candidate capacity per query) of the filtered path.
+    The threshold sits at sample rank r = 1.5 k ns / N + slack, so a row's list is expected to hold r N / ns = 1.5 k + slack
+    N / ns candidates -- the slack term grows with the sample's sparsity (with a fixed 4096-key sample it passed any
+    fixed capacity from N ~ 262k on and EVERY row was recomputed).  The sample therefore grows with N (stride <= 64) and the
+    capacity is twice the expectation + 1024: the count's relative spread is ~ 1 / sqrt(r) <= 18 %."""
+    ns = min(n, max(FUSED_SAMPLE, -(-n // FUSED_MAX_STRIDE)))
+    step = n // ns
+    r = min(ns, int(1.5 * top_k * ns / n) + FUSED_RANK_SLACK)
+    expect = r * n / ns
+    cap = int(2 * expect) + 1024
+    return ns, step, r, cap
 
 
 def find_matches_filtered(query: Tensor, keys: Tensor, top_k: int) -> Tuple[Tensor, Tensor, int]:
     """Cosine top-k WITHOUT the (Q, N) similarity matrix in HBM (evel_her2st.py:74-84), exact:
-      1. a strided sample of FUSED_SAMPLE keys gives every query a threshold -- the value at rank ~1.5 k N_s / N of its sample
-         similarities (small GEMM + mcl_topk_rows);
+      1. a strided sample of the keys (>= FUSED_SAMPLE, at least every 64th) gives every query a threshold -- the value at rank
+         ~1.5 k N_s / N of its sample similarities (small GEMM + mcl_topk_rows);
       2. the full similarity GEMM runs with mcl_gemm's FILTER epilogue: products >= the row's threshold are appended to the row's
          candidate list, nothing else is stored;
       3. mcl_topk_rows_indexed selects the top-k of every list (original key indices, equal values ordered by index).
     A row whose list holds fewer than k or more than its capacity, or whose k-th value is an exact tie, is recomputed on the
-    materialised path -- the result is the same as ``topk_rows(cosine_similarity_matrix(...))`` for every input.  Returns
-    (values, indices, number of recomputed rows)."""
+    materialised path -- the result is the same as ``topk_rows(cosine_similarity_matrix(...))`` for every input.  Queries are
+    processed in chunks so that neither the sample similarities + candidate lists nor a recomputation ever exceed
+    SIM_WORKSPACE_BYTES.  Returns (values, indices, number of recomputed rows)."""
     q, p = query.shape
     n = keys.shape[0]
     dev = query.device
     L = _lib.lib()
-    ns = min(n, FUSED_SAMPLE)
-    step = n // ns
+    ns, step, r, cap = _filter_plan(n, top_k)
     sample = keys[::step][:ns]                                   # strided view: rows stay unit-stride
-    r = min(ns, int(1.5 * top_k * ns / n) + 32)
-    thr = topk_rows(cosine_similarity_matrix(query, sample), r)[0][:, r - 1].contiguous()
-    cap = max(2048, 4 * top_k)
-    cnt = torch.zeros((q,), device=dev, dtype=torch.int32)
-    cval = torch.full((q, cap), float("-inf"), device=dev, dtype=torch.float32)
-    cidx = torch.zeros((q, cap), device=dev, dtype=torch.int32)
-    ops.gemm_raw(q, n, p, 1, query, query.stride(0), 1, 0, keys, 1, keys.stride(0), 0, None, n, 0,
-                 compute=_lib.COMPUTE_F32, filt=(thr, cnt, cval, cidx))
     values = torch.empty((q, top_k), device=dev, dtype=torch.float32)
     indices = torch.empty((q, top_k), device=dev, dtype=torch.int64)
-    tie = torch.zeros((q,), device=dev, dtype=torch.int32)
-    check(L.mcl_topk_rows_indexed(cval.data_ptr(), cap, cidx.data_ptr(), cap, q, cap, top_k, values.data_ptr(), indices.data_ptr(),
-                                  tie.data_ptr(), ops._stream()), "mcl_topk_rows_indexed")
-    bad = ((cnt < top_k) | (cnt > cap) | (tie != 0)).nonzero().flatten()      # (host sync: the retrieval returns to the host anyway)
-    if bad.numel():
-        v, i = topk_rows(cosine_similarity_matrix(query[bad].contiguous(), keys), top_k)
-        values[bad], indices[bad] = v, i
-    return values, indices, int(bad.numel())
+    chunk = max(1, min(q, SIM_WORKSPACE_BYTES // (4 * ns + 8 * cap)))
+    redo_chunk = max(1, SIM_WORKSPACE_BYTES // (4 * n))
+    redone = 0
+    for q0 in range(0, q, chunk):
+        q1 = min(q, q0 + chunk)
+        qc = q1 - q0
+        qry = query[q0:q1]
+        thr = topk_rows(cosine_similarity_matrix(qry, sample), r)[0][:, r - 1].contiguous()
+        cnt = torch.zeros((qc,), device=dev, dtype=torch.int32)
+        cval = torch.full((qc, cap), float("-inf"), device=dev, dtype=torch.float32)
+        cidx = torch.zeros((qc, cap), device=dev, dtype=torch.int32)
+        ops.gemm_raw(qc, n, p, 1, qry, qry.stride(0), 1, 0, keys, 1, keys.stride(0), 0, None, n, 0,
+                     compute=_lib.COMPUTE_F32, filt=(thr, cnt, cval, cidx))
+        v, i = values[q0:q1], indices[q0:q1]
+        tie = torch.zeros((qc,), device=dev, dtype=torch.int32)
+        check(L.mcl_topk_rows_indexed(cval.data_ptr(), cap, cidx.data_ptr(), cap, qc, cap, top_k, v.data_ptr(), i.data_ptr(),
+                                      tie.data_ptr(), ops._stream()), "mcl_topk_rows_indexed")
+        bad = ((cnt < top_k) | (cnt > cap) | (tie != 0)).nonzero().flatten()  # (host sync: the retrieval returns to the host anyway)
+        for b0 in range(0, int(bad.numel()), redo_chunk):
+            rows = bad[b0:b0 + redo_chunk]
+            vv, ii = topk_rows(cosine_similarity_matrix(qry[rows].contiguous(), keys), top_k)
+            v[rows], i[rows] = vv, ii
+        redone += int(bad.numel())
+    return values, indices, redone
 
 
 def find_matches_device(spot_embeddings: ArrayLike, query_embeddings: ArrayLike, top_k: int = 1

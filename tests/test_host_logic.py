@@ -105,3 +105,18 @@ def test_train_flags_include_fp8_infonce():
     from mclstexp_amd.train import generate_args
     a = generate_args(["--infonce", "fp8"])
     assert a.infonce == "fp8" and a.encoder_name == "densenet121" and a.dim == 785     # reference defaults untouched
+
+
+def test_retrieval_filter_plan_keeps_the_expected_list_inside_its_capacity():
+    """mclstexp_amd.retrieval._filter_plan (host arithmetic only): for every key count the expected candidate-list length
+    stays well inside the capacity and above k -- the r05 plan overflowed for N > ~262k."""
+    from mclstexp_amd import retrieval as rt
+    for n in (8192, 20000, 65536, 262144, 300000, 1_000_000, 10_000_000):
+        for k in (1, 50, 200, 600, 1024):
+            if 16 * k > n:
+                continue
+            ns, step, r, cap = rt._filter_plan(n, k)
+            assert ns <= n and step >= 1 and ns * step <= n and step <= rt.FUSED_MAX_STRIDE
+            expect = r * n / ns
+            assert expect >= 1.4 * k, (n, k)
+            assert expect * (1 + 4 / r ** 0.5) < cap, (n, k, expect, cap)      # four standard deviations of the count

@@ -80,7 +80,7 @@ def test_lazy_tables_bit_identical_to_dense_after_60_steps(G):
         for k, what in enumerate(("param", "exp_avg", "exp_avg_sq")):
             assert torch.equal(lazy[n][k][UNTOUCHED_ROW], dense[n][k][UNTOUCHED_ROW]), f"{n}_embed {what}: row {UNTOUCHED_ROW}"
             assert torch.equal(lazy[n][k], dense[n][k]), f"{n}_embed {what}: whole table"
-    assert int(ol.state[ml.x_embed.weight]["row_step"].min()) == steps
+    assert int(ol._row_step(ml.x_embed.weight).min()) == steps
     # and the other parameters walked the same trajectory
     for (na, pa), (nb, pb) in zip(md.named_parameters(), ml.named_parameters()):
         assert torch.equal(pa, pb), na
@@ -161,3 +161,105 @@ def test_step_without_table_gradient_moves_no_row():
     for n in ("x", "y"):
         for k in range(3):
             assert torch.equal(outs[0][n][k], outs[1][n][k]), (n, k)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_checkpoint_resume_equals_uninterrupted_dense_run(graphs, tmp_path):
+    """train N steps, save model + optimizer through torch.save, load both into FRESH objects, train M more
+    -- bit-identical to an uninterrupted run of the dense per-step table update: every parameter, both tables, all moments.
+    (torch's Optimizer.load_state_dict casts state tensors of float parameters to float: the int32 row stamps must not be in
+    the state; the flat-managed parameters' moments must be in the checkpoint.)"""
+    from mclstexp_amd import densenet_fused as dn
+    from mclstexp_amd.engine import TrainStep
+    G, N, M = 172, 9, 11
+
+    def steps(m, opt, first, count, tr=None):
+        out = []
+        for s in range(first, first + count):
+            batch = _batch(8, G, s % 7)
+            if tr is not None:
+                out.append(tr(batch).item())
+            else:
+                loss = m(batch)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                out.append(loss.item())
+        return out
+
+    md, od = _model(G, lazy=False)
+    ref = steps(md, od, 0, N + M)
+    dn.set_weight_provider(None)
+
+    m1, o1 = _model(G, lazy=True)
+    tr1 = TrainStep(m1, o1, None, graphs=graphs, warmup=2) if graphs else None
+    got = steps(m1, o1, 0, N, tr1)
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({"model": m1.state_dict(), "opt": o1.state_dict()}, path)
+    dn.set_weight_provider(None)
+    del m1, o1, tr1
+
+    ck = torch.load(path)
+    for v in ck["opt"]["state"].values():
+        assert set(v) == {"exp_avg", "exp_avg_sq"}, "only Adam's moments belong in the checkpoint"
+    assert len(ck["opt"]["state"]) == len(list(md.parameters())), "every parameter's moments are in the checkpoint"
+    m2, o2 = _model(G, lazy=True)
+    m2.load_state_dict(ck["model"])
+    o2.load_state_dict(ck["opt"])
+    tr2 = TrainStep(m2, o2, None, graphs=graphs, warmup=2) if graphs else None
+    got += steps(m2, o2, N, M, tr2)
+    assert got == ref
+    o2.materialize_tables()
+    dense, lazy = _tables(md, od), _tables(m2, o2)
+    for n in ("x", "y"):
+        for k, what in enumerate(("param", "exp_avg", "exp_avg_sq")):
+            assert torch.equal(lazy[n][k], dense[n][k]), f"{n}_embed {what}"
+    for (na, pa), (nb, pb) in zip(md.named_parameters(), m2.named_parameters()):
+        assert torch.equal(pa, pb), na
+    sd_d, sd_l = od.state_dict(), o2.state_dict()
+    for k in sd_d["state"]:
+        for w in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(sd_d["state"][k][w], sd_l["state"][k][w]), (k, w)
+    dn.set_weight_provider(None)
+
+
+def test_load_state_dict_into_a_live_captured_step():
+    """Loading a checkpoint into the SAME objects after the step graph was captured: the replayed kernels read the moments and
+    row stamps through the pointers they were captured with, so the load must overwrite those tensors in place."""
+    from mclstexp_amd import densenet_fused as dn
+    from mclstexp_amd.engine import TrainStep
+    G = 172
+    m, opt = _model(G, lazy=True)
+    tr = TrainStep(m, opt, None, graphs=True, warmup=2)
+    for s in range(6):
+        tr(_batch(8, G, s % 7))
+    sd_m = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd_o = opt.state_dict()
+    a = [tr(_batch(8, G, (6 + s) % 7)).item() for s in range(5)]
+    assert tr.ga is not None
+    m.load_state_dict(sd_m)
+    opt.load_state_dict(sd_o)
+    b = [tr(_batch(8, G, (6 + s) % 7)).item() for s in range(5)]
+    assert a == b
+    dn.set_weight_provider(None)
+
+
+def test_second_optimizer_takes_over_cleanly():
+    """a second FusedAdam for the same model materialises the first one's pending replays and removes its
+    hooks (they do not pile up; the model stays picklable)."""
+    import pickle
+    from mclstexp_amd.optim import FusedAdam
+    G = 172
+    md, od = _model(G, lazy=False)
+    _train(md, od, 4, G)
+    ml, ol = _model(G, lazy=True)
+    _train(ml, ol, 4, G)
+    n_hooks = len(ml._state_dict_pre_hooks)
+    o2 = FusedAdam(ml.parameters(), lr=1e-4, weight_decay=1e-3).attach_model(ml)
+    assert len(ml._state_dict_pre_hooks) == n_hooks and not ol._hook_handles
+    # the first optimizer's deferred weight-decay steps landed in the tables before the hand-over
+    assert torch.equal(ml.x_embed.weight[UNTOUCHED_ROW], md.x_embed.weight[UNTOUCHED_ROW])
+    o2.detach_model()
+    pickle.dumps(ml.x_embed)
+    from mclstexp_amd import densenet_fused as dn
+    dn.set_weight_provider(None)

@@ -212,6 +212,28 @@ def test_find_matches_filtered_equals_materialised(rt, n, q, k):
     assert torch.equal(v2, v1) and torch.equal(i2, i1)                      # run to run (the candidate order is not fixed)
 
 
+def test_find_matches_filtered_beyond_262k_keys_and_in_query_chunks(rt, monkeypatch):
+    """with a fixed 4096-key sample the expected list length 1.5 k + 32 N / 4096 passed the capacity from
+    N ~ 262k on and EVERY row fell back to an unchunked (Q, N) recomputation.  The sample now grows with N; and queries (and any
+    recomputation) are processed in SIM_WORKSPACE_BYTES-sized chunks."""
+    n, q, k = 600_000, 96, 20
+    g = torch.Generator(device=DEV).manual_seed(5)
+    keys = rt.l2_normalize(torch.randn(n, 256, device=DEV, generator=g))
+    query = rt.l2_normalize(torch.randn(q, 256, device=DEV, generator=g))
+    v1, i1, redo = rt.find_matches_filtered(query, keys, k)
+    assert redo == 0
+    v0, i0 = _materialised(rt, query, keys, k)
+    assert torch.equal(v1, v0) and torch.equal(i1, i0)
+    # a workspace bound that forces several query chunks AND row-by-row recomputation of the rows the threshold missed
+    ns, _, _, cap = rt._filter_plan(n, k)
+    monkeypatch.setattr(rt, "SIM_WORKSPACE_BYTES", 7 * (4 * ns + 8 * cap))
+    query[5] = keys[::n // ns][:ns][:300].sum(0)                            # close to many SAMPLED keys: threshold too high
+    query = rt.l2_normalize(query)
+    v2, i2, redo2 = rt.find_matches_filtered(query, keys, k)
+    v0, i0 = _materialised(rt, query, keys, k)
+    assert torch.equal(v2, v0) and torch.equal(i2, i0)
+
+
 def test_find_matches_filtered_recomputes_rows_the_threshold_missed(rt):
     """Exactness does not depend on the sample: (a) the sampled keys are the query's BEST ones (threshold too high: fewer than k
     candidates), (b) a cluster of near-duplicates overflows a list, (c) exact duplicates tie at the k-th value (the cut must
