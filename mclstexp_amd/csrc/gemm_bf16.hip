@@ -109,6 +109,7 @@ struct GemmB {
   int gelu, gelu_bwd, out_f32;
   int tm, tn, ksplit;                           // tiles in M, N; K slices (slab s at C + s * slab_stride floats)
   long long k_per_split, slab_stride;
+  int dbg;                                      // experiment switches of the pipe kernel (MCL_GEMM_DBG; 0 in production)
 };
 
 // GELU (exact-erf form, nn.GELU's default) and its derivative for bf16 outputs.  Phi(x) = 0.5 erfc(-x / sqrt 2) through Abramowitz &
@@ -119,7 +120,7 @@ struct GemmB {
 // the density term of the derivative.
 __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& ex) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // (v_rcp_f32, 1 ulp: __frcp_rn expands to the 10-instruction IEEE division)
   ex = __expf(-z * z);
   const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
   const float half_erfc = 0.5f * poly * ex;
@@ -570,6 +571,435 @@ __global__ __launch_bounds__(512) void gemm_bf16_stag_kernel(GemmB g) {
 }
 
 
+// ================================================================================================================================
+// Round 6: gemm_bf16_pipe_kernel -- PERSISTENT workgroups, ONE software pipeline across all their tiles, epilogue without LDS.
+//
+// What the round-4 ablation of the staggered kernel said about a K = 768 tile (33 us): the two barrier-separated segments per
+// half-tile are bound by the longer one (fragment reads + DMA issue ~ 900 cycles beside 512 cycles of MFMA), the prologue
+// (three half-tiles of DMA latency with nothing to compute) and the epilogue (LDS transposition + every CU storing its 128 KB
+// at the same moment while no MFMA runs) are paid per tile, and at K = 768 a tile is only 24 half-tiles long.  This kernel:
+//   * one workgroup per CU walks its tiles (virtual block ids w, w + G, ...: the XCD-aware order of the other kernels, the XCD
+//     of a workgroup never changes) and the four-slot half-K ring RUNS ON ACROSS TILES: the DMA cursor is three half-tiles ahead
+//     of the MFMAs whatever tile they belong to, so only the first tile of a workgroup has a prologue;
+//   * inside a half-tile every wave interleaves its own 16 MFMAs with the 12 fragment reads of the NEXT 16 (two register sets)
+//     and its 4 DMA pieces -- one barrier per half-tile instead of two, no wave-group stagger: the MFMA pipe is the pole;
+//   * the MFMA operands are swapped (D^T = B^T A^T): a lane then holds ONE output row and 4 x 4 consecutive columns, so the
+//     result leaves through v_permlane32_swap + 16-byte stores straight from the registers -- no LDS (the ring keeps filling for
+//     the next tile during the epilogue), no barrier, and the stores drain behind the next tile's loop (counted vmcnt).
+// Hazards (un-staggered, by barrier count; g = position of a half-tile in the workgroup's stream, slot g & 3):
+//   RAW  slot g+1 is read (fragments F(g+1, 0)) after barrier B(g); every wave waited for its own pieces of g+1 before B(g).
+//   WAR  slot g-1 is refilled (pieces of g+3) in iteration g; its last reads, F(g-1, 1), were issued before B(g-1) and retired
+//        by the lgkmcnt(0) every wave executes before B(g-1).
+// Interior tiles only (M, N multiples of 256; every K range a multiple of 64 and >= 128); everything else keeps the other kernels.
+struct PipeTile {
+  const unsigned char* baseA;   // this wave's piece of half-tile 0 (bytes)
+  const unsigned char* baseB;
+  int nh;                       // half-tiles (32 k)
+  int m0, n0, ks, b1;
+  long long c_off;
+};
+
+__device__ __forceinline__ unsigned swap_lo_hi(unsigned& x, unsigned& y) {       // x.hi <-> y.lo  (v_permlane32_swap_b32)
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0];
+  y = r[1];
+  return 0;
+}
+
+
+// Epilogue forms of the pipe kernel (compile-time: one form's code per kernel -- with run-time branches the eight unrolled blocks
+// grew to 13 000 instructions, more than the instruction cache holds)
+enum { PE_PLAIN = 0, PE_GELU2 = 1, PE_GELU1 = 2, PE_GBWD2 = 3, PE_GBWD1 = 4, PE_RESID = 5, PE_F32 = 6 };
+
+// Straight from the registers.  Block (i, j) in the transposed MFMA layout: this lane = row m = i*32 + l31, register r = column
+// (r & 3) + 8 (r >> 2) + 4 h of the 32-column block j: four groups of 4 consecutive columns.
+__device__ __forceinline__ void pipe_store16(bf16_t* p, u32x4 v, int dbg) {
+  if (dbg & 32) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  else if (dbg & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else if (dbg & 128) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+  else if (dbg & 256) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<u32x4*>(p) = v;
+}
+
+template <int EPI, int WN>
+__device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2], const PipeTile& cur, int wm, int wn, int h,
+                                              int l31) {
+  const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 64;
+  constexpr bool has_x = EPI == PE_GBWD2 || EPI == PE_GBWD1 || EPI == PE_RESID;
+  // one 64-bit row base per lane and tensor; a block adds a wave-uniform offset
+  const long long row = mw + l31;
+  const bf16_t* xrow = (EPI == PE_GBWD2 || EPI == PE_GBWD1) ? g.aux + row * g.ldaux + nw + 8 * h
+                       : (EPI == PE_RESID ? g.resid + (long long)cur.b1 * g.sRb + row * g.ldr + nw + 8 * h : nullptr);
+  const long long ldx = (EPI == PE_GBWD2 || EPI == PE_GBWD1) ? g.ldaux : g.ldr;
+  bf16_t* crow = reinterpret_cast<bf16_t*>(g.C) + cur.c_off + row * g.ldc + nw + 8 * h;
+  float* frow = reinterpret_cast<float*>(g.C) + (long long)cur.ks * g.slab_stride + cur.c_off + row * g.ldc + nw + 4 * h;
+  const bool second = (EPI == PE_GELU2) || (EPI == PE_GELU1 && g.pre_out);
+  bf16_t* prow = second ? g.pre_out + row * g.ldp + nw + 8 * h : nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    // the residual / gelu' rows of the 4 blocks of a 32-column half are requested together (32 registers)
+    u32x4 xq[4][2];
+    if (has_x) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+          xq[i][pr] = *reinterpret_cast<const u32x4*>(xrow + (long long)(i * 32) * ldx + j * 32 + 16 * pr);
+    }
+    float4 bq[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      bq[gq] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nw + j * 32 + 8 * gq + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_barrier(0);           // one block at a time: keeps the epilogue's live set small
+      float vv[16];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        vv[4 * gq + 0] = fmaf(acc[i][j][4 * gq + 0], g.alpha, bq[gq].x);
+        vv[4 * gq + 1] = fmaf(acc[i][j][4 * gq + 1], g.alpha, bq[gq].y);
+        vv[4 * gq + 2] = fmaf(acc[i][j][4 * gq + 2], g.alpha, bq[gq].z);
+        vv[4 * gq + 3] = fmaf(acc[i][j][4 * gq + 3], g.alpha, bq[gq].w);
+      }
+      if (EPI == PE_F32) {
+        float* o = frow + (long long)(i * 32) * g.ldc + j * 32;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          *reinterpret_cast<float4*>(o + 8 * gq) = make_float4(vv[4 * gq], vv[4 * gq + 1], vv[4 * gq + 2], vv[4 * gq + 3]);
+        continue;
+      }
+      if (has_x) {                                 // the x operand into this lane's own layout, applied at once
+        unsigned xo[4][2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          unsigned u0 = xq[i][pr][0], u1 = xq[i][pr][1], w0 = xq[i][pr][2], w1 = xq[i][pr][3];
+          swap_lo_hi(u0, w0);
+          swap_lo_hi(u1, w1);
+          xo[2 * pr][0] = u0; xo[2 * pr][1] = u1; xo[2 * pr + 1][0] = w0; xo[2 * pr + 1][1] = w1;
+        }
+        if (EPI == PE_GBWD2) {                     // aux holds the stored derivative
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            vv[4 * gq + 0] *= bf_lo(xo[gq][0]); vv[4 * gq + 1] *= bf_hi(xo[gq][0]);
+            vv[4 * gq + 2] *= bf_lo(xo[gq][1]); vv[4 * gq + 3] *= bf_hi(xo[gq][1]);
+          }
+        } else if (EPI == PE_GBWD1) {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            vv[4 * gq + 0] *= gelu_g(bf_lo(xo[gq][0])); vv[4 * gq + 1] *= gelu_g(bf_hi(xo[gq][0]));
+            vv[4 * gq + 2] *= gelu_g(bf_lo(xo[gq][1])); vv[4 * gq + 3] *= gelu_g(bf_hi(xo[gq][1]));
+          }
+        } else {
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            vv[4 * gq + 0] += bf_lo(xo[gq][0]); vv[4 * gq + 1] += bf_hi(xo[gq][0]);
+            vv[4 * gq + 2] += bf_lo(xo[gq][1]); vv[4 * gq + 3] += bf_hi(xo[gq][1]);
+          }
+        }
+      }
+      unsigned P[4][2];
+      if (EPI == PE_GELU2 || EPI == PE_GELU1) {
+        if (EPI == PE_GELU2) {                      // second output: gelu'(pre-activation); one exp / rcp serves both
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            float gr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float Phi, ex;
+              gelu_parts(vv[4 * gq + e], Phi, ex);
+              gr[e] = fmaf(vv[4 * gq + e] * 0.39894228040143267794f, ex, Phi);
+              vv[4 * gq + e] *= Phi;
+            }
+            P[gq][0] = pack_bf16(gr[0], gr[1]);
+            P[gq][1] = pack_bf16(gr[2], gr[3]);
+          }
+        } else {                                    // second output (optional): the pre-activation
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            P[gq][0] = pack_bf16(vv[4 * gq], vv[4 * gq + 1]);
+            P[gq][1] = pack_bf16(vv[4 * gq + 2], vv[4 * gq + 3]);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vv[r] = gelu_f(vv[r]);
+        }
+        if (second) {
+          bf16_t* po = prow + (long long)(i * 32) * g.ldp + j * 32;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            swap_lo_hi(P[2 * pr][0], P[2 * pr + 1][0]);
+            swap_lo_hi(P[2 * pr][1], P[2 * pr + 1][1]);
+            if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
+              pipe_store16(po + 16 * pr, u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]}, g.dbg);
+          }
+        }
+      }
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        P[gq][0] = pack_bf16(vv[4 * gq], vv[4 * gq + 1]);
+        P[gq][1] = pack_bf16(vv[4 * gq + 2], vv[4 * gq + 3]);
+      }
+      // groups (0, 1) and (2, 3): after the swaps a lane holds 8 consecutive columns (lower half: 0-7 / 16-23 of the block,
+      // upper half: 8-15 / 24-31) -> two 16-byte stores per block, 32 contiguous bytes per row and instruction
+      bf16_t* o = crow + (long long)(i * 32) * g.ldc + j * 32;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        swap_lo_hi(P[2 * pr][0], P[2 * pr + 1][0]);
+        swap_lo_hi(P[2 * pr][1], P[2 * pr + 1][1]);
+        if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
+          pipe_store16(o + 16 * pr, u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]}, g.dbg);
+      }
+    }
+  }
+}
+
+// WN = wave columns of the workgroup: 4 -> 8 waves, 256 x 256 tile, four 32 KB slots, one workgroup per CU;
+//                                      2 -> 4 waves, 256 x 128 tile, three 24 KB slots (72 KB), TWO workgroups per CU: independent
+// instruction streams on every SIMD, started half a tile apart (the second workgroup of a CU -- odd hardware wave slot -- sleeps
+// `dephase` x 2048 cycles first; the first one has the matrix pipe to itself meanwhile), so that one workgroup's epilogue (GELU on the
+// VALU, the tile's stores) runs beside the other's MFMA loop and the chip's stores are spread over time instead of arriving as
+// one burst per round of tiles.
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int WN, int DBG = 0>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_pipe_kernel(GemmB g, int total_virtual, int dephase) {
+  constexpr int NW = 2 * WN;                      // waves
+  constexpr int BM = 256, BN = 64 * WN;
+  constexpr int HK = 32, HSUB = 8192;             // half-K; bytes per half sub-tile (128 rows or columns x 32 k)
+  constexpr int BSUBS = WN / 2;                   // 128-column sub-tiles of B
+  constexpr int HOP = 2 * HSUB;                   // offset of B inside a slot (A: two half sub-tiles)
+  constexpr int SLOT = HOP + BSUBS * HSUB;        // 32 KB / 24 KB
+  constexpr int NSLOT = WN == 4 ? 4 : 3;
+  constexpr int D = NSLOT - 1;                    // half-tiles the DMA cursor runs ahead
+  constexpr int PPS = 8 / NW;                     // pieces of a half sub-tile per wave (1 / 2)
+  constexpr int PA = 2 * PPS, PB = BSUBS * PPS;   // DMA instructions per wave and half-tile: A, B
+  constexpr int P = PA + PB;                      // 4 / 6
+  static_assert(P % 2 == 0, "pieces split evenly between the two k-steps");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds_base = (unsigned)(size_t)MCL_LDSP(lds);
+  const int G = gridDim.x;
+
+  // ---- tile decode (wave-uniform).  v = virtual block id in the XCD-aware order of the non-persistent kernels.
+  auto decode = [&](int v, PipeTile& t) -> bool {
+    int b, ks, tx, ty;
+    if (g.tm >= 8) {
+      const int per_batch = ((g.tm + 7) / 8) * 8 * g.tn * g.ksplit;
+      const int bid = v % per_batch;
+      b = v / per_batch;
+      const int xcd = bid & 7, q = bid >> 3;
+      ks = q % g.ksplit;
+      const int q2 = q / g.ksplit;
+      tx = q2 % g.tn;
+      ty = (q2 / g.tn) * 8 + xcd;
+      if (ty >= g.tm) return false;
+    } else {
+      const int per_batch = g.tm * g.tn * g.ksplit;
+      const int bid = v % per_batch;
+      b = v / per_batch;
+      ks = bid % g.ksplit;
+      const int q2 = bid / g.ksplit;
+      tx = q2 % g.tn;
+      ty = q2 / g.tn;
+    }
+    const int m0 = ty * BM, n0 = tx * BN;
+    const long long k_begin = (long long)ks * g.k_per_split;
+    const long long k_end = min((long long)g.K, k_begin + g.k_per_split);
+    const int b1 = b / g.batch2, b2 = b % g.batch2;
+    const bf16_t* A = g.A + (long long)b1 * g.sAb + (long long)b2 * g.sAb2;
+    const bf16_t* B = g.B + (long long)b1 * g.sBb + (long long)b2 * g.sBb2;
+    t.baseA = reinterpret_cast<const unsigned char*>(
+        !A_KMAJOR ? A + (long long)(m0 + 16 * wave_s) * g.lda + k_begin : A + (k_begin + 4 * wave_s) * g.lda + m0);
+    t.baseB = reinterpret_cast<const unsigned char*>(
+        !B_KMAJOR ? B + (long long)(n0 + 16 * wave_s) * g.ldb + k_begin : B + (k_begin + 4 * wave_s) * g.ldb + n0);
+    t.nh = (int)((k_end - k_begin) / HK);
+    t.m0 = m0; t.n0 = n0; t.ks = ks; t.b1 = b1;
+    t.c_off = (long long)b1 * g.sCb + (long long)b2 * g.sCb2;
+    return true;
+  };
+  int v = (int)blockIdx.x - G;
+  auto next_tile = [&](PipeTile& t) -> bool {
+    for (v += G; v < total_virtual; v += G)
+      if (decode(v, t)) return true;
+    return false;
+  };
+
+  // ---- DMA geometry: a half sub-tile (128 rows x 32 k, or 32 k x 128 columns) is 8 pieces of 1 KB; wave w moves pieces
+  // w, w + NW, ... of every half sub-tile of both operands.  The per-lane source offsets (swizzle on the source side, as in
+  // gemm_bf16_stag_kernel) are computed once; piece (sub s, index w + NW e) adds a constant to the wave's base.
+  unsigned vA[2][PPS], vB[BSUBS][PPS];
+  {
+    const unsigned a0 = !A_KMAJOR ? (unsigned)((lane >> 2) * g.lda * 2) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3))) << 4)
+                                  : (unsigned)((lane >> 4) * g.lda * 2) + (unsigned)(((lane & 15) ^ (((lane >> 4) & 3) << 2)) << 4);
+    const unsigned b0 = !B_KMAJOR ? (unsigned)((lane >> 2) * g.ldb * 2) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3))) << 4)
+                                  : (unsigned)((lane >> 4) * g.ldb * 2) + (unsigned)(((lane & 15) ^ (((lane >> 4) & 3) << 2)) << 4);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int e = 0; e < PPS; ++e)        // sub-tile: +128 rows (k-contiguous) / +128 columns; piece + NW e: +16 NW e rows / +4 NW e k-rows
+        vA[sb][e] = a0 + (unsigned)(!A_KMAJOR ? (256ll * sb + 32ll * NW * e) * g.lda : 256ll * sb + 8ll * NW * e * g.lda);
+#pragma unroll
+    for (int sb = 0; sb < BSUBS; ++sb)
+#pragma unroll
+      for (int e = 0; e < PPS; ++e)
+        vB[sb][e] = b0 + (unsigned)(!B_KMAJOR ? (256ll * sb + 32ll * NW * e) * g.ldb : 256ll * sb + 8ll * NW * e * g.ldb);
+  }
+  const long long stepA = !A_KMAJOR ? 2ll * HK : 2ll * HK * g.lda, stepB = !B_KMAJOR ? 2ll * HK : 2ll * HK * g.ldb;
+
+  PipeTile cur, nxt;
+  if (!next_tile(cur)) return;
+  if (WN == 4 && dephase > 0) {              // experiment: every other CU of an XCD starts late (spreads the chip's store bursts)
+    if ((blockIdx.x >> 3) & 1)
+      for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+  if (WN == 2 && dephase > 0) {
+    // second workgroup of this CU (the hardware wave slot of its waves is odd): start half a tile late
+    const unsigned wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID[3:0] = wave id on the SIMD
+    if (wslot & 1)
+      for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(32);
+  }
+  bool nxt_valid = false, pf_in_nxt = false, pf_active = true;
+  int pf_x = 0;                  // half-tile of the prefetch cursor inside its tile
+  unsigned spf = 0, sc = 0;      // ring slots of the prefetch cursor and of the compute cursor
+  const unsigned char* pfA = cur.baseA;
+  const unsigned char* pfB = cur.baseB;
+  // part 0 / 1 = the two halves of the wave's P instructions: (A sub-tile `part`: PPS pieces) + half of B's
+  auto dma_part = [&](int part) {
+    if (!pf_active) return;
+    const unsigned d = lds_base + spf * SLOT + wave_s * 1024;
+    if (!(DBG & 8)) {
+#pragma unroll
+      for (int e = 0; e < PPS; ++e) glds16s(pfA, vA[part][e], d + part * HSUB + e * NW * 1024);
+      if (WN == 4) {
+        glds16s(pfB, vB[part % BSUBS][0], d + HOP + (part % BSUBS) * HSUB);
+      } else {
+        glds16s(pfB, vB[0][part % PPS], d + HOP + (part % PPS) * NW * 1024);
+      }
+    }
+    if (part == 1) {
+      spf = spf + 1 == NSLOT ? 0 : spf + 1;
+      ++pf_x;
+      pfA += stepA;
+      pfB += stepB;
+      if (pf_x == (pf_in_nxt ? nxt.nh : cur.nh)) {       // (nh >= 4 > the cursor's lead: it is never two tiles ahead)
+        nxt_valid = next_tile(nxt);
+        pf_in_nxt = true;
+        pf_x = 0;
+        pf_active = nxt_valid;
+        pfA = nxt.baseA;
+        pfB = nxt.baseB;
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+  bf16x8 fa0[4], fb0[2], fa1[4], fb1[2];       // fragments of k-step 0 / k-step 1 of a half-tile
+  const int tA_off = wm * HSUB, tB_off = HOP + (wn >> 1) * HSUB, cb = (wn & 1) * 64;
+  auto read_a = [&](unsigned slot, int q, int i) -> bf16x8 {
+    const unsigned char* tA = lds + slot * SLOT + tA_off;
+    if (!A_KMAJOR) return frag_kc32(tA, i * 32 + l31, 16 * q, h);
+    return frag_km(tA, 16 * q + 8 * h, i * 32, lane);
+  };
+  auto read_b = [&](unsigned slot, int q, int j) -> bf16x8 {
+    const unsigned char* tB = lds + slot * SLOT + tB_off;
+    if (!B_KMAJOR) return frag_kc32(tB, cb + j * 32 + l31, 16 * q, h);
+    return frag_km(tB, 16 * q + 8 * h, cb + j * 32, lane);
+  };
+#define MCL_SB() __builtin_amdgcn_sched_barrier(0)
+#define MCL_MFMA(I, J, FA, FB) \
+  do { if (!(DBG & 4)) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[J], FA[I], acc[I][J], 0, 0, 0); \
+       else acc[I][J][0] += __builtin_bit_cast(float, FA[I][0] ^ FB[J][0]); } while (0)
+  // counted waits on the vector-memory counter (immediates): n = instructions that may stay in flight
+  auto wait_vm = [&](int n) {
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+      case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+      case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+      case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+
+  // ---- prologue of the workgroup's stream: D half-tiles in flight, the first one landed, its k-step 0 in registers
+  for (int i = 0; i < D; ++i) { dma_part(0); dma_part(1); }
+  wait_vm((D - 1) * P);
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) fb0[j] = read_b(0, 0, j);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa0[i] = read_a(0, 0, i);
+
+  bool first_tile = true;
+  // stores per wave and tile of this epilogue form: 16 (one bf16 result) or 32 (two results / fp32)
+  const int S = (EPI == PE_GELU2 || EPI == PE_F32 || (EPI == PE_GELU1 && g.pre_out != nullptr)) ? 32 : 16;
+  // Steady state at barrier B(g): in issue order [g+1: P] ... [g+D-1: P] [g+D: P/2] -- wait for g+1.  For D-1 half-tiles after
+  // an epilogue its S stores sit in that window too (they were issued after the pieces of the last position + D - 1).
+  constexpr int VM_STEADY = (D - 2) * P + P / 2;
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nh = cur.nh;
+    for (int x = 0; x < nh; ++x) {
+      const unsigned s0 = sc, s1 = sc + 1 == NSLOT ? 0 : sc + 1;
+      // ---- k-step 0: MFMAs on (fa0, fb0) | reads of k-step 1 of this half-tile | first half of the DMA pieces
+      MCL_SB();
+      MCL_MFMA(0, 0, fa0, fb0); fb1[0] = read_b(s0, 1, 0); MCL_SB();
+      MCL_MFMA(0, 1, fa0, fb0); fb1[1] = read_b(s0, 1, 1); MCL_SB();
+      MCL_MFMA(1, 0, fa0, fb0); fa1[0] = read_a(s0, 1, 0); MCL_SB();
+      MCL_MFMA(1, 1, fa0, fb0); fa1[1] = read_a(s0, 1, 1); MCL_SB();
+      MCL_MFMA(2, 0, fa0, fb0); fa1[2] = read_a(s0, 1, 2); MCL_SB();
+      MCL_MFMA(2, 1, fa0, fb0); fa1[3] = read_a(s0, 1, 3); MCL_SB();
+      MCL_MFMA(3, 0, fa0, fb0); MCL_SB();
+      dma_part(0);
+      MCL_SB();
+      MCL_MFMA(3, 1, fa0, fb0); MCL_SB();
+      // own pieces of g+1 landed (counted: the younger pieces -- and, right after an epilogue, its stores, which sit between
+      // them in issue order -- stay in flight); own fragment reads of slot g retired; then the barrier
+      if (!pf_active) wait_vm(0);
+      else if (!first_tile && x < D - 1) wait_vm(VM_STEADY + S);
+      else wait_vm(VM_STEADY);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+      // ---- k-step 1: MFMAs on (fa1, fb1) | reads of k-step 0 of the NEXT half-tile (the next tile's first one at a tile end)
+      MCL_SB();
+      MCL_MFMA(0, 0, fa1, fb1); fb0[0] = read_b(s1, 0, 0); MCL_SB();
+      MCL_MFMA(0, 1, fa1, fb1); fb0[1] = read_b(s1, 0, 1); MCL_SB();
+      MCL_MFMA(1, 0, fa1, fb1); fa0[0] = read_a(s1, 0, 0); MCL_SB();
+      MCL_MFMA(1, 1, fa1, fb1); fa0[1] = read_a(s1, 0, 1); MCL_SB();
+      MCL_MFMA(2, 0, fa1, fb1); fa0[2] = read_a(s1, 0, 2); MCL_SB();
+      MCL_MFMA(2, 1, fa1, fb1); fa0[3] = read_a(s1, 0, 3); MCL_SB();
+      MCL_MFMA(3, 0, fa1, fb1); MCL_SB();
+      dma_part(1);
+      MCL_SB();
+      MCL_MFMA(3, 1, fa1, fb1); MCL_SB();
+      sc = s1;
+    }
+
+    if (!(g.dbg & 2)) pipe_epilogue<EPI, WN>(g, acc, cur, wm, wn, h, l31);
+    if (!nxt_valid) break;
+    cur = nxt;
+    nxt_valid = false;
+    pf_in_nxt = false;
+    first_tile = false;
+    // the next tile's first fragments again (slot `sc`, already read once in the last k-step above): re-reading them here
+    // instead of keeping 24 registers live across the epilogue keeps the epilogue out of scratch
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb0[j] = read_b(sc, 0, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa0[i] = read_a(sc, 0, i);
+  }
+#undef MCL_SB
+#undef MCL_MFMA
+}
+
 }  // namespace
 
 // flags: bit 0 A reduction-major, bit 1 B reduction-major, bit 2 GELU, bit 3 multiply by gelu'(aux), bit 4 fp32 output,
@@ -610,6 +1040,7 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   g.resid = (const bf16_t*)resid; g.ldr = ldr; g.sRb = sRb;
   g.aux = (const bf16_t*)aux; g.ldaux = ldaux;
   g.pre_out = (bf16_t*)pre_out; g.ldp = ldp;
+  g.dbg = 0;
   g.gelu = gelu ? (gelu_grad_out ? 2 : 1) : 0; g.gelu_bwd = gbwd ? (aux_is_grad ? 2 : 1) : 0; g.out_f32 = f32;
   // small problems (batched attention products) take the 128 x 128 tile, two workgroups per CU
   const int subs = (M <= 512 && N <= 512) ? 1 : 2;
@@ -647,6 +1078,67 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   const char* e_stag = getenv("MCL_GEMM_STAG");
   const bool stag = subs == 2 && !(e_stag && e_stag[0] == '0') && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && kps % 64 == 0 &&
                     lda * 512 < (1ll << 31) && ldb * 512 < (1ll << 31);
+  // the persistent pipelined kernel (round 6) wherever the staggered one applies and every K range holds >= 4 half-tiles.
+  // MCL_GEMM_PIPE (read per launch -- tests and A/B runs flip it inside one process): "0" never, "4" / "2" always (8 waves,
+  // 256 x 256 / 4 waves, 256 x 128, two workgroups per CU), unset = where it measured faster than the staggered kernel
+  // (profiles/r06_gemm_bf16_microbench.jsonl): the data gradients with a gelu' epilogue.
+  const char* e_pipe = getenv("MCL_GEMM_PIPE");
+  const long long last_range = (long long)K - (long long)(g.ksplit - 1) * kps;
+  const bool pipe_ok = stag && last_range >= 128 && kps >= 128 && !(gbwd && resid) && !(gelu && (gbwd || resid));
+  const bool pipe = pipe_ok && (e_pipe ? e_pipe[0] != '0' : (gbwd && !f32));
+  if (pipe) {
+    // "2": 4 waves, 256 x 128, two workgroups per CU (measured slower: profiles/r06_gemm_pipe_experiments.txt); else the 8-wave form
+    const int WNsel = (e_pipe && e_pipe[0] == '2') ? 2 : 4;
+    if (WNsel == 2) g.tn = N / 128;
+    const int per_batch_p = (g.tm >= 8 ? ((g.tm + 7) / 8) * 8 : g.tm) * g.tn * g.ksplit;
+    const int total_virtual = per_batch_p * batch;
+    const int cus = mcl_cu_count();
+    const int slots = (WNsel == 2 ? 2 : 1) * (cus / 8) * 8;
+    const int G = total_virtual < slots ? total_virtual : slots;
+    const int epi = f32 ? PE_F32 : gelu ? (gelu_grad_out ? PE_GELU2 : PE_GELU1) : gbwd ? (aux_is_grad ? PE_GBWD2 : PE_GBWD1)
+                    : resid ? PE_RESID : PE_PLAIN;
+    const char* e_dbg = getenv("MCL_GEMM_DBG");
+    g.dbg = e_dbg ? atoi(e_dbg) : 0;
+    // half a tile (K loop at the shared rate ~ 1 us per half-tile) in units of s_sleep 32 (2048 cycles); MCL_GEMM_DEPHASE overrides
+    const char* e_dph = getenv("MCL_GEMM_DEPHASE");
+    const int dephase = e_dph ? atoi(e_dph) : (WNsel == 4 ? 0 : (int)(kps / 32 * 6 / 10));
+    const int lay = (akm ? 2 : 0) | (bkm ? 1 : 0);
+    using KernelT = void (*)(GemmB, int, int);
+#define MCL_PK(AK, BKM, W) {gemm_bf16_pipe_kernel<AK, BKM, PE_PLAIN, W>, gemm_bf16_pipe_kernel<AK, BKM, PE_GELU2, W>,   \
+                            gemm_bf16_pipe_kernel<AK, BKM, PE_GELU1, W>, gemm_bf16_pipe_kernel<AK, BKM, PE_GBWD2, W>,   \
+                            gemm_bf16_pipe_kernel<AK, BKM, PE_GBWD1, W>, gemm_bf16_pipe_kernel<AK, BKM, PE_RESID, W>,   \
+                            gemm_bf16_pipe_kernel<AK, BKM, PE_F32, W>}
+    static const KernelT table[2][4][7] = {
+        {MCL_PK(false, false, 2), MCL_PK(false, true, 2), MCL_PK(true, false, 2), MCL_PK(true, true, 2)},
+        {MCL_PK(false, false, 4), MCL_PK(false, true, 4), MCL_PK(true, false, 4), MCL_PK(true, true, 4)}};
+#undef MCL_PK
+    static const KernelT dbg_table[4] = {gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 4>, gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 8>,
+                                         gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 12>, gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 16>};
+    static mcl_device_once pipe_once;
+    if (auto guard = pipe_once.first()) {
+      for (int w = 0; w < 2; ++w)
+        for (int a = 0; a < 4; ++a)
+          for (int e = 0; e < 7; ++e)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[w][a][e]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      w == 0 ? 3 * 24576 : 4 * 32768);
+      for (int e = 0; e < 4; ++e)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_table[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    }
+    KernelT kern = table[WNsel == 4][lay][epi];
+    if (g.dbg & 28) {                                     // loop ablations (experiments; 8 waves, NT, plain): 4 no MFMA, 8 no DMA, 16 no barrier
+      if (lay != 0 || epi != PE_PLAIN || WNsel != 4) return MCL_EUNSUPPORTED;
+      const int d = g.dbg & 28;
+      kern = d == 4 ? dbg_table[0] : d == 8 ? dbg_table[1] : d == 12 ? dbg_table[2] : dbg_table[3];
+    }
+    hipLaunchKernelGGL(kern, dim3(G), dim3(128 * WNsel), (size_t)(WNsel == 2 ? 3 * 24576 : 4 * 32768), st, g, total_virtual, dephase);
+    if (via_slabs) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+      mcl_launch_wrw_merge_strided(workspace, g.ksplit, (long long)M * ldc, g.slab_stride, final_c, accumulate, st);
+    }
+    MCL_CHECK_LAUNCH();
+    return MCL_OK;
+  }
 #define MCL_LAUNCH(AK, BKM)                                                                                          \
   do {                                                                                                               \
     if (stag) hipLaunchKernelGGL((gemm_bf16_stag_kernel<AK, BKM>), grid, dim3(512), lds_bytes, st, g);              \

@@ -525,15 +525,16 @@ class FusedAdam(torch.optim.Optimizer):
             self.materialize_tables()
 
     def state_dict(self):
-        """torch.optim.Optimizer.state_dict() layout (``exp_avg`` / ``exp_avg_sq`` per parameter, snapshots) + ``mcl_step_count``.
-        The flat-managed parameters' moments live in the flat buffers, not in ``self.state``: they are exported here."""
+        """torch.optim.Optimizer.state_dict() layout (``exp_avg`` / ``exp_avg_sq`` per parameter) + ``mcl_step_count``.  As in
+        torch the tensors are REFERENCES to the live state (``copy.deepcopy`` / ``torch.save`` it for a snapshot).  The
+        flat-managed parameters' moments live in the flat buffers, not in ``self.state``: exported here as views of them."""
         self.materialize_tables()
         added = []
         for f in self._flat.values():
             for p in f.get("params", []):
                 _, o = self._where[id(p)]
-                self.state[p] = {"exp_avg": f["m"].as_strided(p.shape, p.stride(), o).clone(),
-                                 "exp_avg_sq": f["v"].as_strided(p.shape, p.stride(), o).clone()}
+                self.state[p] = {"exp_avg": f["m"].as_strided(p.shape, p.stride(), o),
+                                 "exp_avg_sq": f["v"].as_strided(p.shape, p.stride(), o)}
                 added.append(p)
         try:
             sd = super().state_dict()

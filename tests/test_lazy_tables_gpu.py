@@ -234,7 +234,8 @@ def test_load_state_dict_into_a_live_captured_step():
     for s in range(6):
         tr(_batch(8, G, s % 7))
     sd_m = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    sd_o = opt.state_dict()
+    import copy
+    sd_o = copy.deepcopy(opt.state_dict())          # (a snapshot: state_dict() holds references to the live state, as torch's)
     a = [tr(_batch(8, G, (6 + s) % 7)).item() for s in range(5)]
     assert tr.ga is not None
     m.load_state_dict(sd_m)

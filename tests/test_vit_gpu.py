@@ -41,7 +41,10 @@ def test_gemm_bf16_layouts(M, N, K, akm, bkm):
 @pytest.mark.parametrize("M,N,K,akm,bkm,mode", [
     (1024, 768, 768, 0, 0, "bias"), (1024, 2304, 64, 0, 0, "plain"), (768, 1024, 128, 0, 1, "gelu_bwd"),
     (1024, 768, 192, 0, 1, "resid"), (2304, 1024, 256, 1, 0, "bias_gelu_pre"), (768, 3072, 8192, 1, 1, "f32_splitk"),
-    (1024, 1024, 4096, 1, 1, "f32")])
+    (1024, 1024, 4096, 1, 1, "f32"),
+    # several tiles per persistent workgroup (576 / 1152 tiles on 256 / 512 workgroups), the ViT block's own epilogue forms
+    (16384, 2304, 768, 0, 0, "bias_gelu2"), (16384, 2304, 256, 0, 1, "gelu_bwd2"), (16384, 2304, 384, 0, 0, "resid"),
+    (16384, 2304, 128, 1, 0, "bias"), (2304, 768, 16384, 1, 1, "f32_splitk")])
 def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monkeypatch):
     """gemm_bf16_stag_kernel (problems of interior 256 x 256 tiles: two wave groups one barrier apart over a four-slot half-K
     ring) against the lockstep kernel (MCL_GEMM_STAG=0): same fragments in the same k order and the same epilogue, so equal
@@ -55,8 +58,11 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
     aux = _r(M, N, seed=25, scale=2.0).to(BF).to(DEV)
     flags = akm * vf.A_KM | bkm * vf.B_KM
     outs = []
-    for stag in ("1", "0"):
+    # staggered, lockstep (the reference of the bit comparison), then the round-6 persistent pipelined kernel in both forms (8 waves
+    # / 256 x 256 and 4 waves / 256 x 128; it declines K ranges under 4 half-tiles: those launches fall through to the staggered one)
+    for stag, pipe in (("1", "0"), ("0", "0"), ("1", "4"), ("1", "2")):
         monkeypatch.setenv("MCL_GEMM_STAG", stag)
+        monkeypatch.setenv("MCL_GEMM_PIPE", pipe)
         f32 = mode.startswith("f32")
         C = torch.full((M, N), 3.0, device=DEV, dtype=torch.float32 if f32 else BF)
         pre = torch.zeros((M, N), device=DEV, dtype=BF)
@@ -67,6 +73,10 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
             kw.update(bias=bias)
         elif mode == "bias_gelu_pre":
             kw.update(flags=flags | vf.GELU, bias=bias, pre_out=pre, ldp=N)
+        elif mode == "bias_gelu2":
+            kw.update(flags=flags | vf.GELU | vf.GELU_GRAD_OUT, bias=bias, pre_out=pre, ldp=N)
+        elif mode == "gelu_bwd2":
+            kw.update(flags=flags | vf.AUX_IS_GRAD, aux=aux, ldaux=N)
         elif mode == "resid":
             kw.update(bias=bias, resid=res, ldr=N)
         elif mode == "gelu_bwd":
@@ -80,6 +90,16 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
         outs.append((C, pre))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+    for k in (2, 3):
+        # same fragments and k order, MFMA operands swapped (transposed result layout): the products are equal bit for bit; the
+        # GELU epilogues are compiled in a different expression context (fused multiply-adds may pair differently): one bf16 ulp
+        for w in (0, 1):
+            if "gelu" in mode:
+                d = (outs[k][w].float() - outs[1][w].float()).abs()
+                assert bool((d <= 2.0 ** -7 * outs[1][w].float().abs() + 1e-30).all()), (k, w, float(d.max()))
+                assert float((d > 0).float().mean()) < 0.02
+            else:
+                assert torch.equal(outs[k][w], outs[1][w]), (k, w)
     a = (A.t() if akm else A).double()
     b = (B if bkm else B.t()).double()
     ref = a @ b
@@ -90,6 +110,14 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
     elif mode == "bias_gelu_pre":
         assert_close(outs[0][1].float().cpu(), (ref + bias.double()).cpu(), 3e-3, 2 ** -7, what="staggered pre-activation")
         ref = torch.nn.functional.gelu(ref + bias.double())
+    elif mode == "bias_gelu2":
+        xa = (ref + bias.double()).requires_grad_(True)
+        y = torch.nn.functional.gelu(xa)
+        y.sum().backward()
+        assert_close(outs[0][1].float().cpu(), xa.grad.cpu(), 3e-3, 2 ** -7, what="stored gelu'")
+        ref = y.detach()
+    elif mode == "gelu_bwd2":
+        ref = ref * aux.double()
     elif mode == "resid":
         ref = ref + bias.double() + res.double()
     elif mode == "gelu_bwd":
