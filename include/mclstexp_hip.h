@@ -265,6 +265,43 @@ int mcl_softmax_bf16_bwd(const void* P, void* dP, int64_t ld, int64_t rows, int3
 int mcl_vit_attn_fwd(const void* qkv, void* o, float* lse, int32_t B, int32_t T, int32_t heads, float scale, mcl_stream_t stream);
 int mcl_vit_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* dsum, void* dqkv, int32_t B,
                      int32_t T, int32_t heads, float scale, mcl_stream_t stream);
+/* ---- the ViT's token assembly and token mean on own kernels (csrc/glue.hip; timm VisionTransformer.forward_features behind
+ * /root/reference/model.py:104-116).  x / dx: (B, T, D) with T = patches + 1, row 0 of an image = the class token; dtype 0 = fp32,
+ * 1 = bf16; cls (D), pos (T*D) fp32 parameters.
+ *   mcl_vit_patchify_tokens  mcl_vit_patchify with (lead_zero_row) one zero row in front of every image's patches -- the (B, T, K)
+ *                            token matrix whose row 0 carries no patch -- and (out_f32) an fp32 result;
+ *   mcl_vit_cls_row          x[b][0] = cls + pos[0]                        (the patch rows come from the patch GEMM's epilogue)
+ *   mcl_vit_assemble_f32     x[b][0] = cls + pos[0] ; x[b][t] = tok[b*(T-1) + t-1] + pos[t]          (fp32 path)
+ *   mcl_vit_tokens_extract   dtok[b*(T-1) + t-1] = dx[b][t], t >= 1
+ *   mcl_vit_token_mean_fwd   feat[b] = mean over t >= 1 of x[b][t]  (fp32, token order)              (global_pool = 'avg')
+ *   mcl_vit_token_mean_bwd   dx[b][0] = 0 ; dx[b][t >= 1] = dfeat[b] / (T - 1)
+ *   mcl_vit_pos_grad         dpos[t] (+)= sum_b dx[b][t] (batch order) ; dcls (+)= its t = 0 row (NULL: skipped);
+ *                            accumulate: bit 0 adds into dpos, bit 1 adds into dcls
+ *   mcl_vit_zero_cls_rows    dx[b][0] = 0                                   (before the patch-embedding bias gradient)        */
+int mcl_vit_patchify_tokens(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H, int32_t W,
+                            int32_t p, void* out, int32_t lead_zero_row, int32_t out_f32, mcl_stream_t stream);
+int mcl_vit_cls_row(const float* cls, const float* pos, void* x, int32_t B, int32_t T, int32_t D, int32_t dtype,
+                    mcl_stream_t stream);
+int mcl_vit_assemble_f32(const float* tok, const float* cls, const float* pos, float* x, int32_t B, int32_t T, int32_t D,
+                         mcl_stream_t stream);
+int mcl_vit_tokens_extract(const void* dx, void* dtok, int32_t B, int32_t T, int32_t D, int32_t dtype, mcl_stream_t stream);
+int mcl_vit_token_mean_fwd(const void* x, float* feat, int32_t B, int32_t T, int32_t D, int32_t dtype, mcl_stream_t stream);
+int mcl_vit_token_mean_bwd(const float* dfeat, void* dx, int32_t B, int32_t T, int32_t D, int32_t dtype, mcl_stream_t stream);
+int mcl_vit_pos_grad(const void* dx, float* dpos, float* dcls, int32_t B, int32_t T, int32_t D, int32_t dtype,
+                     int32_t accumulate, mcl_stream_t stream);
+int mcl_vit_zero_cls_rows(void* dx, int32_t B, int32_t T, int32_t D, int32_t dtype, mcl_stream_t stream);
+/* 4-D strided copy of an fp32 source, element strides on both sides: dst[i . d] (+)= src[i . a], i over (n0, n1, n2, n3); dst fp32
+ * (dst_dtype 0) or bf16 (1).  Packs a Conv2d weight of any memory format into the (c, iy, ix) column order of the patch GEMM
+ * (with the cast), and adds a contiguous weight gradient into a .grad that has the parameter's own strides.               */
+int mcl_strided4_f32(const float* src, int32_t n0, int32_t n1, int32_t n2, int32_t n3, int64_t a0, int64_t a1, int64_t a2,
+                     int64_t a3, void* dst, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int32_t dst_dtype, int32_t accumulate,
+                     mcl_stream_t stream);
+/* 2-D copy with row strides in BYTES (a channel slice of a channels-last buffer -> dense rows, or back); 2-byte granularity. */
+int mcl_copy_rows(const void* src, int64_t ld_src_bytes, void* dst, int64_t ld_dst_bytes, int64_t rows, int64_t row_bytes,
+                  mcl_stream_t stream);
+/* wf[ci][ky][kx][co] = w[co][k-1-ky][k-1-kx][ci]: the weight of the "same" convolution that IS the backward-data pass of a
+ * stride-1 convolution (w: (Co, k, k, Ci) storage = a channels-last Conv2d weight); dtype 0 fp32 / 1 bf16.                  */
+int mcl_weight_rot180(const void* w, void* wf, int32_t Co, int32_t k, int32_t Ci, int32_t dtype, mcl_stream_t stream);
 /* Patch extraction for the patch-embedding GEMM: out[(b, py, px)][c*p*p + iy*p + ix] (bf16) from an fp32 image
  * addressed by element strides (sb, sc, sy, sx): NCHW or channels-last.                                            */
 int mcl_vit_patchify(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H, int32_t W,

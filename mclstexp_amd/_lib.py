@@ -125,6 +125,17 @@ PROTOTYPES = {
     "mcl_softmax_bf16_fwd": [c_p, c_l, c_l, c_i, c_p],
     "mcl_softmax_bf16_bwd": [c_p, c_p, c_l, c_l, c_i, c_f, c_p],
     "mcl_vit_patchify": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_p],
+    "mcl_vit_patchify_tokens": [c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
+    "mcl_vit_cls_row": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_vit_assemble_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "mcl_vit_tokens_extract": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_vit_token_mean_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_vit_token_mean_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_vit_pos_grad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "mcl_vit_zero_cls_rows": [c_p, c_i, c_i, c_i, c_i, c_p],
+    "mcl_strided4_f32": [c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_l, c_i, c_i, c_p],
+    "mcl_copy_rows": [c_p, c_l, c_p, c_l, c_l, c_l, c_p],
+    "mcl_weight_rot180": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "mcl_vit_attn_fwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "mcl_vit_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "mcl_quant_e4m3_rows": [c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_l, c_p, c_l, c_p],

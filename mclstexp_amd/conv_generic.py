@@ -44,6 +44,11 @@ def _rows(t: Tensor) -> Tuple[int, int, int, int]:
     return r(t)
 
 
+def _dense_cl(t: Tensor) -> Tensor:
+    from .densenet_fused import dense_cl
+    return dense_cl(t)
+
+
 def _out_hw(H: int, W: int, k: int, stride: int, pad: int) -> Tuple[int, int]:
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 
@@ -141,13 +146,15 @@ def conv_bwd_data(dy: Tensor, wk: Tensor, x_shape, stride: int, pad: int) -> Ten
         dx = torch.empty((B, Ci, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         _gemm(dy, pd, ldd, False, wk, wk.data_ptr(), K, True, dx, dx.data_ptr(), Ci, S, K, Co)
         return dx
-    if stride == 1 and 2 * pad == k - 1 and 2 * Co <= Ci and dy.is_contiguous(memory_format=CL):
+    if stride == 1 and 2 * pad == k - 1 and 2 * Co <= Ci:
         # a "same" convolution with fewer outputs than inputs (DenseNet's 3 x 3: 128 -> 32): the data gradient is itself a same
         # convolution of dy with the kernel rotated by 180 degrees and its channel roles swapped.  Unfolding dy costs k*k*Co columns
         # per pixel instead of the k*k*Ci of the column-gradient buffer (a quarter here), and there is no col2im pass at all
         # (fp32 DenseNet step: 11.1 + 4.7 ms of column-gradient GEMMs and col2im).
         dyc = im2col(dy, k, 1, pad)                                       # (S, k*k*Co), columns (ky, kx, co)
-        wf = wk.permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous()   # (Ci, k, k, Co): wf[ci,ky,kx,co] = w[co,k-1-ky,k-1-kx,ci]
+        # (Ci, k, k, Co): wf[ci,ky,kx,co] = w[co,k-1-ky,k-1-kx,ci] -- one own launch (was permute + flip + contiguous on ATen)
+        wf = torch.empty((Ci, k * k * Co), device=dy.device, dtype=dy.dtype)
+        check(_lib.lib().mcl_weight_rot180(wk.data_ptr(), wf.data_ptr(), Co, k, Ci, _dt(dy), _stream()), "mcl_weight_rot180")
         dx = torch.empty((B, Ci, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         _gemm(dyc, dyc.data_ptr(), k * k * Co, False, wf, wf.data_ptr(), k * k * Co, False, dx, dx.data_ptr(), Ci, S, Ci, k * k * Co)
         return dx
@@ -220,7 +227,7 @@ class ConvFn(torch.autograd.Function):
         cols = ctx.saved_tensors[2] if ctx.has_cols else None
         stride, pad = ctx.geo
         if not dy.is_contiguous(memory_format=CL):
-            dy = dy.contiguous(memory_format=CL)
+            dy = _dense_cl(dy)
         g_before = None
         if ctx.cap is not None and getattr(ctx.w, "grad", None) is not None:
             g_before = ctx.w.grad.detach().clone()
@@ -245,7 +252,7 @@ class MaxPool3s2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        x = x.contiguous(memory_format=CL)
+        x = _dense_cl(x)
         B, C, H, W = x.shape
         y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=x.dtype, memory_format=CL)
         idx = torch.empty((B, y.shape[2], y.shape[3], C), device=x.device, dtype=torch.uint8)
@@ -259,7 +266,7 @@ class MaxPool3s2Fn(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         B, C, H, W = ctx.shape
-        dy = dy.contiguous(memory_format=CL)
+        dy = _dense_cl(dy)
         dx = torch.empty((B, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         check(_lib.lib().mcl_maxpool3s2_nhwc_bwd_any(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C, _dt(dy),
                                                      _stream()), "mcl_maxpool3s2_nhwc_bwd_any")
@@ -271,7 +278,7 @@ class AvgPool2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        x = x.contiguous(memory_format=CL)
+        x = _dense_cl(x)
         B, C, H, W = x.shape
         y = torch.empty((B, C, H // 2, W // 2), device=x.device, dtype=x.dtype, memory_format=CL)
         check(_lib.lib().mcl_avgpool2_nhwc_any(x.data_ptr(), y.data_ptr(), B, H, W, C, 0, _dt(x), _stream()),
@@ -282,7 +289,7 @@ class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
-        dy = dy.contiguous(memory_format=CL)
+        dy = _dense_cl(dy)
         dx = torch.empty((B, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         check(_lib.lib().mcl_avgpool2_nhwc_any(dy.data_ptr(), dx.data_ptr(), B, H, W, C, 1, _dt(dy), _stream()),
               "mcl_avgpool2_nhwc_any")
@@ -316,7 +323,7 @@ class AddReluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        a, b = a.contiguous(memory_format=CL), b.contiguous(memory_format=CL)
+        a, b = _dense_cl(a), _dense_cl(b)
         y = torch.empty_like(a, memory_format=CL)
         check(_lib.lib().mcl_add_relu(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), 0, _dt(a), _stream()), "mcl_add_relu")
         ctx.save_for_backward(y)
@@ -325,7 +332,7 @@ class AddReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
-        dy = dy.contiguous(memory_format=CL)
+        dy = _dense_cl(dy)
         dx = torch.empty_like(y, memory_format=CL)
         check(_lib.lib().mcl_add_relu(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), 1, _dt(y), _stream()),
               "mcl_add_relu (backward)")
@@ -342,7 +349,7 @@ class Fork2Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g1, g2):
-        g1, g2 = g1.contiguous(memory_format=CL), g2.contiguous(memory_format=CL)
+        g1, g2 = _dense_cl(g1), _dense_cl(g2)
         out = torch.empty_like(g1, memory_format=CL)
         check(_lib.lib().mcl_add_relu(g1.data_ptr(), g2.data_ptr(), out.data_ptr(), g1.numel(), 2, _dt(g1), _stream()),
               "mcl_add_relu (plain add)")

@@ -367,10 +367,13 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const bf16_t* __re
 }
 
 // ---- patch extraction for the patch-embedding GEMM: out[(b*np + py*npw + px)][c*p*p + iy*p + ix] = img[b][c][py*p+iy][px*p+ix]
-// (the flattening of timm's Conv2d(3, D, p, p) weight (D, 3, p, p)); img fp32 with arbitrary strides (NCHW or NHWC)
+// (the flattening of timm's Conv2d(3, D, p, p) weight (D, 3, p, p)); img fp32 with arbitrary strides (NCHW or NHWC).
+// lead = 1: every image's patches are preceded by ONE ZERO ROW (the class-token position of the (B, np + 1, K) token matrix: the
+// patch-embedding weight gradient is then one reduction over all B (np + 1) rows).  OUT = bf16_t or float.
+template <typename OUT>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, long long sb, long long sc,
-                                                       long long sy, long long sx, int B, int H, int W, int p,
-                                                       bf16_t* __restrict__ out) {
+                                                       long long sy, long long sx, int B, int H, int W, int p, int lead,
+                                                       OUT* __restrict__ out) {
   const int npw = W / p, nph = H / p, K = 3 * p * p;
   const long long total = (long long)B * nph * npw * K;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
@@ -379,14 +382,26 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int px = (int)(t % npw), py = (int)((t / npw) % nph);
     const long long b = t / ((long long)npw * nph);
     const int ix = k % p, iy = (k / p) % p, c = k / (p * p);
-    out[q] = f2bf(img[b * sb + c * sc + (long long)(py * p + iy) * sy + (long long)(px * p + ix) * sx]);
+    const float v = img[b * sb + c * sc + (long long)(py * p + iy) * sy + (long long)(px * p + ix) * sx];
+    OUT* o = out + (t + lead * (b + 1)) * K + k;
+    if constexpr (sizeof(OUT) == 2) *o = f2bf(v);
+    else *o = v;
+  }
+  if (lead) {
+    const long long zt = (long long)B * K;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < zt; q += (long long)gridDim.x * 256) {
+      const long long b = q / K;
+      OUT* o = out + b * (long long)(nph * npw + 1) * K + (q - b * K);
+      if constexpr (sizeof(OUT) == 2) *o = (OUT)0;
+      else *o = 0.0f;
+    }
   }
 }
 
 // the same for unit pixel stride and p % 8 == 0 (NCHW batches): a thread moves 8 consecutive pixels of one patch row -- two
 // 16-byte loads, one 16-byte store, one index decode per 8 elements (the scalar form spends its time in 64-bit divisions)
 __global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict__ img, long long sb, long long sc, long long sy,
-                                                        int B, int H, int W, int p, bf16_t* __restrict__ out) {
+                                                        int B, int H, int W, int p, int lead, bf16_t* __restrict__ out) {
   const int npw = W / p, nph = H / p, K8 = 3 * p * p / 8, p8 = p / 8;
   const long long total8 = (long long)B * nph * npw * K8;
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total8; q += (long long)gridDim.x * 256) {
@@ -397,7 +412,14 @@ __global__ __launch_bounds__(256) void patchify8_kernel(const float* __restrict_
     const float* src = img + (long long)b * sb + (long long)c * sc + (long long)(py * p + iy) * sy + (px * p + 8 * ix8);
     const float4 a = *reinterpret_cast<const float4*>(src), d = *reinterpret_cast<const float4*>(src + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
-    *reinterpret_cast<uint4*>(out + q * 8) = pack8(v);
+    *reinterpret_cast<uint4*>(out + ((long long)t + lead * (b + 1)) * K8 * 8 + (long long)k8 * 8) = pack8(v);
+  }
+  if (lead) {
+    const long long zt = (long long)B * K8;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < zt; q += (long long)gridDim.x * 256) {
+      const long long b = q / K8;
+      *reinterpret_cast<uint4*>(out + b * (long long)(nph * npw + 1) * K8 * 8 + (q - b * K8) * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 
@@ -510,25 +532,44 @@ extern "C" int mcl_softmax_bf16_bwd(const void* P, void* dP, int64_t ld, int64_t
   return MCL_OK;
 }
 
-extern "C" int mcl_vit_patchify(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H,
-                                int32_t W, int32_t p, void* out_bf16, mcl_stream_t stream) {
-  MCL_CLEAR_ERROR();
-  if (!img || !out_bf16 || B <= 0 || H <= 0 || W <= 0 || p <= 0) return MCL_EINVAL;
+namespace {
+int launch_patchify(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H, int32_t W, int32_t p,
+                    void* out, int lead, int out_f32, mcl_stream_t stream) {
+  if (!img || !out || B <= 0 || H <= 0 || W <= 0 || p <= 0) return MCL_EINVAL;
   if ((H % p) || (W % p)) return MCL_EUNSUPPORTED;
   const long long total = (long long)B * 3 * H * W;
-  if (sx == 1 && (p % 8) == 0 && (sy % 4) == 0 && (sc % 4) == 0 && (sb % 4) == 0 && !(reinterpret_cast<uintptr_t>(img) & 15u) &&
-      !(reinterpret_cast<uintptr_t>(out_bf16) & 15u) && (long long)B * (H / p) * (W / p) < (1ll << 31)) {
+  if (!out_f32 && sx == 1 && (p % 8) == 0 && (sy % 4) == 0 && (sc % 4) == 0 && (sb % 4) == 0 &&
+      !(reinterpret_cast<uintptr_t>(img) & 15u) && !(reinterpret_cast<uintptr_t>(out) & 15u) &&
+      (long long)B * (H / p) * (W / p) < (1ll << 31)) {
     long long blocks8 = (total / 8 + 255) / 256;
     if (blocks8 > 65535 * 4) blocks8 = 65535 * 4;
     hipLaunchKernelGGL(patchify8_kernel, dim3((unsigned)blocks8), dim3(256), 0, mcl_stream(stream), img, (long long)sb,
-                       (long long)sc, (long long)sy, B, H, W, p, (bf16_t*)out_bf16);
-    MCL_CHECK_LAUNCH();
-    return MCL_OK;
+                       (long long)sc, (long long)sy, B, H, W, p, lead, (bf16_t*)out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MCL_OK : (int)e;
   }
   long long blocks = (total + 255) / 256;
   if (blocks > 65535 * 4) blocks = 65535 * 4;
-  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), img, (long long)sb,
-                     (long long)sc, (long long)sy, (long long)sx, B, H, W, p, (bf16_t*)out_bf16);
-  MCL_CHECK_LAUNCH();
-  return MCL_OK;
+  if (out_f32)
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), img, (long long)sb,
+                       (long long)sc, (long long)sy, (long long)sx, B, H, W, p, lead, (float*)out);
+  else
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, mcl_stream(stream), img, (long long)sb,
+                       (long long)sc, (long long)sy, (long long)sx, B, H, W, p, lead, (bf16_t*)out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MCL_OK : (int)e;
+}
+}  // namespace
+
+extern "C" int mcl_vit_patchify(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H,
+                                int32_t W, int32_t p, void* out_bf16, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  return launch_patchify(img, sb, sc, sy, sx, B, H, W, p, out_bf16, 0, 0, stream);
+}
+
+extern "C" int mcl_vit_patchify_tokens(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int32_t B, int32_t H,
+                                       int32_t W, int32_t p, void* out, int32_t lead_zero_row, int32_t out_f32,
+                                       mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  return launch_patchify(img, sb, sc, sy, sx, B, H, W, p, out, lead_zero_row ? 1 : 0, out_f32 ? 1 : 0, stream);
 }

@@ -113,6 +113,25 @@ def _rows(t: Tensor) -> Tuple[int, int, int, int]:
     return t.data_ptr(), B * H * W, C, ld
 
 
+def dense_cl(t: Tensor) -> Tensor:
+    """``t.contiguous(memory_format=channels_last)`` on an own kernel for the case that occurs inside the encoders: ``t`` is a
+    CHANNEL SLICE of a wider channels-last buffer (rows of C elements at a larger row stride) -- one 2-D copy (mcl_copy_rows)
+    instead of an ATen strided copy.  A tensor that is dense channels-last already is returned as is; a genuinely different
+    layout (an NCHW batch) keeps the torch conversion."""
+    if t.is_contiguous(memory_format=CL):
+        return t
+    B, C, H, W = t.shape
+    ld = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else t.stride(0))
+    ok = (t.is_cuda and t.stride(1) == 1 and (W == 1 or t.stride(3) == ld) and (H == 1 or t.stride(2) == W * ld)
+          and (B == 1 or t.stride(0) == H * W * ld) and ld >= C)
+    if not ok:
+        return t.contiguous(memory_format=CL)
+    out = torch.empty((B, C, H, W), device=t.device, dtype=t.dtype, memory_format=CL)
+    es = t.element_size()
+    check(_lib.lib().mcl_copy_rows(t.data_ptr(), ld * es, out.data_ptr(), C * es, B * H * W, C * es, _stream()), "mcl_copy_rows")
+    return out
+
+
 def _ws(nfloats: int, device) -> Tensor:
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     w = _ws_cache.get(key)
@@ -230,7 +249,7 @@ class BNActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
-        dy = dy.contiguous(memory_format=CL)
+        dy = dense_cl(dy)
         dx = torch.empty_like(x, memory_format=CL)
         direct = DIRECT_PARAM_GRADS and _direct_grad_ok(gamma) and _direct_grad_ok(beta)
         dg, db = bn_act_bwd(dy, x, gamma, beta, mean, rstd, ctx.relu, dx, False, into_param_grads=direct)
@@ -647,7 +666,11 @@ def _conv_bwd(dy: Tensor, x: Tensor, w: Tensor, w_param: Tensor, padding: int, c
     dw is None when it was accumulated straight into ``w_param.grad``, else an fp32 tensor shaped like the parameter.
     ``cols``: the forward's unfolded patches when it kept them."""
     from . import conv_generic as cg
-    dy = dy if dy.is_contiguous(memory_format=CL) else dy.contiguous(memory_format=CL)
+    # (a channel slice of the gradient buffer is read in place: the GEMMs / im2col take a row stride)
+    try:
+        _rows(dy)
+    except RuntimeError:
+        dy = dense_cl(dy)
     dw = cg.conv_bwd_weight(dy, x, w_param, 1, padding, cols)
     dx = cg.conv_bwd_data(dy, w, x.shape, 1, padding)
     return dx, dw
@@ -903,7 +926,7 @@ class DenseBlockFn(torch.autograd.Function):
             buf, adopted = pre.detach(), True
         else:
             buf, adopted = torch.empty((B, Ct, H, W), device=dev, dtype=dt, memory_format=CL), False
-            x0 = x0.contiguous(memory_format=CL)
+            x0 = dense_cl(x0)
         if adopted:
             pass
         elif prefilled:
@@ -977,7 +1000,7 @@ class DenseBlockFn(torch.autograd.Function):
         # the incoming gradient is produced by our own BNActFn for the block's single consumer: accumulate
         # in place into it (no clone) when it is already a dense channels-last tensor
         if not gbuf.is_contiguous(memory_format=CL):
-            gbuf = gbuf.contiguous(memory_format=CL)
+            gbuf = dense_cl(gbuf)
         if ctx.cap is not None:
             ctx.cap["gin"] = gbuf.clone(memory_format=CL)
             ctx.cap["dz"] = [None] * L
@@ -1125,13 +1148,13 @@ class DenseBlockFn(torch.autograd.Function):
                 dz, dg2, db2, _ = dense_conv3x3_bwd(dy_view, w2c, z, g2, b2, m2, r2, into_param_grads=d2)
                 dw2 = None
             else:
-                dy = dy_view.contiguous(memory_format=CL)
+                dy = dy_view                                  # (read in place through its row stride)
                 if a2.numel() == 0:
                     a2 = torch.empty_like(z, memory_format=CL)
                     bn_act_fwd(z, g2, b2, m2, r2, True, a2)
                 da2, dw2 = _conv_bwd(dy, a2, w2c, w2, 1, ctx.kept_cols.pop(l, None))
                 dz = torch.empty_like(z, memory_format=CL)
-                dg2, db2 = bn_act_bwd(da2.contiguous(memory_format=CL), z, g2, b2, m2, r2, True, dz, False,
+                dg2, db2 = bn_act_bwd(dense_cl(da2), z, g2, b2, m2, r2, True, dz, False,
                                       into_param_grads=d2)
             d1 = DIRECT_PARAM_GRADS and _direct_grad_ok(g1) and _direct_grad_ok(b1)
             if fused1:
@@ -1191,7 +1214,7 @@ def _bn_train(x: Tensor, bn: nn.BatchNorm2d, relu: bool, rec: _RunningStats) -> 
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     var = torch.empty_like(mean)
     rstd = torch.empty_like(mean)
-    x = x.contiguous(memory_format=CL)
+    x = dense_cl(x)
     bn_stats(x, mean, var, rstd, bn.eps)
     rec.add(bn, mean, var, x.numel() // C)
     return BNActFn.apply(x, bn.weight, bn.bias, mean, rstd, relu)
@@ -1266,7 +1289,7 @@ class Conv0Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w16 = ctx.saved_tensors
-        dy = dy.contiguous(memory_format=CL)
+        dy = dense_cl(dy)
         w = ctx.w
         if ctx.cap is not None:
             ctx.cap["dy"] = dy
@@ -1306,7 +1329,7 @@ class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
-        dy = dy.contiguous(memory_format=CL)
+        dy = dense_cl(dy)
         dx = torch.empty((B, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         check(_lib.lib().mcl_avgpool2_nhwc_bf16(dy.data_ptr(), dx.data_ptr(), B, H, W, C, 1, _stream()), "mcl_avgpool2")
         return dx
@@ -1330,7 +1353,7 @@ class MaxPool3s2Fn(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         B, C, H, W = ctx.shape
-        dy = dy.contiguous(memory_format=CL)
+        dy = dense_cl(dy)
         dx = torch.empty((B, C, H, W), device=dy.device, dtype=dy.dtype, memory_format=CL)
         check(_lib.lib().mcl_maxpool3s2_nhwc_bf16_bwd(idx.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()),
               "mcl_maxpool bwd")
@@ -1651,7 +1674,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
     else:
         from . import conv_generic as cg
         x = cg.conv2d(x, features.conv0.weight, features.conv0.stride[0], features.conv0.padding[0])
-    x = x.contiguous(memory_format=CL)
+    x = dense_cl(x)
     if _stem_tail_ok(x):
         C0 = x.shape[1]
         if not own_conv0:
@@ -1661,7 +1684,7 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
         x = StemTailFn.apply(x, features.norm0.weight, features.norm0.bias, mean0, rstd0)
     else:
         x = _bn_train(x, features.norm0, True, rec)
-        x = max_pool_3s2(x.contiguous(memory_format=CL))
+        x = max_pool_3s2(dense_cl(x))
     i = 1
     out = None
     next_stats = None
@@ -1701,7 +1724,8 @@ def densenet_features_fused(features: nn.Sequential, x: Tensor, act_dtype: torch
             else:
                 out = BNActFn.apply(buf, features.norm5.weight, features.norm5.bias, stats.mean, stats.rstd, False)
                 if pooled:
-                    out = F.adaptive_avg_pool2d(out.float(), (1, 1)).flatten(1)
+                    from . import conv_generic as _cg
+                    out = _cg.global_avg_pool(out)        # own kernel, fp32 (B, C) (was F.adaptive_avg_pool2d)
             rec.add(features.norm5, stats.mean, stats.var, n)
         i += 1
     rec.flush()
@@ -1747,7 +1771,7 @@ def densenet_features_eval(features: nn.Sequential, x: Tensor, act_dtype: torch.
     rs = {id(bn): r for bn, r in zip(bns, eval_rstd(bns))}
 
     def affine(t: Tensor, bn: nn.BatchNorm2d, relu: bool) -> Tensor:
-        t = t.contiguous(memory_format=CL)
+        t = dense_cl(t)
         out = torch.empty_like(t, memory_format=CL)
         bn_act_fwd(t, bn.weight, bn.bias, bn.running_mean, rs[id(bn)], relu, out)
         return out

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -31,6 +32,10 @@ from ._lib import check
 
 Tensor = torch.Tensor
 
+
+# model -> weakref(the FusedAdam that owns its lazy position tables).  Not an attribute of the model: ``copy.deepcopy(model)`` must
+# not inherit an owner (the copy is attached to its own optimizer).
+_TABLE_OWNERS = weakref.WeakKeyDictionary()
 
 HIST_LEN = 8192      # per-step Adam constants kept for the lazy tables' replay (power of two; 32 B per step)
 
@@ -59,6 +64,13 @@ class FusedAdam(torch.optim.Optimizer):
         self._hook_handles: list = []             # what attach_model() registered on the model (detach_model removes them)
         self._model_ref = None
 
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy(model)`` reaches the optimizer through the hooks attach_model() registered (bound methods): the copied
+        model's hooks keep pointing at THIS optimizer (they materialise this optimizer's tables -- harmless for the copy, which
+        gets an optimizer of its own), never at a field-less clone (torch's Optimizer.__getstate__ drops every attribute added
+        here)."""
+        return self
+
     # ------------------------------------------------------------------ wiring
     def attach_model(self, model) -> "FusedAdam":
         """Registers the model's position tables for the row-sparse update (model.embedding_grad ==
@@ -72,7 +84,8 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 self._group_of[id(p)] = gi
-        prev = getattr(model, "_mcl_table_owner", None)
+        ref = _TABLE_OWNERS.get(model)
+        prev = ref() if ref is not None else None
         if prev is not None and prev is not self:
             # a second optimizer for the same model: the first one's pending replays must land in the tables before this
             # one declares every row current, and its hooks must not pile up on the model
@@ -84,7 +97,7 @@ class FusedAdam(torch.optim.Optimizer):
             # through the module API gets it materialised first.  Bound methods (picklable with the optimizer), handles
             # kept for detach_model().
             model._table_catchup = self.catch_up
-            model._mcl_table_owner = self
+            _TABLE_OWNERS[model] = weakref.ref(self)
             hs = self._hook_handles
             hs.append(model.register_state_dict_pre_hook(self._hook_state_dict_pre))
             if hasattr(model, "register_load_state_dict_pre_hook"):
@@ -124,8 +137,9 @@ class FusedAdam(torch.optim.Optimizer):
         self._hook_handles = []
         m = self._model_ref
         if m is not None:
-            if getattr(m, "_mcl_table_owner", None) is self:
-                m._mcl_table_owner = None
+            ref = _TABLE_OWNERS.get(m)
+            if ref is not None and ref() is self:
+                del _TABLE_OWNERS[m]
             if getattr(m, "_table_catchup", None) == self.catch_up:
                 m._table_catchup = None
         self._model_ref = None

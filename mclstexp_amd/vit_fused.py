@@ -69,6 +69,52 @@ def _w16(w: Tensor) -> Tensor:
     return w.detach().to(BF).contiguous()
 
 
+def _dense_f32(p: Tensor) -> Tensor:
+    """The parameter's fp32 values as a dense array (a view; parameters are contiguous fp32, also inside FusedAdam's flat buffer)."""
+    t = p.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("vit_fused: expected a contiguous fp32 parameter")
+    return t
+
+
+def _patch_weight_matrix(w: Tensor, dt: torch.dtype) -> Tensor:
+    """timm PatchEmbed's Conv2d weight (D, 3, p, p) as the (D, 3 p p) GEMM operand in (c, iy, ix) column order, whatever memory
+    format the parameter has (``model.to(memory_format=channels_last)`` permutes 4-D parameters), in ``dt`` (fp32 / bf16):
+    the parameter itself / FusedAdam's shadow when that already is the matrix, else one own strided pack launch."""
+    D, C, p, _ = w.shape
+    wd = w.detach()
+    if wd.is_contiguous():
+        if dt == torch.float32:
+            return wd.reshape(D, C * p * p)
+        return _w16(wd.reshape(D, C * p * p))
+    out = torch.empty((D, C * p * p), device=w.device, dtype=dt)
+    s0, s1, s2, s3 = wd.stride()
+    check(_lib.lib().mcl_strided4_f32(wd.data_ptr(), D, C, p, p, s0, s1, s2, s3, out.data_ptr(), C * p * p, p * p, p, 1,
+                                      0 if dt == torch.float32 else 1, 0, _st()), "mcl_strided4_f32")
+    return out
+
+
+def _patch_weight_grad(dy: Tensor, patches: Tensor, w: Tensor, rows: int):
+    """d pe.weight from dy (rows, D) and the token-matrix patches (rows, K0).  Straight into ``w.grad`` when that is a dense
+    (D, K0) array; for a channels-last parameter the contiguous result is ADDED into the .grad's own strides by one own launch
+    (no AccumulateGrad add / layout clone); otherwise returned to autograd."""
+    D, C, p, _ = w.shape
+    if w.is_contiguous():
+        gw = linear_wgrad(dy, patches, w, rows)
+        return None if gw is None else gw.view_as(w)
+    K0 = C * p * p
+    gw = torch.empty((D, K0), device=dy.device, dtype=torch.float32)
+    ks = _ksplit(D, K0)
+    gemm(dy, patches, gw, D, K0, rows, dy.shape[-1], K0, K0, flags=A_KM | B_KM | OUT_F32, ksplit=ks, accumulate=False)
+    if _direct_grad_ok(w):
+        g = w.grad
+        s0, s1, s2, s3 = g.stride()
+        check(_lib.lib().mcl_strided4_f32(gw.data_ptr(), D, C, p, p, K0, p * p, p, 1, g.data_ptr(), s0, s1, s2, s3, 0, 1, _st()),
+              "mcl_strided4_f32")
+        return None
+    return gw.view(D, C, p, p)
+
+
 GELU_HANDOFF = True         # 0: fc1 stores the pre-activation, gelu' evaluated in the backward (A/B)
 FUSED_ATTN = True            # 0: batched GEMMs + softmax launches (A/B, T > 224)
 JOIN_EVERY = 4              # encoder blocks between joins of the side stream
@@ -179,18 +225,18 @@ class ViTFn(torch.autograd.Function):
         L = _lib.lib()
         img = image if image.dtype == torch.float32 else image.float()
         # patches with a zero row at the class-token position: (B, T, K0); the weight gradient of the patch embedding
-        # is then ONE reduction over all B*T rows
-        patches = torch.zeros((B, T, K0), device=dev, dtype=BF)
-        tmp = torch.empty((B * npatch, K0), device=dev, dtype=BF)
-        check(L.mcl_vit_patchify(img.data_ptr(), img.stride(0), img.stride(1), img.stride(2), img.stride(3), B, H, W, p,
-                                 tmp.data_ptr(), _st()), "mcl_vit_patchify")
-        patches[:, 1:].copy_(tmp.view(B, npatch, K0))
-        pos16 = vit.pos_embed.detach().to(BF).reshape(T, D).contiguous()
+        # is then ONE reduction over all B*T rows.  Token assembly on own kernels (csrc/glue.hip): no ATen launch.
+        patches = torch.empty((B, T, K0), device=dev, dtype=BF)
+        check(L.mcl_vit_patchify_tokens(img.data_ptr(), img.stride(0), img.stride(1), img.stride(2), img.stride(3), B, H, W, p,
+                                        patches.data_ptr(), 1, 0, _st()), "mcl_vit_patchify_tokens")
+        pos, cls = _dense_f32(vit.pos_embed), _dense_f32(vit.cls_token)
+        pos16 = torch.empty((T, D), device=dev, dtype=BF)
+        check(L.mcl_cast_f32_to_bf16(pos.data_ptr(), D, pos16.data_ptr(), D, T, D, _st()), "mcl_cast_f32_to_bf16")
         x = torch.empty((B, T, D), device=dev, dtype=BF)
-        wpe = pe.weight.detach().contiguous().reshape(D, K0).to(BF)       # (c, iy, ix) order whatever the memory format
+        wpe = _patch_weight_matrix(pe.weight, BF)                            # (D, K0), (c, iy, ix) order whatever the memory format
         gemm(patches, wpe, x, npatch, D, K0, K0, K0, D, a_off=K0, c_off=D, batch=B, sA=(T * K0, 0), sC=(T * D, 0),
              bias=pe.bias, resid=pos16, ldr=D, sRb=0, r_off=D)
-        x[:, 0] = (vit.cls_token.detach().reshape(D) + vit.pos_embed.detach().reshape(T, D)[0]).to(BF)
+        check(L.mcl_vit_cls_row(cls.data_ptr(), pos.data_ptr(), x.data_ptr(), B, T, D, 1, _st()), "mcl_vit_cls_row")
         saved = []
         scale = dh ** -0.5
         fused_attn = FUSED_ATTN and dh == 64 and T <= 224
@@ -223,7 +269,8 @@ class ViTFn(torch.autograd.Function):
             gemm(h1, _w16(m.fc2.weight), x2, M, D, Dh, Dh, Dh, D, bias=m.fc2.bias, resid=x1, ldr=D, sRb=0)
             saved += [x, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h1]
             x = x2
-        feat = x[:, 1:].float().mean(dim=1)                        # global_pool='avg' over the patch tokens
+        feat = torch.empty((B, D), device=dev, dtype=torch.float32)      # global_pool='avg' over the patch tokens
+        check(L.mcl_vit_token_mean_fwd(x.data_ptr(), feat.data_ptr(), B, T, D, 1, _st()), "mcl_vit_token_mean_fwd")
         ctx.save_for_backward(patches, *saved)
         ctx.vit = vit
         ctx.dims = (B, T, D, K0, heads, dh, Tp, npatch)
@@ -241,8 +288,9 @@ class ViTFn(torch.autograd.Function):
         L = _lib.lib()
         from . import densenet_fused as _dn
         scale = dh ** -0.5
-        dx = torch.zeros((B, T, D), device=dev, dtype=BF)
-        dx[:, 1:] = (dfeat / float(npatch)).to(BF).unsqueeze(1)
+        dx = torch.empty((B, T, D), device=dev, dtype=BF)
+        dfeat = dfeat if (dfeat.dtype == torch.float32 and dfeat.is_contiguous()) else dfeat.float().contiguous()
+        check(L.mcl_vit_token_mean_bwd(dfeat.data_ptr(), dx.data_ptr(), B, T, D, 1, _st()), "mcl_vit_token_mean_bwd")
         grads = {}
         nblk = len(vit.blocks)
         for li in range(nblk - 1, -1, -1):
@@ -291,26 +339,111 @@ class ViTFn(torch.autograd.Function):
             if li % JOIN_EVERY == 0:
                 _dn._side_join(dev)      # bounds what stays parked for the side stream (0.7 GB of operands per block)
         # embeddings: position table and class token (fp32 sums over the batch), patch projection
-        dxf = dx.float()
-        dpos = dxf.sum(dim=0, keepdim=True)
-        grads[vit.pos_embed] = dpos
-        grads[vit.cls_token] = dpos[:, :1].clone()
+        tp, accp, retp = _grad_target(vit.pos_embed)
+        tc, accc, retc = _grad_target(vit.cls_token)
+        check(L.mcl_vit_pos_grad(dx.data_ptr(), tp.data_ptr(), tc.data_ptr(), B, T, D, 1, (1 if accp else 0) | (2 if accc else 0),
+                                 _st()), "mcl_vit_pos_grad")
+        grads[vit.pos_embed], grads[vit.cls_token] = retp, retc
         pe = vit.patch_embed.proj
-        dxp = dx.clone()
-        dxp[:, 0] = 0                                            # class-token rows carry no patch
-        gw = linear_wgrad(dxp, patches, pe.weight, M)
-        grads[pe.weight] = None if gw is None else gw.view_as(pe.weight)
-        grads[pe.bias] = bias_grad(dxp, pe.bias, M)
+        # class-token rows carry no patch: zeroed in place (dx is dead after this) for the bias gradient; their patch rows are zero
+        check(L.mcl_vit_zero_cls_rows(dx.data_ptr(), B, T, D, 1, _st()), "mcl_vit_zero_cls_rows")
+        grads[pe.weight] = _patch_weight_grad(dx, patches, pe.weight, M)
+        grads[pe.bias] = bias_grad(dx, pe.bias, M)
         _dn._side_join(dev)
         return (None, None, *[grads.get(prm) for prm in _param_list(vit)])
+
+
+class _EmbedF32Fn(torch.autograd.Function):
+    """timm PatchEmbed + class token + position embedding in fp32: x (B*T, D) = [cls ; patches W^T + b] + pos, on own kernels
+    (patch unfold, exact-fp32 MFMA product, assembly; the backward's token extraction, weight / bias / position / class-token
+    gradients -- written straight into dense .grad buffers where the parameters own them)."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, cls, pos, p):
+        L = _lib.lib()
+        B, Cin, H, W = img.shape
+        nph, npw = H // p, W // p
+        npatch, T = nph * npw, nph * npw + 1
+        D, K0 = w.shape[0], Cin * p * p
+        dev = img.device
+        patches = torch.empty((B * npatch, K0), device=dev, dtype=torch.float32)
+        check(L.mcl_vit_patchify_tokens(img.data_ptr(), img.stride(0), img.stride(1), img.stride(2), img.stride(3), B, H, W, p,
+                                        patches.data_ptr(), 0, 1, _st()), "mcl_vit_patchify_tokens")
+        wm = _patch_weight_matrix(w, torch.float32)
+        with ops.forced_compute(_lib.COMPUTE_F32):
+            tok, _ = ops.linear_fwd(patches, wm, b.detach() if b is not None else None)
+        x = torch.empty((B * T, D), device=dev, dtype=torch.float32)
+        check(L.mcl_vit_assemble_f32(tok.data_ptr(), _dense_f32(cls).data_ptr(), _dense_f32(pos).data_ptr(), x.data_ptr(), B, T, D,
+                                     _st()), "mcl_vit_assemble_f32")
+        ctx.save_for_backward(patches)
+        ctx.params = (w, b, cls, pos)
+        ctx.dims = (B, T, D, Cin, p)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (patches,) = ctx.saved_tensors
+        w, b, cls, pos = ctx.params
+        B, T, D, Cin, p = ctx.dims
+        L = _lib.lib()
+        dx = ops._rowmajor(dx, "dx")
+        if dx.stride(0) != D:
+            raise RuntimeError("vit_fused: the token gradient must be a dense (B*T, D) matrix")
+        dtok = torch.empty((B * (T - 1), D), device=dx.device, dtype=torch.float32)
+        check(L.mcl_vit_tokens_extract(dx.data_ptr(), dtok.data_ptr(), B, T, D, 0, _st()), "mcl_vit_tokens_extract")
+        tp, accp, retp = _grad_target(pos)
+        tc, accc, retc = _grad_target(cls)
+        check(L.mcl_vit_pos_grad(dx.data_ptr(), tp.data_ptr(), tc.data_ptr(), B, T, D, 0, (1 if accp else 0) | (2 if accc else 0),
+                                 _st()), "mcl_vit_pos_grad")
+        with ops.forced_compute(_lib.COMPUTE_F32):
+            K0 = Cin * p * p
+            if w.is_contiguous() and _direct_grad_ok(w) and w.grad.is_contiguous():
+                ops.gemm_raw(D, K0, dtok.shape[0], 1, dtok, 1, D, 0, patches, K0, 1, 0, w.grad, K0, 0, flags=ops.EPI_ACCUM)
+                dw = None
+            else:
+                gw = torch.empty((D, K0), device=dx.device, dtype=torch.float32)
+                ops.gemm_raw(D, K0, dtok.shape[0], 1, dtok, 1, D, 0, patches, K0, 1, 0, gw, K0, 0)
+                if _direct_grad_ok(w):
+                    g = w.grad
+                    s0, s1, s2, s3 = g.stride()
+                    check(L.mcl_strided4_f32(gw.data_ptr(), D, Cin, p, p, K0, p * p, p, 1, g.data_ptr(), s0, s1, s2, s3, 0, 1, _st()),
+                          "mcl_strided4_f32")
+                    dw = None
+                else:
+                    dw = gw.view(D, Cin, p, p)
+            db = ops.colsum(dtok, b) if b is not None else None
+        return None, dw, db, retc, retp, None
+
+
+class _TokenMeanF32Fn(torch.autograd.Function):
+    """timm's global_pool='avg': mean over the patch tokens (class token excluded) of x (B*T, D) fp32 -> (B, D)."""
+
+    @staticmethod
+    def forward(ctx, x, B, T):
+        x = ops._rowmajor(x, "x")
+        D = x.shape[1]
+        if x.stride(0) != D:
+            raise RuntimeError("vit_fused: the token matrix must be dense")
+        feat = torch.empty((B, D), device=x.device, dtype=torch.float32)
+        check(_lib.lib().mcl_vit_token_mean_fwd(x.data_ptr(), feat.data_ptr(), B, T, D, 0, _st()), "mcl_vit_token_mean_fwd")
+        ctx.dims = (B, T, D)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        B, T, D = ctx.dims
+        dfeat = dfeat if (dfeat.dtype == torch.float32 and dfeat.is_contiguous()) else dfeat.float().contiguous()
+        dx = torch.empty((B * T, D), device=dfeat.device, dtype=torch.float32)
+        check(_lib.lib().mcl_vit_token_mean_bwd(dfeat.data_ptr(), dx.data_ptr(), B, T, D, 0, _st()), "mcl_vit_token_mean_bwd")
+        return dx, None, None
 
 
 def vit_features_fp32(vit, image: Tensor) -> Tensor:
     """``VisionTransformer.forward`` in fp32 ("reference numerics": /root/reference/model.py:104-116 computes in fp32) on this
     library's fp32 kernels: every contraction is ``mcl_gemm`` in exact-fp32 MFMA mode, LayerNorm / GELU / bias gradients the
     spot branch's kernels, the attention core csrc/attention.hip with one sequence per image (no (B, heads, T, T) tensor).
-    Token assembly (unfold of the patches, class token, position embedding, final token mean) stays a handful of elementwise
-    torch ops, differentiated by autograd.  (B, D) fp32."""
+    Token assembly (unfold of the patches, class token, position embedding) and the final token mean are own kernels as well
+    (csrc/glue.hip; round 6).  (B, D) fp32."""
     if not image.is_cuda:
         raise RuntimeError("vit_features_fp32: input is on the CPU; the ViT kernels are GPU-only")
     F32 = _lib.COMPUTE_F32
@@ -324,18 +457,14 @@ def vit_features_fp32(vit, image: Tensor) -> Tensor:
     dh = D // heads
     if dh != 64:
         raise RuntimeError(f"vit_features_fp32: head dimension {dh} (the fp32 attention kernel is built for 64)")
-    img = image.float()
-    # (B, npatch, c*p*p) with timm's (c, iy, ix) order inside a patch: one strided copy
-    patches = img.reshape(B, Cin, nph, p, npw, p).permute(0, 2, 4, 1, 3, 5).reshape(B * npatch, Cin * p * p)
-    tok = ops.LinearFn.apply(patches, pe.weight.reshape(D, Cin * p * p), pe.bias, F32).view(B, npatch, D)
-    x = torch.cat([vit.cls_token.expand(B, 1, D), tok], dim=1) + vit.pos_embed
-    x = x.reshape(B * T, D)
+    img = image if image.dtype == torch.float32 else image.float()
+    x = _EmbedF32Fn.apply(img, pe.weight, pe.bias, vit.cls_token, vit.pos_embed, p)          # (B*T, D), own kernels only
     for blk in vit.blocks:
         a, m = blk.attn, blk.mlp
         x = ops.AttnBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.proj.weight, a.proj.bias,
                                   blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
                                   heads, dh, a.qkv.bias, B, float(blk.norm1.eps), F32)
-    feat = x.view(B, T, D)[:, 1:].mean(dim=1)                      # global_pool='avg' over the patch tokens
+    feat = _TokenMeanF32Fn.apply(x, B, T)                          # global_pool='avg' over the patch tokens
     return ops.LayerNormFn.apply(feat, vit.fc_norm.weight, vit.fc_norm.bias, vit.fc_norm.eps)
 
 

@@ -283,11 +283,6 @@ def test_every_encoder_selector_runs_on_own_kernels(encoder_name, dim, dtype, mo
     run()                                                  # (first call: dense .grad tensors are created here, outside the audit)
     ks = kernel_audit.step_kernels(run)
     bad = kernel_audit.foreign(ks)
-    if (encoder_name, dtype, mode) == ("densenet121", "f32", "train") or encoder_name == "vit":
-        # KNOWN GAP (stated in DESIGN.md): these still issue a handful of ATen ELEMENTWISE launches -- strided copies into
-        # the concat buffer (fp32 DenseNet training), the class-token / position-embedding assembly, the final token mean and
-        # dtype casts (ViT).  Every contraction, normalisation, attention and pooling kernel is this library's.
-        glue = ("copy_kernel", "FillFunctor", "CUDAFunctor_add", "MulFunctor", "MeanOps", "sum_functor", "CatArrayBatchedCopy",
-                "DivFunctor", "reduce_kernel", "flip")
-        bad = [k for k in bad if not any(t in k for t in glue)]
+    # (round 6: the former "known gap" -- ATen elementwise launches for the ViT's token assembly / token mean and for the fp32
+    # DenseNet's strided copies, rotated weights and pool -- is closed: csrc/glue.hip; all 20 combinations are strict)
     assert not bad, bad

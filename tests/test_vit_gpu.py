@@ -384,3 +384,80 @@ def test_vit_fp32_selector_and_direct_grads():
     with torch.no_grad():
         y_train = m.encode_image(x)
     assert torch.equal(y_eval, y_train)                    # no dropout / BatchNorm in the encoder: same arithmetic
+
+
+def test_glue_kernels_vs_torch():
+    """csrc/glue.hip: the ViT's token assembly / token mean / embedding gradients, the strided copy, the strided 4-D pack and the
+    rotated weight against the torch expressions they replace (bit for bit where the arithmetic is the same)."""
+    import ctypes as C
+    from mclstexp_amd import _lib
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, T, D, p = 3, 5, 16, 8
+    np_ = T - 1
+    g = torch.Generator().manual_seed(3)
+    cls, pos = torch.randn(D, generator=g).to(DEV), torch.randn(T * D, generator=g).to(DEV)
+    tok = torch.randn(B * np_, D, generator=g).to(DEV)
+    ref = torch.cat([cls.view(1, 1, D).expand(B, 1, D), tok.view(B, np_, D)], dim=1) + pos.view(1, T, D)
+    x = torch.empty(B, T, D, device=DEV)
+    _lib.check(L.mcl_vit_assemble_f32(tok.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), B, T, D, st))
+    assert torch.equal(x, ref)
+    x16 = torch.full((B, T, D), 9.0, device=DEV, dtype=BF)
+    _lib.check(L.mcl_vit_cls_row(cls.data_ptr(), pos.data_ptr(), x16.data_ptr(), B, T, D, 1, st))
+    assert torch.equal(x16[:, 0], (cls + pos[:D]).to(BF).expand(B, D)) and bool((x16[:, 1:] == 9.0).all())
+    for dt, t in ((0, x), (1, ref.to(BF))):
+        feat = torch.empty(B, D, device=DEV)
+        _lib.check(L.mcl_vit_token_mean_fwd(t.data_ptr(), feat.data_ptr(), B, T, D, dt, st))
+        assert_close(feat.cpu(), t[:, 1:].double().mean(dim=1).float().cpu(), 1e-6, 1e-6, what="token mean")
+        dfeat = torch.randn(B, D, generator=g).to(DEV)
+        dx = torch.empty_like(t)
+        _lib.check(L.mcl_vit_token_mean_bwd(dfeat.data_ptr(), dx.data_ptr(), B, T, D, dt, st))
+        want = torch.zeros(B, T, D, device=DEV)
+        want[:, 1:] = (dfeat / float(np_)).unsqueeze(1)
+        assert torch.equal(dx, want.to(t.dtype))
+        dtok = torch.empty(B * np_, D, device=DEV, dtype=t.dtype)
+        _lib.check(L.mcl_vit_tokens_extract(t.data_ptr(), dtok.data_ptr(), B, T, D, dt, st))
+        assert torch.equal(dtok.view(B, np_, D), t[:, 1:])
+        dpos, dcls = torch.ones(T * D, device=DEV), torch.ones(D, device=DEV)
+        _lib.check(L.mcl_vit_pos_grad(t.data_ptr(), dpos.data_ptr(), dcls.data_ptr(), B, T, D, dt, 1, st))    # += dpos, = dcls
+        s = t.float().sum(dim=0).reshape(-1)
+        assert_close(dpos.cpu(), (1.0 + s).cpu(), 1e-6, 1e-6, what="dpos (accumulated)")
+        assert_close(dcls.cpu(), s[:D].cpu(), 1e-6, 1e-6, what="dcls (overwritten)")
+        z = t.clone()
+        _lib.check(L.mcl_vit_zero_cls_rows(z.data_ptr(), B, T, D, dt, st))
+        assert bool((z[:, 0] == 0).all()) and torch.equal(z[:, 1:], t[:, 1:])
+    # patch tokens with a leading zero row, bf16 and fp32, NCHW and channels-last images
+    img = torch.rand(B, 3, 2 * p, 2 * p, generator=g).to(DEV)
+    K0 = 3 * p * p
+    want = img.reshape(B, 3, 2, p, 2, p).permute(0, 2, 4, 1, 3, 5).reshape(B, 4, K0)
+    for im in (img, img.contiguous(memory_format=torch.channels_last)):
+        for f32 in (0, 1):
+            out = torch.full((B, 5, K0), 7.0, device=DEV, dtype=torch.float32 if f32 else BF)
+            _lib.check(L.mcl_vit_patchify_tokens(im.data_ptr(), *im.stride(), B, 2 * p, 2 * p, p, out.data_ptr(), 1, f32, st))
+            assert bool((out[:, 0] == 0).all()) and torch.equal(out[:, 1:], want.to(out.dtype))
+    # strided 4-D pack (a channels-last Conv2d weight -> (D, c, iy, ix) matrix, with the cast) and its accumulating inverse
+    w = torch.randn(6, 3, p, p, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    for dt, tdt in ((0, torch.float32), (1, BF)):
+        m = torch.empty(6, K0, device=DEV, dtype=tdt)
+        _lib.check(L.mcl_strided4_f32(w.data_ptr(), 6, 3, p, p, *w.stride(), m.data_ptr(), K0, p * p, p, 1, dt, 0, st))
+        assert torch.equal(m, w.reshape(6, K0).to(tdt))
+    gacc = torch.ones_like(w)                                                 # channels-last strides
+    gw = torch.randn(6, K0, generator=g).to(DEV)
+    _lib.check(L.mcl_strided4_f32(gw.data_ptr(), 6, 3, p, p, K0, p * p, p, 1, gacc.data_ptr(), *gacc.stride(), 0, 1, st))
+    assert torch.equal(gacc, 1.0 + gw.view(6, 3, p, p))
+    # 2-D row copy: a channel slice of a channels-last buffer -> dense rows (16-, 4- and 2-byte paths)
+    for C_, c0, c1, tdt in ((64, 8, 40, torch.float32), (64, 3, 12, torch.float32), (67, 5, 20, BF)):
+        buf = torch.randn(2, C_, 5, 7, generator=g).to(DEV).to(tdt).contiguous(memory_format=torch.channels_last)
+        sl = buf[:, c0:c1]
+        from mclstexp_amd.densenet_fused import dense_cl
+        d = dense_cl(sl)
+        assert d.is_contiguous(memory_format=torch.channels_last) and torch.equal(d, sl)
+    # rotated, role-swapped weight of the backward-data "same" convolution
+    Co, k, Ci = 5, 3, 7
+    wk = torch.randn(Co, Ci, k, k, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)     # (Co, k, k, Ci) storage
+    for dt, tdt in ((0, torch.float32), (1, BF)):
+        a = wk.to(tdt).contiguous(memory_format=torch.channels_last)
+        wf = torch.empty(Ci, k * k * Co, device=DEV, dtype=tdt)
+        _lib.check(L.mcl_weight_rot180(a.data_ptr(), wf.data_ptr(), Co, k, Ci, dt, st))
+        ref_wf = a.permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous().reshape(Ci, k * k * Co)
+        assert torch.equal(wf, ref_wf)
