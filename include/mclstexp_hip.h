@@ -398,6 +398,23 @@ int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, const void* x, 
                       float* dgamma, float* dbeta, int32_t accumulate_params, void* gbuf, int64_t ldg,
                       mcl_stream_t stream);
 
+/* Round 6 -- two consecutive layers' dx passes as ONE pass over the channels both read (the BatchNorm-1 backward of the 56 x 56 /
+ * 28 x 28 dense blocks re-reads and re-writes the block's whole growing gradient buffer once per layer: O(L^2) bytes).
+ *   mcl_dense_bn1_dx_window  mcl_dense_bn1_dx restricted to the channel window [c0, c0 + nc) of the layer's C input channels
+ *                            (c0 % 8 == 0): layer l's term on the 32 channels layer l-1 produced, which layer l-1's 3x3
+ *                            backward consumes next;
+ *   mcl_dense_bn1_dx_pair    gbuf[:, 0:C] += term_A + term_B for layer A = l (input C + 32 channels: W1A rows are ldwA long) and
+ *                            layer B = l - 1 (input C channels), x and gbuf read once, gbuf written once; both dz W1 products
+ *                            recomputed on the matrix cores; the two deltas are added in fp32 and rounded to bf16 once.
+ * Operands as mcl_dense_bn1_dx (coef = that layer's mcl_dense_bn1_wrw output).                                             */
+int mcl_dense_bn1_dx_window(const void* dz, const void* W1, int32_t C, int32_t c0, int32_t nc, const void* x, int64_t ldx,
+                            int64_t S, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                            const float* coef, void* gbuf, int64_t ldg, mcl_stream_t stream);
+int mcl_dense_bn1_dx_pair(const void* dzA, const void* W1A, int32_t ldwA, const float* gammaA, const float* betaA,
+                          const float* coefA, const void* dzB, const void* W1B, const float* gammaB, const float* betaB,
+                          const float* coefB, int32_t C, const void* x, int64_t ldx, int64_t S, const float* mean,
+                          const float* rstd, void* gbuf, int64_t ldg, mcl_stream_t stream);
+
 /* Deterministic replacement of the reduce launch of mcl_dense_bn1_bwd AND of the bottleneck weight gradient
  * (csrc/wrw_fused.hip): one pass over (dz, x) forms the Gram matrices R = dz^T mask and Qx = dz^T (mask*x) and from
  * them  dW1 (+)= dz^T relu(bn1(x))  [accumulate_w != 0: += into the parameter's fp32 .grad (128, C) contiguous],

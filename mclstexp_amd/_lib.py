@@ -163,6 +163,8 @@ PROTOTYPES = {
     "mcl_dense_conv3x3_wrw_det": [c_p, c_l, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p],
     "mcl_wrw_workspace_floats": [c_l, c_i, c_i],
     "mcl_dense_bn1_wrw": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p],
+    "mcl_dense_bn1_dx_window": [c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "mcl_dense_bn1_dx_pair": [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_l, c_p],
     "mcl_dense_bn1_dx": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "mcl_dense_bn1_dx_sums": [c_p, c_p, c_i, c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_l, c_p],
     "mcl_dense_bn1_fix": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p, c_p],

@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // that is first dz, then x, then (dx launch) the bf16 deltas: 64 KB, two workgroups per CU.
 template <int MODE, int TMv>
 __global__ __launch_bounds__(256, (TMv == 64 && MODE != 2 ? 3 : 2)) void bn1_bwd_kernel(const bf16_t* __restrict__ dz, const bf16_t* __restrict__ W1,
-                                                         int K /* C_in: row length of W1 */,
+                                                         int K /* channels of this launch */, int ldw /* row length of W1 (>= K: a channel window) */,
                                                          const bf16_t* __restrict__ x, long long ldx, long long S,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, (TMv == 64 && MODE != 2 ? 3 : 2)) void bn1_bwd
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = rr + 16 * i;
-      wv[i] = cok ? *reinterpret_cast<const uint4*>(W1 + (long long)k * K + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      wv[i] = cok ? *reinterpret_cast<const uint4*>(W1 + (long long)k * ldw + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -234,6 +234,169 @@ __global__ __launch_bounds__(256, (TMv == 64 && MODE != 2 ? 3 : 2)) void bn1_bwd
             }
             *reinterpret_cast<uint4*>(gbuf + rg * ldg + n0 + cc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
           }
+        }
+      }
+    }
+  }
+}
+
+// ---- the dx pass of TWO consecutive layers (A = l: W1A rows ldwA long; B = l - 1: W1B rows K long) over their common K input
+// channels: 64-pixel row tiles, both 128 x 128 weight blocks resident (2 x 32 KB), ONE shared 16 KB tile that is dzA, then dzB,
+// then x / the bf16 deltas: 80 KB, two workgroups per CU.  Same fragments, swizzles and rounding points as bn1_bwd_kernel<1, 64>;
+// the two layers' deltas are added in fp32 and rounded to bf16 ONCE (the sequential form rounds each).
+constexpr size_t PAIR_LDS = 2 * TK * 256 + 64 * 256;
+__global__ __launch_bounds__(256, 2) void bn1_dx_pair_kernel(const bf16_t* __restrict__ dzA, const bf16_t* __restrict__ W1A, int ldwA,
+                                                             const float* __restrict__ gammaA, const float* __restrict__ betaA,
+                                                             const float* __restrict__ coefA, const bf16_t* __restrict__ dzB,
+                                                             const bf16_t* __restrict__ W1B, const float* __restrict__ gammaB,
+                                                             const float* __restrict__ betaB, const float* __restrict__ coefB,
+                                                             int K, const bf16_t* __restrict__ x, long long ldx, long long S,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             bf16_t* gbuf, long long ldg, int nrt) {
+  constexpr int TMv = 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.y * TN;
+  unsigned char* wtA = lds;
+  unsigned char* wtB = lds + TK * 256;
+  unsigned char* dzt = lds + 2 * TK * 256;
+  bf16_t* xt = reinterpret_cast<bf16_t*>(dzt);
+  const int cc = tid & 15, rr = tid >> 4;
+  const bool cok = n0 + cc * 8 < K;
+  constexpr int NL = TMv / 16;
+  uint4 dar[NL], dbr[NL], xr[NL], gr[NL];
+  auto issue_loads = [&](int rt) {
+    const long long row0 = (long long)rt * TMv;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const long long rg = row0 + rr + 16 * i;
+      const bool ok = rg < S;
+      dar[i] = ok ? *reinterpret_cast<const uint4*>(dzA + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      dbr[i] = ok ? *reinterpret_cast<const uint4*>(dzB + rg * TK + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      xr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(x + rg * ldx + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      gr[i] = (ok && cok) ? *reinterpret_cast<const uint4*>(gbuf + rg * ldg + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  if ((int)blockIdx.x < nrt) issue_loads(blockIdx.x);
+  {
+    uint4 wa[8], wb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = rr + 16 * i;
+      wa[i] = cok ? *reinterpret_cast<const uint4*>(W1A + (long long)k * ldwA + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+      wb[i] = cok ? *reinterpret_cast<const uint4*>(W1B + (long long)k * K + n0 + cc * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = rr + 16 * i;
+      const int f = ((k & 3) << 2) | ((k >> 2) & 3);
+      *reinterpret_cast<uint4*>(wtA + k * 256 + ((cc ^ f) << 4)) = wa[i];
+      *reinterpret_cast<uint4*>(wtB + k * 256 + ((cc ^ f) << 4)) = wb[i];
+    }
+  }
+  // per-channel constants of this lane's two channels: the statistics are the channels' (shared), the affine / mean terms per layer
+  float scA[2], shA[2], scB[2], shB[2], ka[2], kb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = n0 + wn * 64 + j * 32 + l31;
+    const bool cv = c < K;
+    const float mu = cv ? mean[c] : 0.0f, rs = cv ? rstd[c] : 0.0f;
+    scA[j] = cv ? gammaA[c] * rs : 0.0f;
+    shA[j] = cv ? fmaf(-mu, scA[j], betaA[c]) : 0.0f;
+    scB[j] = cv ? gammaB[c] * rs : 0.0f;
+    shB[j] = cv ? fmaf(-mu, scB[j], betaB[c]) : 0.0f;
+    const float c1A = cv ? coefA[2 * c] : 0.0f, c2A = cv ? coefA[2 * c + 1] : 0.0f;
+    const float c1B = cv ? coefB[2 * c] : 0.0f, c2B = cv ? coefB[2 * c + 1] : 0.0f;
+    // dx_L = sc_L*(g_L - c1_L - xhat*c2_L) = sc_L*g_L + (ka_L*x + kb_L), as bn1_bwd_kernel<1>; the two affine parts added
+    const float kaA = -scA[j] * c2A * rs, kaB = -scB[j] * c2B * rs;
+    const float kbA = fmaf(-kaA, mu, -scA[j] * c1A), kbB = fmaf(-kaB, mu, -scB[j] * c1B);
+    ka[j] = kaA + kaB;
+    kb[j] = kbA + kbB;
+  }
+  const int q = (lane & 15) >> 2, jj = lane & 3;
+  const int g2 = 2 * ((lane >> 4) & 1) + (jj >> 1);
+  auto product = [&](const unsigned char* wt, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int r = wm * (TMv / 2) + l31;
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(dzt + r * 256 + (((2 * ks + h) ^ (r & 15)) << 4));
+      bf16x8 fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int chunk = (wn * 64 + j * 32) / 8 + g2;
+        const int k_lo = 16 * ks + 8 * h + q, k_hi = k_lo + 4;
+        const int f_lo = ((k_lo & 3) << 2) | ((k_lo >> 2) & 3), f_hi = ((k_hi & 3) << 2) | ((k_hi >> 2) & 3);
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(wt + k_lo * 256 + ((chunk ^ f_lo) << 4) + (jj & 1) * 8));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (v4s __attribute__((address_space(3)))*)(wt + k_hi * 256 + ((chunk ^ f_hi) << 4) + (jj & 1) * 8));
+        fb[j][0] = lo[0]; fb[j][1] = lo[1]; fb[j][2] = lo[2]; fb[j][3] = lo[3];
+        fb[j][4] = hi[0]; fb[j][5] = hi[1]; fb[j][6] = hi[2]; fb[j][7] = hi[3];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+    }
+  };
+  for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+    const long long row0 = (long long)rt * TMv;
+    if (rt != (int)blockIdx.x) issue_loads(rt);
+    __syncthreads();   // the previous row tile is done with the shared tile (and, first trip, the weights are staged below)
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int r = rr + 16 * i;
+      *reinterpret_cast<uint4*>(dzt + r * 256 + ((cc ^ (r & 15)) << 4)) = dar[i];
+    }
+    __syncthreads();
+    f32x16 accA[2], accB[2];
+    product(wtA, accA);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int r = rr + 16 * i;
+      *reinterpret_cast<uint4*>(dzt + r * 256 + ((cc ^ (r & 15)) << 4)) = dbr[i];
+    }
+    __syncthreads();
+    product(wtB, accB);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NL; ++i) *reinterpret_cast<uint4*>(xt + (rr + 16 * i) * TN + cc * 8) = xr[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cl = wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (TMv / 2) + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float xv = bf2f(xt[row * TN + cl]);
+        const float gA = fmaf(xv, scA[j], shA[j]) > 0.0f ? accA[j][r] : 0.0f;
+        const float gB = fmaf(xv, scB[j], shB[j]) > 0.0f ? accB[j][r] : 0.0f;
+        xt[row * TN + cl] = f2bf(fmaf(scA[j], gA, fmaf(scB[j], gB, fmaf(ka[j], xv, kb[j]))));
+      }
+    }
+    __syncthreads();
+    if (cok) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int r = rr + 16 * i;
+        const long long rg = row0 + r;
+        if (rg < S) {
+          const uint4 dv = *reinterpret_cast<const uint4*>(xt + r * TN + cc * 8);
+          const unsigned gw[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+          unsigned o[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float lo = __uint_as_float(gw[u] << 16) + __uint_as_float(dw[u] << 16);
+            const float hi = __uint_as_float(gw[u] & 0xFFFF0000u) + __uint_as_float(dw[u] & 0xFFFF0000u);
+            const f32x2 pv = {lo, hi};
+            o[u] = __builtin_bit_cast(unsigned, __builtin_convertvector(pv, bf16x2_t));
+          }
+          *reinterpret_cast<uint4*>(gbuf + rg * ldg + n0 + cc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
         }
       }
     }
@@ -908,7 +1071,7 @@ extern "C" int mcl_dense_bn1_bwd(const void* dz, const void* W1, int32_t C, cons
   if (gx > nrt) gx = nrt;
   dim3 grid(gx, nct);
 #define MCL_BN1(MODE, TMV, COEF, GB, LDG, PART)                                                                         \
-  hipLaunchKernelGGL((bn1_bwd_kernel<MODE, TMV>), grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,       \
+  hipLaunchKernelGGL((bn1_bwd_kernel<MODE, TMV>), grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, C,    \
                      (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, COEF, GB, LDG, PART, nrt)
   MCL_BN1(0, 64, (const float*)nullptr, (bf16_t*)nullptr, 0LL, part);
   hipLaunchKernelGGL(bn1_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float2*)part, nrt, C,
@@ -944,7 +1107,7 @@ extern "C" int mcl_dense_bn1_dx_sums(const void* dz, const void* W1, int32_t C, 
   const int gcap = S >= 50000 ? 512 : 768;
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
-  hipLaunchKernelGGL((bn1_bwd_kernel<2, 64>), dim3(gx, nct), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C,
+  hipLaunchKernelGGL((bn1_bwd_kernel<2, 64>), dim3(gx, nct), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)W1, C, C,
                      (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd,
                      have_prev ? (const float*)kprev : (const float*)nullptr,
                      (bf16_t*)gbuf, (long long)ldg, part, nrt);
@@ -972,12 +1135,12 @@ extern "C" int mcl_dense_bn1_fix(const void* x, int64_t ldx, void* gbuf, int64_t
 
 // dx pass alone: gbuf += gamma*rstd*(g - coef[2c] - xhat*coef[2c+1]),  g = relu'(.)*(dz W1), with the two means per channel
 // supplied by the caller (mcl_dense_bn1_wrw derives them from the weight-gradient Gram matrices: no reduce launch).
-extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
-                                const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                const float* coef, void* gbuf, int64_t ldg, mcl_stream_t stream) {
-  MCL_CLEAR_ERROR();
-  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !coef || !gbuf || S <= 0 || C <= 0) return MCL_EINVAL;
-  if ((C % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
+namespace {
+int bn1_dx_impl(const void* dz, const void* W1, int32_t C, int32_t ldw, const void* x, int64_t ldx, int64_t S, const float* gamma,
+                const float* beta, const float* mean, const float* rstd, const float* coef, void* gbuf, int64_t ldg,
+                mcl_stream_t stream) {
+  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !coef || !gbuf || S <= 0 || C <= 0 || ldw < C) return MCL_EINVAL;
+  if ((C % 8) || (ldw % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dz) & 15u) ||
       (reinterpret_cast<uintptr_t>(W1) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
       (reinterpret_cast<uintptr_t>(gbuf) & 15u))
     return MCL_EUNSUPPORTED;
@@ -986,8 +1149,61 @@ extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const
   int gx = (gcap + nct - 1) / nct;
   if (gx > nrt) gx = nrt;
   hipLaunchKernelGGL((bn1_bwd_kernel<1, 64>), dim3(gx, nct), dim3(256), 0, mcl_stream(stream), (const bf16_t*)dz,
-                     (const bf16_t*)W1, C, (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, coef,
+                     (const bf16_t*)W1, C, ldw, (const bf16_t*)x, (long long)ldx, (long long)S, gamma, beta, mean, rstd, coef,
                      (bf16_t*)gbuf, (long long)ldg, (float2*)nullptr, nrt);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+}  // namespace
+
+extern "C" int mcl_dense_bn1_dx(const void* dz, const void* W1, int32_t C, const void* x, int64_t ldx, int64_t S,
+                                const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                const float* coef, void* gbuf, int64_t ldg, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  return bn1_dx_impl(dz, W1, C, C, x, ldx, S, gamma, beta, mean, rstd, coef, gbuf, ldg, stream);
+}
+
+// The same pass over a channel WINDOW [c0, c0 + nc) of the layer's input (round 6, the paired form below): every per-channel
+// pointer (W1 column, x, gamma, beta, mean, rstd, coef (2 floats per channel), gbuf) is offset by c0 here.
+extern "C" int mcl_dense_bn1_dx_window(const void* dz, const void* W1, int32_t C, int32_t c0, int32_t nc, const void* x,
+                                       int64_t ldx, int64_t S, const float* gamma, const float* beta, const float* mean,
+                                       const float* rstd, const float* coef, void* gbuf, int64_t ldg, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (c0 < 0 || nc <= 0 || c0 + nc > C || (c0 % 8)) return MCL_EINVAL;
+  if (!dz || !W1 || !x || !gamma || !beta || !mean || !rstd || !coef || !gbuf) return MCL_EINVAL;
+  return bn1_dx_impl(dz, (const bf16_t*)W1 + c0, nc, C, (const bf16_t*)x + c0, ldx, S, gamma + c0, beta + c0, mean + c0, rstd + c0,
+                     coef + 2 * c0, (bf16_t*)gbuf + c0, ldg, stream);
+}
+
+// TWO layers' dx passes as ONE pass over the channels both read (round 6): layer A = l (its input has C + 32
+// channels: W1A rows are ldwA long) and layer B = l - 1 (C channels).  gbuf[:, 0:C] += termA + termB with x and the gradient buffer
+// read once and the buffer written once -- the traffic of one pass instead of two; both da = dz W1 products are recomputed on the
+// matrix cores.  (Layer A's term on its last 32 input channels, which layer B's 3x3 backward consumes, is applied before by
+// mcl_dense_bn1_dx_window.)
+extern "C" int mcl_dense_bn1_dx_pair(const void* dzA, const void* W1A, int32_t ldwA, const float* gammaA, const float* betaA,
+                                     const float* coefA, const void* dzB, const void* W1B, const float* gammaB,
+                                     const float* betaB, const float* coefB, int32_t C, const void* x, int64_t ldx, int64_t S,
+                                     const float* mean, const float* rstd, void* gbuf, int64_t ldg, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!dzA || !W1A || !gammaA || !betaA || !coefA || !dzB || !W1B || !gammaB || !betaB || !coefB || !x || !mean || !rstd || !gbuf ||
+      S <= 0 || C <= 0 || ldwA < C)
+    return MCL_EINVAL;
+  if ((C % 8) || (ldwA % 8) || (ldx % 8) || (ldg % 8) || (reinterpret_cast<uintptr_t>(dzA) & 15u) ||
+      (reinterpret_cast<uintptr_t>(dzB) & 15u) || (reinterpret_cast<uintptr_t>(W1A) & 15u) ||
+      (reinterpret_cast<uintptr_t>(W1B) & 15u) || (reinterpret_cast<uintptr_t>(x) & 15u) ||
+      (reinterpret_cast<uintptr_t>(gbuf) & 15u))
+    return MCL_EUNSUPPORTED;
+  static mcl_device_once attr_once;
+  if (auto guard = attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn1_dx_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)PAIR_LDS);
+  const int nrt = (int)((S + 63) / 64), nct = (C + TN - 1) / TN;
+  const int gcap = 512;
+  int gx = (gcap + nct - 1) / nct;
+  if (gx > nrt) gx = nrt;
+  hipLaunchKernelGGL(bn1_dx_pair_kernel, dim3(gx, nct), dim3(256), PAIR_LDS, mcl_stream(stream), (const bf16_t*)dzA,
+                     (const bf16_t*)W1A, ldwA, gammaA, betaA, coefA, (const bf16_t*)dzB, (const bf16_t*)W1B, gammaB, betaB, coefB, C,
+                     (const bf16_t*)x, (long long)ldx, (long long)S, mean, rstd, (bf16_t*)gbuf, (long long)ldg, nrt);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

@@ -613,19 +613,9 @@ enum { PE_PLAIN = 0, PE_GELU2 = 1, PE_GELU1 = 2, PE_GBWD2 = 3, PE_GBWD1 = 4, PE_
 
 // Straight from the registers.  Block (i, j) in the transposed MFMA layout: this lane = row m = i*32 + l31, register r = column
 // (r & 3) + 8 (r >> 2) + 4 h of the 32-column block j: four groups of 4 consecutive columns.
-__device__ __forceinline__ void pipe_store16(bf16_t* p, u32x4 v, int dbg) {
-  if (dbg & 32) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
-  else if (dbg & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-  else if (dbg & 128) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
-  else if (dbg & 256) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else *reinterpret_cast<u32x4*>(p) = v;
-}
-
-// DEFER (experiment, MCL_GEMM_PIPE=3): the first result's sixteen 16-byte stores are not issued here but parked in `pk` (64
-// registers) and trickled out one per half-tile by the next tile's loop.
-template <int EPI, int WN, bool DEFER = false>
+template <int EPI, int WN>
 __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2], const PipeTile& cur, int wm, int wn, int h,
-                                              int l31, u32x4* pk = nullptr, bf16_t** pk_row = nullptr) {
+                                              int l31) {
   const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 64;
   constexpr bool has_x = EPI == PE_GBWD2 || EPI == PE_GBWD1 || EPI == PE_RESID;
   // one 64-bit row base per lane and tensor; a block adds a wave-uniform offset
@@ -731,7 +721,7 @@ __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2
             swap_lo_hi(P[2 * pr][0], P[2 * pr + 1][0]);
             swap_lo_hi(P[2 * pr][1], P[2 * pr + 1][1]);
             if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
-              pipe_store16(po + 16 * pr, u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]}, g.dbg);
+              *reinterpret_cast<u32x4*>(po + 16 * pr) = u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]};
           }
         }
       }
@@ -747,23 +737,21 @@ __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2
       for (int pr = 0; pr < 2; ++pr) {
         swap_lo_hi(P[2 * pr][0], P[2 * pr + 1][0]);
         swap_lo_hi(P[2 * pr][1], P[2 * pr + 1][1]);
-        if (DEFER) pk[(j * 4 + i) * 2 + pr] = u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]};
-        else if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
-          pipe_store16(o + 16 * pr, u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]}, g.dbg);
+        if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
+          *reinterpret_cast<u32x4*>(o + 16 * pr) = u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]};
       }
     }
   }
-  if (DEFER) *pk_row = crow;
 }
 
-// WN = wave columns of the workgroup: 4 -> 8 waves, 256 x 256 tile, four 32 KB slots, one workgroup per CU;
-//                                      2 -> 4 waves, 256 x 128 tile, three 24 KB slots (72 KB), TWO workgroups per CU: independent
-// instruction streams on every SIMD, started half a tile apart (the second workgroup of a CU -- odd hardware wave slot -- sleeps
-// `dephase` x 2048 cycles first; the first one has the matrix pipe to itself meanwhile), so that one workgroup's epilogue (GELU on the
-// VALU, the tile's stores) runs beside the other's MFMA loop and the chip's stores are spread over time instead of arriving as
-// one burst per round of tiles.
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int WN, int DBG = 0, bool DEFER = false>
-__global__ __launch_bounds__(128 * WN, (DEFER ? 1 : 2)) void gemm_bf16_pipe_kernel(GemmB g, int total_virtual, int dephase) {
+// WN = wave columns of the workgroup: 4 -> 8 waves, 256 x 256 tile, four 32 KB slots, one workgroup per CU (what is built);
+//                                      2 -> 4 waves, 256 x 128 tile, three 24 KB slots: two independent workgroups per CU.  The second
+// form was built to let one workgroup's epilogue run beside the other's MFMA loop and measured SLOWER on every ViT shape -- with
+// the workgroups started half a tile apart, at one workgroup per CU, and with the tile's stores trickled out one per half-tile
+// of the next tile from parked registers (profiles/r06_gemm_pipe_experiments.txt); the code path stays generic, only WN = 4 is
+// instantiated.
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int WN, int DBG = 0>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_pipe_kernel(GemmB g, int total_virtual) {
   constexpr int NW = 2 * WN;                      // waves
   constexpr int BM = 256, BN = 64 * WN;
   constexpr int HK = 32, HSUB = 8192;             // half-K; bytes per half sub-tile (128 rows or columns x 32 k)
@@ -852,16 +840,6 @@ __global__ __launch_bounds__(128 * WN, (DEFER ? 1 : 2)) void gemm_bf16_pipe_kern
 
   PipeTile cur, nxt;
   if (!next_tile(cur)) return;
-  if (WN == 4 && dephase > 0) {              // experiment: every other CU of an XCD starts late (spreads the chip's store bursts)
-    if ((blockIdx.x >> 3) & 1)
-      for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(32);
-  }
-  if (WN == 2 && dephase > 0) {
-    // second workgroup of this CU (the hardware wave slot of its waves is odd): start half a tile late
-    const unsigned wslot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_REG_HW_ID[3:0] = wave id on the SIMD
-    if (wslot & 1)
-      for (int i = 0; i < dephase; ++i) __builtin_amdgcn_s_sleep(32);
-  }
   bool nxt_valid = false, pf_in_nxt = false, pf_active = true;
   int pf_x = 0;                  // half-tile of the prefetch cursor inside its tile
   unsigned spf = 0, sc = 0;      // ring slots of the prefetch cursor and of the compute cursor
@@ -937,20 +915,6 @@ __global__ __launch_bounds__(128 * WN, (DEFER ? 1 : 2)) void gemm_bf16_pipe_kern
 #pragma unroll
   for (int i = 0; i < 4; ++i) fa0[i] = read_a(0, 0, i);
 
-  // DEFER: the previous tile's packed result and how many of its 16 stores are out
-  u32x4 pk[16];
-  bf16_t* pk_row = nullptr;
-  int pk_next = 16;
-  auto deferred_store = [&](int sidx) {
-    // store s = (j*4 + i)*2 + pr of the parked tile: row block i, 32-column half j, 16-column pair pr
-#define MCL_DS(S) case S: *reinterpret_cast<u32x4*>(pk_row + (long long)(((S >> 1) & 3) * 32) * g.ldc + (S >> 3) * 32 + 16 * (S & 1)) = pk[S]; break;
-    switch (sidx) {
-      MCL_DS(0) MCL_DS(1) MCL_DS(2) MCL_DS(3) MCL_DS(4) MCL_DS(5) MCL_DS(6) MCL_DS(7)
-      MCL_DS(8) MCL_DS(9) MCL_DS(10) MCL_DS(11) MCL_DS(12) MCL_DS(13) MCL_DS(14) MCL_DS(15)
-      default: break;
-    }
-#undef MCL_DS
-  };
   bool first_tile = true;
   // stores per wave and tile of this epilogue form: 16 (one bf16 result) or 32 (two results / fp32)
   const int S = (EPI == PE_GELU2 || EPI == PE_F32 || (EPI == PE_GELU1 && g.pre_out != nullptr)) ? 32 : 16;
@@ -977,21 +941,12 @@ __global__ __launch_bounds__(128 * WN, (DEFER ? 1 : 2)) void gemm_bf16_pipe_kern
       MCL_MFMA(2, 1, fa0, fb0); fa1[3] = read_a(s0, 1, 3); MCL_SB();
       MCL_MFMA(3, 0, fa0, fb0); MCL_SB();
       dma_part(0);
-      bool stored_now = false;
-      if (DEFER && pk_next < 16) {
-        deferred_store(pk_next);
-        ++pk_next;
-        stored_now = true;
-      }
       MCL_SB();
       MCL_MFMA(3, 1, fa0, fb0); MCL_SB();
       // own pieces of g+1 landed (counted: the younger pieces -- and, right after an epilogue, its stores, which sit between
       // them in issue order -- stay in flight); own fragment reads of slot g retired; then the barrier
       if (!pf_active) wait_vm(0);
-      else if (DEFER) {                       // (D = 2: the store issued above is younger than every piece of g+1)
-        if (stored_now) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else wait_vm(VM_STEADY);
-      } else if (!first_tile && x < D - 1) wait_vm(VM_STEADY + S);
+      else if (!first_tile && x < D - 1) wait_vm(VM_STEADY + S);
       else wait_vm(VM_STEADY);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
@@ -1010,18 +965,8 @@ __global__ __launch_bounds__(128 * WN, (DEFER ? 1 : 2)) void gemm_bf16_pipe_kern
       sc = s1;
     }
 
-    if (DEFER) {
-      for (; pk_next < 16; ++pk_next) deferred_store(pk_next);       // (a tile shorter than 16 half-tiles: the rest now)
-      pipe_epilogue<EPI, WN, true>(g, acc, cur, wm, wn, h, l31, pk, &pk_row);
-      pk_next = 0;
-      if (!nxt_valid) {
-        for (; pk_next < 16; ++pk_next) deferred_store(pk_next);
-        break;
-      }
-    } else {
-      if (!(g.dbg & 2)) pipe_epilogue<EPI, WN>(g, acc, cur, wm, wn, h, l31);
-      if (!nxt_valid) break;
-    }
+    if (!(g.dbg & 2)) pipe_epilogue<EPI, WN>(g, acc, cur, wm, wn, h, l31);
+    if (!nxt_valid) break;
     cur = nxt;
     nxt_valid = false;
     pf_in_nxt = false;
@@ -1116,69 +1061,47 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
   const bool stag = subs == 2 && !(e_stag && e_stag[0] == '0') && M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && kps % 64 == 0 &&
                     lda * 512 < (1ll << 31) && ldb * 512 < (1ll << 31);
   // the persistent pipelined kernel (round 6) wherever the staggered one applies and every K range holds >= 4 half-tiles.
-  // MCL_GEMM_PIPE (read per launch -- tests and A/B runs flip it inside one process): "0" never, "4" / "2" always (8 waves,
-  // 256 x 256 / 4 waves, 256 x 128, two workgroups per CU), unset = where it measured faster than the staggered kernel
+  // MCL_GEMM_PIPE (read per launch -- tests and A/B runs flip it inside one process): "0" never, anything else always, unset =
+  // where it measured faster than the staggered kernel
   // (profiles/r06_gemm_bf16_microbench.jsonl): the data gradients with a gelu' epilogue.
   const char* e_pipe = getenv("MCL_GEMM_PIPE");
   const long long last_range = (long long)K - (long long)(g.ksplit - 1) * kps;
   const bool pipe_ok = stag && last_range >= 128 && kps >= 128 && !(gbwd && resid) && !(gelu && (gbwd || resid));
   const bool pipe = pipe_ok && (e_pipe ? e_pipe[0] != '0' : (gbwd && !f32));
   if (pipe) {
-    // "2": 4 waves, 256 x 128, two workgroups per CU (measured slower: profiles/r06_gemm_pipe_experiments.txt); else the 8-wave form
-    const bool defer = e_pipe && e_pipe[0] == '3';              // experiment: 4 waves, 256 x 128, ONE workgroup per CU, trickled stores
-    const int WNsel = (e_pipe && (e_pipe[0] == '2' || defer)) ? 2 : 4;
-    if (WNsel == 2) g.tn = N / 128;
-    const int per_batch_p = (g.tm >= 8 ? ((g.tm + 7) / 8) * 8 : g.tm) * g.tn * g.ksplit;
-    const int total_virtual = per_batch_p * batch;
+    const int total_virtual = per_batch * batch;
     const int cus = mcl_cu_count();
-    const int slots = (WNsel == 2 && !defer ? 2 : 1) * (cus / 8) * 8;
+    const int slots = (cus / 8) * 8;
     const int G = total_virtual < slots ? total_virtual : slots;
     const int epi = f32 ? PE_F32 : gelu ? (gelu_grad_out ? PE_GELU2 : PE_GELU1) : gbwd ? (aux_is_grad ? PE_GBWD2 : PE_GBWD1)
                     : resid ? PE_RESID : PE_PLAIN;
-    const char* e_dbg = getenv("MCL_GEMM_DBG");
+    const char* e_dbg = getenv("MCL_GEMM_DBG");           // experiment switches: 1 no stores, 2 no epilogue, 4 / 8 / 16 loop ablations
     g.dbg = e_dbg ? atoi(e_dbg) : 0;
-    // half a tile (K loop at the shared rate ~ 1 us per half-tile) in units of s_sleep 32 (2048 cycles); MCL_GEMM_DEPHASE overrides
-    const char* e_dph = getenv("MCL_GEMM_DEPHASE");
-    const int dephase = e_dph ? atoi(e_dph) : ((WNsel == 4 || defer) ? 0 : (int)(kps / 32 * 6 / 10));
     const int lay = (akm ? 2 : 0) | (bkm ? 1 : 0);
-    using KernelT = void (*)(GemmB, int, int);
-#define MCL_PK(AK, BKM, W) {gemm_bf16_pipe_kernel<AK, BKM, PE_PLAIN, W>, gemm_bf16_pipe_kernel<AK, BKM, PE_GELU2, W>,   \
-                            gemm_bf16_pipe_kernel<AK, BKM, PE_GELU1, W>, gemm_bf16_pipe_kernel<AK, BKM, PE_GBWD2, W>,   \
-                            gemm_bf16_pipe_kernel<AK, BKM, PE_GBWD1, W>, gemm_bf16_pipe_kernel<AK, BKM, PE_RESID, W>,   \
-                            gemm_bf16_pipe_kernel<AK, BKM, PE_F32, W>}
-    static const KernelT table[2][4][7] = {
-        {MCL_PK(false, false, 2), MCL_PK(false, true, 2), MCL_PK(true, false, 2), MCL_PK(true, true, 2)},
-        {MCL_PK(false, false, 4), MCL_PK(false, true, 4), MCL_PK(true, false, 4), MCL_PK(true, true, 4)}};
+    using KernelT = void (*)(GemmB, int);
+#define MCL_PK(AK, BKM) {gemm_bf16_pipe_kernel<AK, BKM, PE_PLAIN, 4>, gemm_bf16_pipe_kernel<AK, BKM, PE_GELU2, 4>,   \
+                         gemm_bf16_pipe_kernel<AK, BKM, PE_GELU1, 4>, gemm_bf16_pipe_kernel<AK, BKM, PE_GBWD2, 4>,   \
+                         gemm_bf16_pipe_kernel<AK, BKM, PE_GBWD1, 4>, gemm_bf16_pipe_kernel<AK, BKM, PE_RESID, 4>,   \
+                         gemm_bf16_pipe_kernel<AK, BKM, PE_F32, 4>}
+    static const KernelT table[4][7] = {MCL_PK(false, false), MCL_PK(false, true), MCL_PK(true, false), MCL_PK(true, true)};
 #undef MCL_PK
     static const KernelT dbg_table[4] = {gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 4>, gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 8>,
                                          gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 12>, gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 4, 16>};
     static mcl_device_once pipe_once;
     if (auto guard = pipe_once.first()) {
-      for (int w = 0; w < 2; ++w)
-        for (int a = 0; a < 4; ++a)
-          for (int e = 0; e < 7; ++e)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[w][a][e]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      w == 0 ? 3 * 24576 : 4 * 32768);
+      for (int a = 0; a < 4; ++a)
+        for (int e = 0; e < 7; ++e)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[a][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
       for (int e = 0; e < 4; ++e)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_table[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     }
-    KernelT kern = table[WNsel == 4][lay][epi];
-    if (defer) {
-      if (epi != PE_PLAIN) return MCL_EUNSUPPORTED;
-      static const KernelT dtable[4] = {gemm_bf16_pipe_kernel<false, false, PE_PLAIN, 2, 0, true>, gemm_bf16_pipe_kernel<false, true, PE_PLAIN, 2, 0, true>,
-                                        gemm_bf16_pipe_kernel<true, false, PE_PLAIN, 2, 0, true>, gemm_bf16_pipe_kernel<true, true, PE_PLAIN, 2, 0, true>};
-      static mcl_device_once d_once;
-      if (auto guard = d_once.first())
-        for (int a = 0; a < 4; ++a)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dtable[a]), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576);
-      kern = dtable[lay];
-    }
-    if (g.dbg & 28) {                                     // loop ablations (experiments; 8 waves, NT, plain): 4 no MFMA, 8 no DMA, 16 no barrier
-      if (lay != 0 || epi != PE_PLAIN || WNsel != 4) return MCL_EUNSUPPORTED;
+    KernelT kern = table[lay][epi];
+    if (g.dbg & 28) {                                     // loop ablations (NT, plain): 4 no MFMA, 8 no DMA, 16 no barrier
+      if (lay != 0 || epi != PE_PLAIN) return MCL_EUNSUPPORTED;
       const int d = g.dbg & 28;
       kern = d == 4 ? dbg_table[0] : d == 8 ? dbg_table[1] : d == 12 ? dbg_table[2] : dbg_table[3];
     }
-    hipLaunchKernelGGL(kern, dim3(G), dim3(128 * WNsel), (size_t)(WNsel == 2 ? 3 * 24576 : 4 * 32768), st, g, total_virtual, dephase);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(512), (size_t)(4 * 32768), st, g, total_virtual);
     if (via_slabs) {
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return (int)e;

@@ -428,13 +428,12 @@ def _bn1_wrw_ok(w_param: Tensor) -> bool:
             and w_param.shape[0] == 128 and w_param.shape[2:] == (1, 1))
 
 
-def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
-                     w_param: Tensor, into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-    """w_param.grad += dz^T relu(bn1(x)); norm1 parameter gradients; gbuf += d loss / d x -- two C-ABI calls
-    (mcl_dense_bn1_wrw: Gram partials + fixed-order merge; mcl_dense_bn1_dx)."""
+def dense_bn1_wrw(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, w_param: Tensor,
+                  into_param_grads: bool):
+    """w_param.grad += dz^T relu(bn1(x)); norm1 parameter gradients; returns (dgamma, dbeta, coef) -- coef = the layer's two
+    BatchNorm-backward means per channel, what the dx pass(es) apply (mcl_dense_bn1_wrw: Gram partials + fixed-order merge)."""
     px, S, C, ldx = _rows(x)
-    pg, S2, C2, ldg = _rows(gbuf)
-    assert (S2, C2) == (S, C) and dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128
+    assert dz.is_contiguous(memory_format=CL) and dz.shape[1] == 128
     L = _lib.lib()
     ws = _ws(L.mcl_wrw_workspace_floats(S, 128, C), x.device)
     if into_param_grads:
@@ -447,9 +446,52 @@ def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor,
                               mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), w_param.grad.data_ptr(), 1,
                               dg.data_ptr(), db.data_ptr(), int(into_param_grads), coef.data_ptr(), _stream()),
           "mcl_dense_bn1_wrw")
-    check(L.mcl_dense_bn1_dx(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
-                             mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), pg, ldg, _stream()), "mcl_dense_bn1_dx")
-    return (None, None) if into_param_grads else (dg, db)
+    return (None, None, coef) if into_param_grads else (dg, db, coef)
+
+
+def dense_bn1_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, coef: Tensor,
+                 gbuf: Tensor, window=None) -> None:
+    """gbuf += d loss / d x of the layer head (mcl_dense_bn1_dx); ``window`` = (c0, nc): only those input channels."""
+    px, S, C, ldx = _rows(x)
+    pg, S2, C2, ldg = _rows(gbuf)
+    assert (S2, C2) == (S, C)
+    L = _lib.lib()
+    if window is None:
+        check(L.mcl_dense_bn1_dx(dz.data_ptr(), w16.data_ptr(), C, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
+                                 mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), pg, ldg, _stream()), "mcl_dense_bn1_dx")
+    else:
+        c0, nc = window
+        check(L.mcl_dense_bn1_dx_window(dz.data_ptr(), w16.data_ptr(), C, c0, nc, px, ldx, S, g1.data_ptr(), b1.data_ptr(),
+                                        mean.data_ptr(), rstd.data_ptr(), coef.data_ptr(), pg, ldg, _stream()),
+              "mcl_dense_bn1_dx_window")
+
+
+def dense_bn1_dx_pair(A, B, x: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor) -> None:
+    """Layers A = l and B = l - 1 (each a tuple (dz, w16, g1, b1, coef)): gbuf[:, :C] += both layers' terms in ONE pass over
+    the C channels layer B reads (mcl_dense_bn1_dx_pair); x / gbuf are the [:C] slices."""
+    dzA, wA, gA, bA, cA = A
+    dzB, wB, gB, bB, cB = B
+    px, S, C, ldx = _rows(x)
+    pg, S2, C2, ldg = _rows(gbuf)
+    assert (S2, C2) == (S, C) and wA.shape[1] >= C and wB.shape[1] == C
+    check(_lib.lib().mcl_dense_bn1_dx_pair(dzA.data_ptr(), wA.data_ptr(), wA.shape[1], gA.data_ptr(), bA.data_ptr(), cA.data_ptr(),
+                                           dzB.data_ptr(), wB.data_ptr(), gB.data_ptr(), bB.data_ptr(), cB.data_ptr(), C, px, ldx, S,
+                                           mean.data_ptr(), rstd.data_ptr(), pg, ldg, _stream()), "mcl_dense_bn1_dx_pair")
+
+
+def dense_bn1_wrw_dx(dz: Tensor, w16: Tensor, x: Tensor, g1: Tensor, b1: Tensor, mean: Tensor, rstd: Tensor, gbuf: Tensor,
+                     w_param: Tensor, into_param_grads: bool) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """w_param.grad += dz^T relu(bn1(x)); norm1 parameter gradients; gbuf += d loss / d x -- two C-ABI calls
+    (mcl_dense_bn1_wrw: Gram partials + fixed-order merge; mcl_dense_bn1_dx)."""
+    dg, db, coef = dense_bn1_wrw(dz, w16, x, g1, b1, mean, rstd, w_param, into_param_grads)
+    dense_bn1_dx(dz, w16, x, g1, b1, mean, rstd, coef, gbuf)
+    return dg, db
+
+
+# Round 6: the dx passes of two consecutive layers of a 56 x 56 / 28 x 28 block as ONE pass over the channels both read (x and
+# the gradient buffer read once, the buffer written once; layer l's term on the 32 channels layer l - 1 produced goes first, in a
+# windowed launch).  MCL_BN1_PAIR=0: one dx pass per layer (A/B).
+USE_BN1_PAIR = os.environ.get("MCL_BN1_PAIR", "1") != "0"
 
 
 # conv2 (3x3) backward-data + norm2/relu2 backward (csrc/dense_bwd.hip): dy is read in place from the gradient buffer
@@ -1046,6 +1088,17 @@ class DenseBlockFn(torch.autograd.Function):
                 stamp(f"bwd block {buf.shape[2]}x{buf.shape[3]} after join (main)")
             return (gbuf[:, :C0], None, *grads)
         kacc = None             # single-pass BatchNorm-1 backward: the previous pass's mean terms, [C_total][2]
+        pair_a = None           # paired dx passes (Gram path): layer A's (dz, w1, gamma, beta, coef) waiting for layer B
+        pair_cin = 0
+
+        def flush_pair():
+            """Layer A's term on the channels below its window, when no layer B follows on the paired path."""
+            nonlocal pair_a
+            if pair_a is not None:
+                dzA, wA, gA, bA, cA = pair_a
+                dense_bn1_dx(dzA, wA, buf[:, :pair_cin], gA, bA, stats.mean[:pair_cin], stats.rstd[:pair_cin], cA,
+                             gbuf[:, :pair_cin], window=(0, pair_cin - growth))
+                pair_a = None
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
             a, z, a2 = saved[3 * l: 3 * l + 3]
@@ -1089,16 +1142,31 @@ class DenseBlockFn(torch.autograd.Function):
                 if fused_wrw:
                     # the bottleneck weight gradient rides on the BatchNorm-backward reduction (one pass over dz, x;
                     # no atomics): it is part of the main chain now, only the 3x3 weight gradient forks off
-                    dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
-                                                gbuf[:, :cin], w1, into_param_grads=d1)
+                    dg1, db1, coef = dense_bn1_wrw(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], w1,
+                                                   into_param_grads=d1)
+                    mine = (dz, w1c, g1, b1, coef)
+                    if pair_a is not None:
+                        # layer B of a pair: both layers' terms on the channels this layer reads, in one pass
+                        dense_bn1_dx_pair(pair_a, mine, buf[:, :cin], stats.mean[:cin], stats.rstd[:cin], gbuf[:, :cin])
+                        pair_a = None
+                    elif USE_BN1_PAIR and l >= 1 and growth == 32 and cin - growth >= 8:
+                        # layer A of a pair: only the 32 channels the layer below produced (its 3x3 backward reads them next);
+                        # the rest waits for that layer's pass
+                        dense_bn1_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], coef, gbuf[:, :cin],
+                                     window=(cin - growth, growth))
+                        pair_a, pair_cin = mine, cin
+                    else:
+                        dense_bn1_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], coef, gbuf[:, :cin])
                     gw1 = None
                 elif single:
+                    flush_pair()
                     have_prev = kacc is not None
                     if not have_prev:
                         kacc = torch.empty((buf.shape[1], 2), device=buf.device, dtype=torch.float32)
                     dg1, db1 = dense_bn1_dx_sums(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                                  gbuf[:, :cin], kacc, have_prev, into_param_grads=d1)
                 else:
+                    flush_pair()
                     dg1, db1 = dense_bn1_bwd(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
                                              gbuf[:, :cin], into_param_grads=d1)
                 side.wait_event(ev)
@@ -1110,6 +1178,7 @@ class DenseBlockFn(torch.autograd.Function):
                 _side_park(z.device, dz, gbuf, z, buf, dy_w)
                 grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None]
                 continue
+            flush_pair()
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
             sp_here = (USE_BN1_SINGLE_PASS and fused1 and z.shape[2] * z.shape[3] <= BN1_SINGLE_PASS_MAX_MAP
@@ -1196,6 +1265,7 @@ class DenseBlockFn(torch.autograd.Function):
         # the main chain wait whenever the side stream runs behind; the small maps can afford to keep their tensors alive
         # (tens of MB) until a later block joins: 14.58 -> 14.28 ms/step on configs[1].  The network's first block is the
         # last one of the backward: it always joins, so nothing is left running when the backward returns.
+        flush_pair()
         if kacc is not None:
             dense_bn1_fix(buf, gbuf, 0, C0, stats.mean, stats.rstd, kacc)     # the block input: the mean terms of layer 0
         if STAMPS:

@@ -102,6 +102,24 @@ def _bn1_dx(a):                 # (dz, W1, C, x, ldx, S, ...): dz + x + g read, 
     return 2 * S * (128 + 3 * C)
 
 
+def _bn1_dx_window(a):          # (dz, W1, C, c0, nc, x, ldx, S, ...): dz + x + g read, g written on nc of the layer's C channels
+    nc, S = a[4], a[7]
+    return 2 * S * (128 + 3 * nc)
+
+
+def _bn1_dx_window_flops(a):
+    return 2 * a[7] * 128 * a[4]
+
+
+def _bn1_dx_pair(a):            # (dzA, W1A, ldwA, gA, bA, cA, dzB, W1B, gB, bB, cB, C, x, ldx, S, ...): both dz + x + g read, g written
+    C, S = a[11], a[14]
+    return 2 * S * (2 * 128 + 3 * C)
+
+
+def _bn1_dx_pair_flops(a):      # two dz W1 products
+    return 2 * 2 * a[14] * 128 * a[11]
+
+
 def _bn1_dx_sums(a):            # (dz, W1, C, x, ldx, S, ...): dz + x + g read, g written -- the whole BatchNorm-1 backward of a layer
     C, S = a[2], a[5]
     return 2 * S * (128 + 3 * C)
@@ -166,7 +184,11 @@ TABLE = {
                                     _conv3x3_wrw_det, flops=_conv3x3_flops_S3,
                                     bound="mfma/lds"),
     "mcl_dense_bn1_wrw": _e("wrw_partial_kernel<Gram> + wrw_merge_kernel", _bn1_wrw, flops=_bn1_wrw_flops),
-    "mcl_dense_bn1_dx": _e("bn1_bwd_kernel<1>", _bn1_dx, flops=_bn1_flops),
+    "mcl_dense_bn1_dx": _e("bn1_bwd_kernel<1> (one layer) / bn1_dx_pair_kernel (two consecutive layers' passes as one: "
+                           "mcl_dense_bn1_dx_pair, preceded by the 32-channel mcl_dense_bn1_dx_window)", _bn1_dx, flops=_bn1_flops),
+    "mcl_dense_bn1_dx_window": _e("bn1_bwd_kernel<1> on a 32-channel window", _bn1_dx_window, flops=_bn1_dx_window_flops,
+                                  unit="mcl_dense_bn1_dx"),
+    "mcl_dense_bn1_dx_pair": _e("bn1_dx_pair_kernel", _bn1_dx_pair, flops=_bn1_dx_pair_flops, unit="mcl_dense_bn1_dx"),
     "mcl_dense_bn1_dx_sums": _e("bn1_bwd_kernel<2> (single pass: dx data term + previous layer's mean terms + sums) + "
                                 "bn1_bwd_finalize_kernel", _bn1_dx_sums, flops=_bn1_flops),
     "mcl_dense_bn1_fix": _e("bn1_fix_kernel", _bn1_fix, bound="latency"),

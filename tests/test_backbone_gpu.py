@@ -935,3 +935,78 @@ def test_conv0_wrw_kernel(B, H, W):
         assert_close_scaled((dW - (0.25 if acc else 0.0)).cpu(), w64.grad.cpu(), 2e-5, floor=1e-4, what=f"dW conv0 acc={acc}")
         outs.append(dW)
     assert torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("S,C,ld", [(401408 // 16, 192, 256), (100352 // 4, 448, 512), (300, 96, 160), (129, 136, 512),
+                                    (70001, 64, 128)])
+def test_dense_bn1_dx_pair_vs_two_passes(S, C, ld):
+    """Round 6 (csrc/dense_bwd.hip bn1_dx_pair_kernel): the dx passes of two consecutive layers -- A reads channels [0, C + 32),
+    B reads [0, C) -- as DenseBlockFn.backward issues them: A's term on its LAST 32 channels in a windowed launch
+    (mcl_dense_bn1_dx_window: bit-identical to the full pass on those channels), then ONE pass that adds both layers' terms to
+    [0, C).  Against the two sequential full passes (same arithmetic; the pair rounds the sum of the two deltas to bf16 once
+    instead of each: at most one bf16 ulp of the buffer apart) and against fp64."""
+    from mclstexp_amd import _lib, densenet_fused as dn
+    L = _lib.lib()
+    CA = C + 32
+    g = torch.Generator().manual_seed(S + C)
+    xw = ((torch.rand(S, ld, generator=g) - 0.4) * 2).to(torch.bfloat16).to(DEV)
+    gw = ((torch.rand(S, ld, generator=g) - 0.5) * 0.1).to(torch.bfloat16).to(DEV)
+    dzA = ((torch.rand(S, 128, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)
+    dzB = ((torch.rand(S, 128, generator=g) - 0.5) * 0.2).to(torch.bfloat16).to(DEV)
+    WA = ((torch.rand(128, CA, generator=g) - 0.5) / 8).to(torch.bfloat16).to(DEV)
+    WB = ((torch.rand(128, C, generator=g) - 0.5) / 8).to(torch.bfloat16).to(DEV)
+    gamA, betA = (torch.rand(CA, generator=g) + 0.5).to(DEV), (torch.rand(CA, generator=g) - 0.5).to(DEV)
+    gamB, betB = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.rand(C, generator=g) - 0.5).to(DEV)
+    xd = xw[:, :CA].double()
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    rs = 1.0 / torch.sqrt(var + 1e-5)
+    muf, rsf = mu.float().contiguous(), rs.float().contiguous()
+    ws = torch.empty(L.mcl_wrw_workspace_floats(S, 128, CA), device=DEV)
+    st = dn._stream()
+
+    def coef_of(dz, W, Cl, gam, bet):
+        dg, db, dW, coef = (torch.zeros(Cl, device=DEV), torch.zeros(Cl, device=DEV), torch.zeros(128, Cl, device=DEV),
+                            torch.empty(2 * Cl, device=DEV))
+        _lib.check(L.mcl_dense_bn1_wrw(dz.data_ptr(), W.data_ptr(), Cl, xw.data_ptr(), ld, S, gam.data_ptr(), bet.data_ptr(),
+                                       muf.data_ptr(), rsf.data_ptr(), ws.data_ptr(), dW.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), 1,
+                                       coef.data_ptr(), st))
+        return coef
+
+    cA, cB = coef_of(dzA, WA, CA, gamA, betA), coef_of(dzB, WB, C, gamB, betB)
+    # sequential: A over [0, CA), then B over [0, C)
+    g_seq = gw.clone()
+    _lib.check(L.mcl_dense_bn1_dx(dzA.data_ptr(), WA.data_ptr(), CA, xw.data_ptr(), ld, S, gamA.data_ptr(), betA.data_ptr(),
+                                  muf.data_ptr(), rsf.data_ptr(), cA.data_ptr(), g_seq.data_ptr(), ld, st))
+    _lib.check(L.mcl_dense_bn1_dx(dzB.data_ptr(), WB.data_ptr(), C, xw.data_ptr(), ld, S, gamB.data_ptr(), betB.data_ptr(),
+                                  muf.data_ptr(), rsf.data_ptr(), cB.data_ptr(), g_seq.data_ptr(), ld, st))
+    # paired: A's window [C, CA), then both on [0, C)
+    g_pair = gw.clone()
+    _lib.check(L.mcl_dense_bn1_dx_window(dzA.data_ptr(), WA.data_ptr(), CA, C, 32, xw.data_ptr(), ld, S, gamA.data_ptr(),
+                                         betA.data_ptr(), muf.data_ptr(), rsf.data_ptr(), cA.data_ptr(), g_pair.data_ptr(), ld, st))
+    _lib.check(L.mcl_dense_bn1_dx_pair(dzA.data_ptr(), WA.data_ptr(), CA, gamA.data_ptr(), betA.data_ptr(), cA.data_ptr(),
+                                       dzB.data_ptr(), WB.data_ptr(), gamB.data_ptr(), betB.data_ptr(), cB.data_ptr(), C,
+                                       xw.data_ptr(), ld, S, muf.data_ptr(), rsf.data_ptr(), g_pair.data_ptr(), ld, st))
+    torch.cuda.synchronize()
+    assert torch.equal(g_pair[:, C:], g_seq[:, C:])                      # the window (and everything beyond CA) bit for bit
+    d = (g_pair[:, :C].float() - g_seq[:, :C].float()).abs()
+    assert bool((d <= 2.0 ** -7 * g_seq[:, :C].float().abs() + 1e-30).all()), float(d.max())
+    # fp64: both layers through autograd on the same bf16 data
+    xr = xd.clone().requires_grad_(True)
+    m_, v_ = xr.mean(0), xr.var(0, unbiased=False)
+    xh = (xr - m_) / torch.sqrt(v_ + 1e-5)
+    zA = torch.relu(xh * gamA.double() + betA.double()) @ WA.double().t()
+    zB = torch.relu(xh[:, :C] * gamB.double() + betB.double()) @ WB.double().t()
+    (zA * dzA.double()).sum().add((zB * dzB.double()).sum()).backward()
+    ref = gw[:, :CA].double() + xr.grad
+    assert_close_scaled(g_pair[:, :CA].float().cpu(), ref.cpu(), 8e-3, what="paired dx vs fp64")
+    e_pair = float((g_pair[:, :C].double() - ref[:, :C]).abs().mean())
+    e_seq = float((g_seq[:, :C].double() - ref[:, :C]).abs().mean())
+    assert e_pair <= e_seq * 1.02 + 1e-12, (e_pair, e_seq)               # one rounding instead of two: not further from fp64
+    # run-to-run
+    g2 = gw.clone()
+    _lib.check(L.mcl_dense_bn1_dx_window(dzA.data_ptr(), WA.data_ptr(), CA, C, 32, xw.data_ptr(), ld, S, gamA.data_ptr(),
+                                         betA.data_ptr(), muf.data_ptr(), rsf.data_ptr(), cA.data_ptr(), g2.data_ptr(), ld, st))
+    _lib.check(L.mcl_dense_bn1_dx_pair(dzA.data_ptr(), WA.data_ptr(), CA, gamA.data_ptr(), betA.data_ptr(), cA.data_ptr(),
+                                       dzB.data_ptr(), WB.data_ptr(), gamB.data_ptr(), betB.data_ptr(), cB.data_ptr(), C,
+                                       xw.data_ptr(), ld, S, muf.data_ptr(), rsf.data_ptr(), g2.data_ptr(), ld, st))
+    assert torch.equal(g2, g_pair)

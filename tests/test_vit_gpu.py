@@ -58,9 +58,9 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
     aux = _r(M, N, seed=25, scale=2.0).to(BF).to(DEV)
     flags = akm * vf.A_KM | bkm * vf.B_KM
     outs = []
-    # staggered, lockstep (the reference of the bit comparison), then the round-6 persistent pipelined kernel in both forms (8 waves
-    # / 256 x 256 and 4 waves / 256 x 128; it declines K ranges under 4 half-tiles: those launches fall through to the staggered one)
-    for stag, pipe in (("1", "0"), ("0", "0"), ("1", "4"), ("1", "2")):
+    # staggered, lockstep (the reference of the bit comparison), then the round-6 persistent pipelined kernel (it declines K ranges
+    # under 4 half-tiles: those launches fall through to the staggered one)
+    for stag, pipe in (("1", "0"), ("0", "0"), ("1", "1")):
         monkeypatch.setenv("MCL_GEMM_STAG", stag)
         monkeypatch.setenv("MCL_GEMM_PIPE", pipe)
         f32 = mode.startswith("f32")
@@ -90,7 +90,7 @@ def test_gemm_bf16_staggered_kernel_bit_identical(M, N, K, akm, bkm, mode, monke
         outs.append((C, pre))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
-    for k in (2, 3):
+    for k in (2,):
         # same fragments and k order, MFMA operands swapped (transposed result layout): the products are equal bit for bit; the
         # GELU epilogues are compiled in a different expression context (fused multiply-adds may pair differently): one bf16 ulp
         for w in (0, 1):
