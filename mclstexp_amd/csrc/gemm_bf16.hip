@@ -613,9 +613,14 @@ enum { PE_PLAIN = 0, PE_GELU2 = 1, PE_GELU1 = 2, PE_GBWD2 = 3, PE_GBWD1 = 4, PE_
 
 // Straight from the registers.  Block (i, j) in the transposed MFMA layout: this lane = row m = i*32 + l31, register r = column
 // (r & 3) + 8 (r >> 2) + 4 h of the 32-column block j: four groups of 4 consecutive columns.
+// bf16 results leave through a wave-private 4 KB LDS area `stage` (beyond the ring): a 32-row block of the wave's 64 columns is
+// written as 8-byte pieces (this lane's 4 x 4 columns of its row), read back as 16-byte chunks with 8 lanes per row, and stored as
+// WHOLE 128-byte lines -- the register-direct form (v_permlane32_swap + two 16-byte stores per block: 32-byte row segments) wrote
+// 28 % more bytes to HBM than the tensor holds (profiles/r06_gemm_pipe_experiments.txt 7).  LDS operations of one wave execute in
+// order: no wait between the writes and the reads, no barrier (nobody else touches the area).
 template <int EPI, int WN>
 __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2], const PipeTile& cur, int wm, int wn, int h,
-                                              int l31) {
+                                              int l31, unsigned char* __restrict__ stage) {
   const int mw = cur.m0 + wm * 128, nw = cur.n0 + wn * 64;
   constexpr bool has_x = EPI == PE_GBWD2 || EPI == PE_GBWD1 || EPI == PE_RESID;
   // one 64-bit row base per lane and tensor; a block adds a wave-uniform offset
@@ -627,24 +632,46 @@ __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2
   float* frow = reinterpret_cast<float*>(g.C) + (long long)cur.ks * g.slab_stride + cur.c_off + row * g.ldc + nw + 4 * h;
   const bool second = (EPI == PE_GELU2) || (EPI == PE_GELU1 && g.pre_out);
   bf16_t* prow = second ? g.pre_out + row * g.ldp + nw + 8 * h : nullptr;
+  const int lane = l31 + 32 * h;
+  // staging geometry: row l31 of the 32-row block, 16-byte chunk c (8 columns) stored at chunk c ^ (row & 7)
+  auto stage_put = [&](int j, const unsigned (&P)[4][2]) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    // the residual / gelu' rows of the 4 blocks of a 32-column half are requested together (32 registers)
-    u32x4 xq[4][2];
+    for (int gq = 0; gq < 4; ++gq) {
+      const int col = j * 32 + gq * 8 + 4 * h;                  // first of this piece's 4 columns
+      const int chunk = (col >> 3) ^ (l31 & 7);
+      *reinterpret_cast<uint2*>(stage + l31 * 128 + (chunk << 4) + (col & 7) * 2) = make_uint2(P[gq][0], P[gq][1]);
+    }
+  };
+  auto stage_flush = [&](bf16_t* rowbase, long long ld) {      // rowbase: this wave's (row 0, column 0) of the 32-row block
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = (lane >> 3) + 8 * t, c = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + r * 128 + ((c ^ (r & 7)) << 4));
+      if (!(g.dbg & 1) || v[0] == 0x12345678u) *reinterpret_cast<u32x4*>(rowbase + (long long)r * ld + c * 8) = v;
+    }
+  };
+  bf16_t* cblk = reinterpret_cast<bf16_t*>(g.C) + cur.c_off + (long long)mw * g.ldc + nw;
+  bf16_t* pblk = second ? g.pre_out + (long long)mw * g.ldp + nw : nullptr;
+  (void)crow; (void)prow;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // the residual / gelu' rows of the block row's two 32-column halves (16 registers)
+    u32x4 xq[2][2];
     if (has_x) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
-          xq[i][pr] = *reinterpret_cast<const u32x4*>(xrow + (long long)(i * 32) * ldx + j * 32 + 16 * pr);
+          xq[j][pr] = *reinterpret_cast<const u32x4*>(xrow + (long long)(i * 32) * ldx + j * 32 + 16 * pr);
     }
-    float4 bq[4];
+    unsigned Pp[2][4][2];                            // packed second result of the two halves (the first goes to the staging area at once)
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq)
-      bq[gq] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nw + j * 32 + 8 * gq + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_sched_barrier(0);             // one block at a time: keeps the epilogue's live set small
+      float4 bq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_barrier(0);           // one block at a time: keeps the epilogue's live set small
+      for (int gq = 0; gq < 4; ++gq)
+        bq[gq] = g.bias ? *reinterpret_cast<const float4*>(g.bias + nw + j * 32 + 8 * gq + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
       float vv[16];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
@@ -664,7 +691,7 @@ __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2
         unsigned xo[4][2];
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          unsigned u0 = xq[i][pr][0], u1 = xq[i][pr][1], w0 = xq[i][pr][2], w1 = xq[i][pr][3];
+          unsigned u0 = xq[j][pr][0], u1 = xq[j][pr][1], w0 = xq[j][pr][2], w1 = xq[j][pr][3];
           swap_lo_hi(u0, w0);
           swap_lo_hi(u1, w1);
           xo[2 * pr][0] = u0; xo[2 * pr][1] = u1; xo[2 * pr + 1][0] = w0; xo[2 * pr + 1][1] = w1;
@@ -689,57 +716,45 @@ __device__ __forceinline__ void pipe_epilogue(const GemmB& g, f32x16 (&acc)[4][2
           }
         }
       }
-      unsigned P[4][2];
-      if (EPI == PE_GELU2 || EPI == PE_GELU1) {
-        if (EPI == PE_GELU2) {                      // second output: gelu'(pre-activation); one exp / rcp serves both
+      if (EPI == PE_GELU2) {                        // second output: gelu'(pre-activation); one exp / rcp serves both
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            float gr[4];
+        for (int gq = 0; gq < 4; ++gq) {
+          float gr[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float Phi, ex;
-              gelu_parts(vv[4 * gq + e], Phi, ex);
-              gr[e] = fmaf(vv[4 * gq + e] * 0.39894228040143267794f, ex, Phi);
-              vv[4 * gq + e] *= Phi;
-            }
-            P[gq][0] = pack_bf16(gr[0], gr[1]);
-            P[gq][1] = pack_bf16(gr[2], gr[3]);
+          for (int e = 0; e < 4; ++e) {
+            float Phi, ex;
+            gelu_parts(vv[4 * gq + e], Phi, ex);
+            gr[e] = fmaf(vv[4 * gq + e] * 0.39894228040143267794f, ex, Phi);
+            vv[4 * gq + e] *= Phi;
           }
-        } else {                                    // second output (optional): the pre-activation
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            P[gq][0] = pack_bf16(vv[4 * gq], vv[4 * gq + 1]);
-            P[gq][1] = pack_bf16(vv[4 * gq + 2], vv[4 * gq + 3]);
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) vv[r] = gelu_f(vv[r]);
+          Pp[j][gq][0] = pack_bf16(gr[0], gr[1]);
+          Pp[j][gq][1] = pack_bf16(gr[2], gr[3]);
+          __builtin_amdgcn_sched_barrier(0);          // four elements at a time: the 16-element form spilled
         }
-        if (second) {
-          bf16_t* po = prow + (long long)(i * 32) * g.ldp + j * 32;
+      } else if (EPI == PE_GELU1) {                 // second output (optional): the pre-activation
 #pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            swap_lo_hi(P[2 * pr][0], P[2 * pr + 1][0]);
-            swap_lo_hi(P[2 * pr][1], P[2 * pr + 1][1]);
-            if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
-              *reinterpret_cast<u32x4*>(po + 16 * pr) = u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]};
-          }
+        for (int gq = 0; gq < 4; ++gq) {
+          Pp[j][gq][0] = pack_bf16(vv[4 * gq], vv[4 * gq + 1]);
+          Pp[j][gq][1] = pack_bf16(vv[4 * gq + 2], vv[4 * gq + 3]);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vv[r] = gelu_f(vv[r]);
       }
+      unsigned Pc[4][2];
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        P[gq][0] = pack_bf16(vv[4 * gq], vv[4 * gq + 1]);
-        P[gq][1] = pack_bf16(vv[4 * gq + 2], vv[4 * gq + 3]);
+        Pc[gq][0] = pack_bf16(vv[4 * gq], vv[4 * gq + 1]);
+        Pc[gq][1] = pack_bf16(vv[4 * gq + 2], vv[4 * gq + 3]);
       }
-      // groups (0, 1) and (2, 3): after the swaps a lane holds 8 consecutive columns (lower half: 0-7 / 16-23 of the block,
-      // upper half: 8-15 / 24-31) -> two 16-byte stores per block, 32 contiguous bytes per row and instruction
-      bf16_t* o = crow + (long long)(i * 32) * g.ldc + j * 32;
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        swap_lo_hi(P[2 * pr][0], P[2 * pr + 1][0]);
-        swap_lo_hi(P[2 * pr][1], P[2 * pr + 1][1]);
-        if (!(g.dbg & 1) || P[0][0] == 0x12345678u)
-          *reinterpret_cast<u32x4*>(o + 16 * pr) = u32x4{P[2 * pr][0], P[2 * pr][1], P[2 * pr + 1][0], P[2 * pr + 1][1]};
-      }
+      stage_put(j, Pc);
+    }
+    if (EPI == PE_F32) continue;
+    __builtin_amdgcn_sched_barrier(0);
+    stage_flush(cblk + (long long)(i * 32) * g.ldc, g.ldc);
+    if (second) {
+      stage_put(0, Pp[0]);
+      stage_put(1, Pp[1]);
+      stage_flush(pblk + (long long)(i * 32) * g.ldp, g.ldp);
     }
   }
 }
@@ -965,7 +980,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_pipe_kernel(GemmB g, in
       sc = s1;
     }
 
-    if (!(g.dbg & 2)) pipe_epilogue<EPI, WN>(g, acc, cur, wm, wn, h, l31);
+    if (!(g.dbg & 2)) pipe_epilogue<EPI, WN>(g, acc, cur, wm, wn, h, l31, lds + NSLOT * SLOT + wave * 4096);
     if (!nxt_valid) break;
     cur = nxt;
     nxt_valid = false;
@@ -1062,12 +1077,13 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
                     lda * 512 < (1ll << 31) && ldb * 512 < (1ll << 31);
   // the persistent pipelined kernel (round 6) wherever the staggered one applies and every K range holds >= 4 half-tiles.
   // MCL_GEMM_PIPE (read per launch -- tests and A/B runs flip it inside one process): "0" never, anything else always, unset =
-  // where it measured faster than the staggered kernel
-  // (profiles/r06_gemm_bf16_microbench.jsonl): the data gradients with a gelu' epilogue.
+  // where it measured faster than the staggered kernel (profiles/r06_gemm_pipe_experiments.txt 8): every bf16-output epilogue
+  // (qkv / fc1 / fc2 -1 ... -3 %, the gelu'-multiplying data gradient -19 %); the fp32 split-K slabs of the weight gradients stay
+  // on the staggered kernel (+9 % there).
   const char* e_pipe = getenv("MCL_GEMM_PIPE");
   const long long last_range = (long long)K - (long long)(g.ksplit - 1) * kps;
   const bool pipe_ok = stag && last_range >= 128 && kps >= 128 && !(gbwd && resid) && !(gelu && (gbwd || resid));
-  const bool pipe = pipe_ok && (e_pipe ? e_pipe[0] != '0' : (gbwd && !f32));
+  const bool pipe = pipe_ok && (e_pipe ? e_pipe[0] != '0' : !f32);
   if (pipe) {
     const int total_virtual = per_batch * batch;
     const int cus = mcl_cu_count();
@@ -1091,9 +1107,9 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
     if (auto guard = pipe_once.first()) {
       for (int a = 0; a < 4; ++a)
         for (int e = 0; e < 7; ++e)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[a][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[a][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768);
       for (int e = 0; e < 4; ++e)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_table[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dbg_table[e]), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32768);
     }
     KernelT kern = table[lay][epi];
     if (g.dbg & 28) {                                     // loop ablations (NT, plain): 4 no MFMA, 8 no DMA, 16 no barrier
@@ -1101,7 +1117,8 @@ extern "C" int mcl_gemm_bf16(const void* A, int64_t lda, int64_t sAb, const void
       const int d = g.dbg & 28;
       kern = d == 4 ? dbg_table[0] : d == 8 ? dbg_table[1] : d == 12 ? dbg_table[2] : dbg_table[3];
     }
-    hipLaunchKernelGGL(kern, dim3(G), dim3(512), (size_t)(4 * 32768), st, g, total_virtual);
+    // LDS: the four-slot ring (128 KB) + 4 KB of epilogue staging per wave = all 160 KB of the CU
+    hipLaunchKernelGGL(kern, dim3(G), dim3(512), (size_t)(5 * 32768), st, g, total_virtual);
     if (via_slabs) {
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return (int)e;
