@@ -1099,6 +1099,24 @@ class DenseBlockFn(torch.autograd.Function):
                 dense_bn1_dx(dzA, wA, buf[:, :pair_cin], gA, bA, stats.mean[:pair_cin], stats.rstd[:pair_cin], cA,
                              gbuf[:, :pair_cin], window=(0, pair_cin - growth))
                 pair_a = None
+
+        def gram_dx(l, dz, w1c, g1, b1, cin, coef):
+            """The dx pass(es) of a Gram-path layer: alone, as layer A of a pair (windowed) or as layer B (paired).  Both
+            backward schedules (side-stream lanes / serial) go through here, so they launch identical kernels."""
+            nonlocal pair_a, pair_cin
+            mine = (dz, w1c, g1, b1, coef)
+            if pair_a is not None:
+                # layer B of a pair: both layers' terms on the channels this layer reads, in one pass
+                dense_bn1_dx_pair(pair_a, mine, buf[:, :cin], stats.mean[:cin], stats.rstd[:cin], gbuf[:, :cin])
+                pair_a = None
+            elif USE_BN1_PAIR and l >= 1 and growth == 32 and cin - growth >= 8:
+                # layer A of a pair: only the 32 channels the layer below produced (its 3x3 backward reads them next);
+                # the rest waits for that layer's pass
+                dense_bn1_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], coef, gbuf[:, :cin],
+                             window=(cin - growth, growth))
+                pair_a, pair_cin = mine, cin
+            else:
+                dense_bn1_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], coef, gbuf[:, :cin])
         for l in range(L - 1, -1, -1):
             g1, b1, w1, g2, b2, w2 = params[6 * l: 6 * l + 6]
             a, z, a2 = saved[3 * l: 3 * l + 3]
@@ -1144,19 +1162,7 @@ class DenseBlockFn(torch.autograd.Function):
                     # no atomics): it is part of the main chain now, only the 3x3 weight gradient forks off
                     dg1, db1, coef = dense_bn1_wrw(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], w1,
                                                    into_param_grads=d1)
-                    mine = (dz, w1c, g1, b1, coef)
-                    if pair_a is not None:
-                        # layer B of a pair: both layers' terms on the channels this layer reads, in one pass
-                        dense_bn1_dx_pair(pair_a, mine, buf[:, :cin], stats.mean[:cin], stats.rstd[:cin], gbuf[:, :cin])
-                        pair_a = None
-                    elif USE_BN1_PAIR and l >= 1 and growth == 32 and cin - growth >= 8:
-                        # layer A of a pair: only the 32 channels the layer below produced (its 3x3 backward reads them next);
-                        # the rest waits for that layer's pass
-                        dense_bn1_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], coef, gbuf[:, :cin],
-                                     window=(cin - growth, growth))
-                        pair_a, pair_cin = mine, cin
-                    else:
-                        dense_bn1_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], coef, gbuf[:, :cin])
+                    gram_dx(l, dz, w1c, g1, b1, cin, coef)
                     gw1 = None
                 elif single:
                     flush_pair()
@@ -1178,11 +1184,13 @@ class DenseBlockFn(torch.autograd.Function):
                 _side_park(z.device, dz, gbuf, z, buf, dy_w)
                 grads[6 * l: 6 * l + 6] = [dg1, db1, gw1, dg2, db2, None]
                 continue
-            flush_pair()
+            gram_here = fused1 and _bn1_wrw_ok(w1) and z.shape[0] * z.shape[2] * z.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS
+            if not gram_here:
+                flush_pair()        # (a pending layer A: its term on the lower channels, before any other kind of pass)
             main = torch.cuda.current_stream()
             side = _side_stream(z.device) if (USE_SIDE_STREAM and fused1 and fused2) else None
             sp_here = (USE_BN1_SINGLE_PASS and fused1 and z.shape[2] * z.shape[3] <= BN1_SINGLE_PASS_MAX_MAP
-                       and not (_bn1_wrw_ok(w1) and z.shape[0] * z.shape[2] * z.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS))
+                       and not gram_here)
             fold = None
             if kacc is not None:
                 if sp_here:                                     # the previous pass's mean terms: this layer's 32 output channels
@@ -1230,10 +1238,11 @@ class DenseBlockFn(torch.autograd.Function):
                 # fused forward: nothing of norm1's output was kept.  Weight gradient with BN1+ReLU recomputed from the
                 # concat buffer; data gradient + BN1 backward without materialising da
                 bn1 = (g1, b1, stats.mean[:cin], stats.rstd[:cin])
-                if _bn1_wrw_ok(w1) and dz.shape[0] * dz.shape[2] * dz.shape[3] >= FUSED_BN1_WRW_MIN_PIXELS:
+                if gram_here:
                     dw1 = ("direct", None)
-                    dg1, db1 = dense_bn1_wrw_dx(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin],
-                                                gbuf[:, :cin], w1, into_param_grads=d1)
+                    dg1, db1, coef = dense_bn1_wrw(dz, w1c, buf[:, :cin], g1, b1, stats.mean[:cin], stats.rstd[:cin], w1,
+                                                   into_param_grads=d1)
+                    gram_dx(l, dz, w1c, g1, b1, cin, coef)
                     if side is not None:
                         main.wait_stream(side)
                     grads[6 * l: 6 * l + 6] = [dg1, db1, None, dg2, db2, None if (dw2_done or dw2 is None) else _wgrad(w2, dw2)]
