@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCL_ABI_VERSION 8
+#define MCL_ABI_VERSION 9
 
 #define MCL_OK 0
 #define MCL_EINVAL (-1)       /* null pointer / non-positive size / inconsistent arguments */
@@ -92,6 +92,37 @@ uint32_t mcl_gemm_args_min_size(void);
 /* Slices that give a problem with few 64x64 output tiles ~256 workgroups (1 = do not split). */
 int32_t mcl_gemm_auto_ksplit(int32_t M, int32_t N, int32_t K, int32_t batch);
 int64_t mcl_gemm_workspace_floats(int32_t M, int32_t N, int32_t batch, int32_t ksplit);
+/* n <= 4 independent problems as ONE launch (a layer's backward: its weight gradients and its data gradient are a few dozen
+ * 64x64 tiles each).  `args`: an array of mcl_gemm_args, args[0].struct_size bytes apart, every element with the same
+ * struct_size.  Each problem keeps its own layouts and epilogue; results are bit-identical to n separate mcl_gemm calls.
+ * Restrictions: compute MCL_COMPUTE_F32, batch 1, ksplit <= 1, no filter epilogue -> MCL_EUNSUPPORTED otherwise.           */
+int mcl_gemm_group(const mcl_gemm_args* args, int32_t n, mcl_stream_t stream);
+
+/* ---------------------------------------------------------------- K7 ProjectionHead (model.py:151-168), projection_dim = 256
+ * Forward as ONE launch, exact fp32 (csrc/proj_head.hip):
+ *     p = x Wp^T + bp ;  a = gelu(p) ;  z = a Wf^T + bf + p ;  e = LayerNorm(z; gamma, beta, eps)      (dropout p = 0)
+ * x (M, D) row stride ldx; Wp (256, D) row stride ldwp; Wf (256, 256) row stride ldwf; bp, bf, gamma, beta (256).
+ * Outputs, all dense (M, 256) / (M): e, and for the backward p, a, z, mean, rstd.  The first product is cut into `ksplit`
+ * K slices over the grid (mcl_proj_head_ksplit(M, D) recommends; 1..16); the last workgroup to arrive at a block of 16 rows adds
+ * the slices in slice order (bit-reproducible) and finishes the rows.  ws: >= mcl_proj_head_ws_floats(M, ksplit) floats;
+ * counters: ceil(M / 16) uint32, ZERO before the first call and left zero by every call -- one counter array per concurrently
+ * running call.  16-byte aligned: e, p, a, z, ws, bp, gamma, beta.
+ * Backward, row-local part as ONE launch:
+ *     dz = LayerNorm'(de) ;  dp = (dz Wf) * gelu'(p) + dz ;  dgamma = sum_rows de * xhat, dbeta = sum_rows de,
+ *     dbf = sum_rows dz, dbp = sum_rows dp     (bit i of accumulate_mask: output i of (dgamma, dbeta, dbf, dbp) is added to --
+ *     the parameter's .grad -- instead of overwritten; a NULL output is skipped; sums over row blocks in block order).
+ * dz, dp dense (M, 256); ws >= ceil(M / 16) * 1024 floats; counter: ONE zero uint32, as above.  The remaining three products
+ * (dWf = dz^T a, dWp = dp^T x, dx = dp Wp) are plain problems for mcl_gemm_group.                                              */
+int32_t mcl_proj_head_ksplit(int32_t M, int32_t D);
+int64_t mcl_proj_head_ws_floats(int32_t M, int32_t ksplit);
+int mcl_proj_head_fwd(const float* x, int64_t ldx, int32_t M, int32_t D, const float* wp, int64_t ldwp, const float* bp,
+                      const float* wf, int64_t ldwf, const float* bf, const float* gamma, const float* beta, float eps,
+                      float* e, float* p, float* a, float* z, float* mean, float* rstd, float* ws, uint32_t* counters,
+                      int32_t ksplit, mcl_stream_t stream);
+int mcl_proj_head_bwd_rows(const float* de, int64_t ldde, int32_t M, const float* z, const float* mean, const float* rstd,
+                           const float* gamma, const float* p, const float* wf, int64_t ldwf, float* dz, float* dp,
+                           float* dgamma, float* dbeta, float* dbf, float* dbp, int32_t accumulate_mask, float* ws,
+                           uint32_t* counter, mcl_stream_t stream);
 
 /* ---------------------------------------------------------------- K1 position-embedding add
  * model.py:230-235:  out[b,:] = expr[b,:] + X[(long)pos[b,0],:] + Y[(long)pos[b,1],:]

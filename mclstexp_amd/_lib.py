@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads torch/lib/libamdhip64.so)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCL_LIB_PATH") or os.path.join(_HERE, "libmclstexp_hip.so")   # override: A/B of kernel builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib: Optional[C.CDLL] = None
 
@@ -68,6 +68,12 @@ PROTOTYPES = {
     "mcl_gemm_args_min_size": [],
     "mcl_gemm_auto_ksplit": [c_i, c_i, c_i, c_i],
     "mcl_gemm_workspace_floats": [c_i, c_i, c_i, c_i],
+    "mcl_gemm_group": [C.POINTER(GemmArgs), c_i, c_p],
+    "mcl_proj_head_ksplit": [c_i, c_i],
+    "mcl_proj_head_ws_floats": [c_i, c_i],
+    "mcl_proj_head_fwd": [c_p, c_l, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                          c_i, c_p],
+    "mcl_proj_head_bwd_rows": [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "mcl_pos_embed_add_fwd": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_p],
     "mcl_embed_rowgrad": [c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
     "mcl_embed_scatter_rows": [c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p],
@@ -210,7 +216,8 @@ _RESTYPES = {"mcl_error_string": C.c_char_p, "mcl_gemm_args_size": C.c_uint32, "
              "mcl_wrw_workspace_floats": C.c_int64, "mcl_dense_conv3x3_wrw_workspace_floats": C.c_int64,
              "mcl_conv0_wrw_workspace_floats": C.c_int64, "mcl_infonce_fp8_workspace_bytes": C.c_int64,
              "mcl_gemm_bf16_workspace_floats": C.c_int64, "mcl_colred_workspace_floats": C.c_int64,
-             "mcl_gemm_workspace_floats": C.c_int64, "mcl_rowred_workspace_floats": C.c_int64}
+             "mcl_gemm_workspace_floats": C.c_int64, "mcl_rowred_workspace_floats": C.c_int64,
+             "mcl_proj_head_ws_floats": C.c_int64}
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

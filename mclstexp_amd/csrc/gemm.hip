@@ -108,17 +108,16 @@ __device__ __forceinline__ void store_slice(const float (&reg)[8], float* __rest
 // "reference numerics" image encoders: M = 25 216 token rows, im2col rows of the generic convolutions) -- each wave a 64 x 64 block as
 // 2 x 2 MFMA tiles: two A and two B operand reads feed four products, and a tile's operand traffic per flop halves (the 64 x 64
 // form asks L2 for 16 KB per 262 kflop: ~10 TB/s with every CU busy).
+// (the body is a device function of the block coordinates: mcl_gemm_group runs several problems' tiles in one launch)
 template <bool AKC, bool BKC, bool VEC, bool BF16, int TM>
-__global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
+__device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const int by, const int bzz, float* __restrict__ As,
+                                          float* __restrict__ Bs) {
   constexpr int BMT = BM * TM, BNT = BN * TM, LD = BMT + 1;
-  __shared__ float As[BK * LD];
-  __shared__ float Bs[BK * LD];
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BMT, n0 = blockIdx.x * BNT;
-  const int bz = blockIdx.z % p.batch, ksl = blockIdx.z / p.batch;
+  const int m0 = by * BMT, n0 = bx * BNT;
+  const int bz = bzz % p.batch, ksl = bzz / p.batch;
   const int kbeg = ksl * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   const float* __restrict__ A = p.A + (long long)bz * p.sAb;
   const float* __restrict__ B = p.B + (long long)bz * p.sBb;
@@ -275,6 +274,49 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
     }
 }
 
+template <bool AKC, bool BKC, bool VEC, bool BF16, int TM>
+__global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
+  constexpr int LD = BM * TM + 1;
+  __shared__ float As[BK * LD];
+  __shared__ float Bs[BK * LD];
+  gemm_tile<AKC, BKC, VEC, BF16, TM>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Up to four independent fp32 problems as ONE launch (mcl_gemm_group): the weight gradients and the data gradient of a layer's
+// backward are a few dozen 64 x 64 tiles each -- launched one by one they leave most of the chip idle three times over.  Block b
+// belongs to the problem whose tile range [first[i], first[i + 1]) holds it; each problem keeps its own operand layout, epilogue
+// and tile order, so a grouped launch is bit-identical to the separate ones.
+constexpr int GROUP_MAX = 4;
+struct GemmGroup {
+  GemmP p[GROUP_MAX];
+  int first[GROUP_MAX + 1];
+  int layout[GROUP_MAX];       // bit 0: A contiguous along k, bit 1: B contiguous along k, bit 2: 16-byte loads allowed
+  int n;
+};
+
+template <bool VEC>
+__device__ __forceinline__ void group_dispatch(const GemmP& p, int lay, int bx, int by, float* As, float* Bs) {
+  switch (lay & 3) {
+    case 3: gemm_tile<true, true, VEC, false, 1>(p, bx, by, 0, As, Bs); break;
+    case 1: gemm_tile<true, false, VEC, false, 1>(p, bx, by, 0, As, Bs); break;
+    case 2: gemm_tile<false, true, VEC, false, 1>(p, bx, by, 0, As, Bs); break;
+    default: gemm_tile<false, false, VEC, false, 1>(p, bx, by, 0, As, Bs); break;
+  }
+}
+
+__global__ __launch_bounds__(NT) void gemm_group_kernel(const GemmGroup g) {
+  constexpr int LD = BM + 1;
+  __shared__ float As[BK * LD];
+  __shared__ float Bs[BK * LD];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+  const GemmP& p = g.p[i];
+  const int t = (int)blockIdx.x - g.first[i];
+  const int tn = (p.N + BN - 1) / BN;
+  if (g.layout[i] & 4) group_dispatch<true>(p, g.layout[i], t % tn, t / tn, As, Bs);
+  else                 group_dispatch<false>(p, g.layout[i], t % tn, t / tn, As, Bs);
+}
+
 // Split-K second pass: fixed-order sum of the K slices + the same epilogue as the one-pass kernel (deterministic).
 __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmP p) {
   const long long MN = (long long)p.M * p.N, total = MN * p.batch;
@@ -330,22 +372,21 @@ static constexpr uint32_t kGemmArgsMin = (uint32_t)(offsetof(mcl_gemm_args, work
 extern "C" uint32_t mcl_gemm_args_size(void) { return (uint32_t)sizeof(mcl_gemm_args); }
 extern "C" uint32_t mcl_gemm_args_min_size(void) { return kGemmArgsMin; }
 
-extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
-  MCL_CLEAR_ERROR();
+// Argument check + the kernel-side descriptor of one problem.  `vec`: 16-byte operand loads allowed.
+static int gemm_prepare(const mcl_gemm_args* caller_args, mcl_gemm_args* a, GemmP& p, bool& akc, bool& bkc, bool& vec) {
   if (!caller_args) return MCL_EINVAL;
   const uint32_t sz = caller_args->struct_size;
   if (sz < kGemmArgsMin) return MCL_EINVAL;
-  mcl_gemm_args local;
-  memset(&local, 0, sizeof(local));
-  memcpy(&local, caller_args, sz < sizeof(local) ? sz : sizeof(local));   // fields beyond the caller's size stay zero / NULL
-  const mcl_gemm_args* a = &local;
+  memset(a, 0, sizeof(*a));
+  memcpy(a, caller_args, sz < sizeof(*a) ? sz : sizeof(*a));   // fields beyond the caller's size stay zero / NULL
   if (!a->A || !a->B || (!a->C && !a->flt_thr)) return MCL_EINVAL;
   if (a->flt_thr && (!a->flt_cnt || !a->flt_val || !a->flt_idx || a->flt_cap <= 0 || a->batch != 1 || a->ksplit > 1 || a->bias ||
                      a->resid || a->pre_out || a->flags))
     return MCL_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return MCL_EINVAL;
-  const bool akc = (a->sAk == 1), amc = (a->sAm == 1);
-  const bool bkc = (a->sBk == 1), bnc = (a->sBn == 1);
+  akc = (a->sAk == 1);
+  bkc = (a->sBk == 1);
+  const bool amc = (a->sAm == 1), bnc = (a->sBn == 1);
   if (!(akc || amc) || !(bkc || bnc)) return MCL_EINVAL;
   if ((a->pre_out || (a->flags & MCL_EPI_GELU_BWD)) && a->batch != 1) return MCL_EINVAL;
   if ((a->flags & MCL_EPI_GELU_BWD) && !a->aux) return MCL_EINVAL;
@@ -353,8 +394,6 @@ extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
   if (a->batch > 65535) return MCL_EUNSUPPORTED;
   const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
   if (ksplit > 1 && (!a->workspace || (long long)a->batch * ksplit > 65535 || ksplit > 64)) return MCL_EINVAL;
-
-  GemmP p;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.A = a->A; p.sAm = a->sAm; p.sAk = a->sAk; p.sAb = a->sAb;
   p.B = a->B; p.sBk = a->sBk; p.sBn = a->sBn; p.sBb = a->sBb;
@@ -365,12 +404,51 @@ extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
   p.batch = a->batch; p.ksplit = ksplit; p.ws = a->workspace;
   p.flt_thr = a->flt_thr; p.flt_cnt = a->flt_cnt; p.flt_val = a->flt_val; p.flt_idx = a->flt_idx; p.flt_cap = a->flt_cap;
   p.kchunk = ksplit > 1 ? (((a->K + ksplit - 1) / ksplit + BK - 1) / BK) * BK : a->K;
+  // (the k-contiguous reading is preferred when a dimension of extent-1 stride is ambiguous)
+  const long long lda = akc ? a->sAm : a->sAk, ldb = bkc ? a->sBn : a->sBk;
+  vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) && (a->sAb % 4 == 0) && (a->sBb % 4 == 0);
+  return MCL_OK;
+}
 
-  // prefer the k-contiguous reading when a dimension of extent-1 stride is ambiguous
+// mcl_gemm_group: n <= 4 problems (fp32 compute, batch 1, no split-K, no filter epilogue) as one launch; `args` is an array of
+// structs `args[0].struct_size` bytes apart.
+extern "C" int mcl_gemm_group(const mcl_gemm_args* args, int32_t n, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (!args || n <= 0 || n > GROUP_MAX) return MCL_EINVAL;
+  const uint32_t stride = args->struct_size;
+  if (stride < kGemmArgsMin) return MCL_EINVAL;
+  GemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const mcl_gemm_args* ai = reinterpret_cast<const mcl_gemm_args*>(reinterpret_cast<const char*>(args) + (size_t)i * stride);
+    if (ai->struct_size != stride) return MCL_EINVAL;
+    mcl_gemm_args local;
+    bool akc, bkc, vec;
+    const int rc = gemm_prepare(ai, &local, g.p[i], akc, bkc, vec);
+    if (rc != MCL_OK) return rc;
+    if (local.compute != MCL_COMPUTE_F32 || local.batch != 1 || local.ksplit > 1 || local.flt_thr) return MCL_EUNSUPPORTED;
+    g.layout[i] = (akc ? 1 : 0) | (bkc ? 2 : 0) | (vec ? 4 : 0);
+    g.first[i] = tiles;
+    tiles += ((local.M + BM - 1) / BM) * ((local.N + BN - 1) / BN);
+  }
+  for (int i = n; i <= GROUP_MAX; ++i) g.first[i] = tiles;
+  hipLaunchKernelGGL(gemm_group_kernel, dim3(tiles), dim3(NT), 0, mcl_stream(stream), g);
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  mcl_gemm_args local;
+  GemmP p;
+  bool akc, bkc, vec;
+  const int rc = gemm_prepare(caller_args, &local, p, akc, bkc, vec);
+  if (rc != MCL_OK) return rc;
+  const mcl_gemm_args* a = &local;
+  const int ksplit = p.ksplit;
   const bool AKC = akc, BKC = bkc;
-  const long long lda = AKC ? a->sAm : a->sAk, ldb = BKC ? a->sBn : a->sBk;
-  const bool vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) &&
-                   (a->sAb % 4 == 0) && (a->sBb % 4 == 0);
   hipStream_t st = mcl_stream(stream);
   const bool bf16 = a->compute == MCL_COMPUTE_BF16;
   if (AKC && BKC) launch1<true, true>(p, a->batch, vec, bf16, st);

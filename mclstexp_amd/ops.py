@@ -423,12 +423,118 @@ class LinearFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- ProjectionHead (model.py:151-168)
+# Round 6: the head as one forward launch (mcl_proj_head_fwd), one row-local backward launch (mcl_proj_head_bwd_rows) and one
+# grouped launch for the three products over the batch rows (mcl_gemm_group) -- 3 launches where the epilogue-fused GEMMs + split-K
+# merges + LayerNorm + column sums were 17.  fp32 compute mode and projection_dim = 256 only; MCL_FUSED_HEAD=0: the separate
+# launches (A/B; same math, other summation order).
+FUSED_HEAD = os.environ.get("MCL_FUSED_HEAD", "1") != "0"
+HEAD_P = 256
+_head_counters = {}
+
+
+def _head_counter_words(owner: Tensor, n: int) -> Tensor:
+    """The head kernels' arrival counters: zero before the first call, left zero by every call (csrc/proj_head.hip), one
+    array per weight (two heads may run on two streams at once)."""
+    key = (owner.device.index, owner.data_ptr())
+    t = _head_counters.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1024), device=owner.device, dtype=torch.int32)
+        _head_counters[key] = t
+    return t
+
+
+def gemm_group(problems) -> None:
+    """``problems``: up to four dicts of mcl_gemm_args fields (fp32, batch 1, no split-K) -> one launch."""
+    n = len(problems)
+    arr = (_lib.GemmArgs * n)()
+    for i, kw in enumerate(problems):
+        a = arr[i]
+        a.struct_size = C.sizeof(_lib.GemmArgs)
+        a.batch, a.alpha, a.compute = 1, 1.0, _lib.COMPUTE_F32
+        for k, v in kw.items():
+            setattr(a, k, v)
+    check(_lib.lib().mcl_gemm_group(arr, n, _stream()), "mcl_gemm_group")
+
+
+def _fused_head_ok(x: Tensor, wp: Tensor, wf: Tensor, vecs=()) -> bool:
+    return (FUSED_HEAD and _compute_mode == COMPUTE_F32 and wp.shape[0] == HEAD_P and tuple(wf.shape) == (HEAD_P, HEAD_P)
+            and x.dim() == 2 and x.shape[0] > 0 and wp.stride(1) == 1 and wf.stride(1) == 1
+            and all(v.is_contiguous() and v.data_ptr() % 16 == 0 for v in vecs))     # (bias / LayerNorm vectors: 16-byte loads)
+
+
+def proj_head_fwd(x: Tensor, wp: Tensor, bp: Tensor, wf: Tensor, bf: Tensor, g: Tensor, be: Tensor, eps: float = LN_EPS):
+    """(e, p, a, z, mean, rstd) of the projection head, one launch."""
+    x = _rowmajor(x, "x")
+    M, D = x.shape
+    dev = x.device
+    e, p, a, z = (torch.empty((M, HEAD_P), device=dev, dtype=torch.float32) for _ in range(4))
+    mean = torch.empty((M,), device=dev, dtype=torch.float32)
+    rstd = torch.empty((M,), device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    ks = int(os.environ.get("MCL_HEAD_KSPLIT", "0")) or L.mcl_proj_head_ksplit(M, D)
+    ws = torch.empty(L.mcl_proj_head_ws_floats(M, ks), device=dev, dtype=torch.float32)
+    cnt = _head_counter_words(wp, (M + 15) // 16 + 1)
+    check(L.mcl_proj_head_fwd(x.data_ptr(), x.stride(0), M, D, wp.data_ptr(), wp.stride(0), bp.data_ptr(), wf.data_ptr(),
+                              wf.stride(0), bf.data_ptr(), g.data_ptr(), be.data_ptr(), eps, e.data_ptr(), p.data_ptr(),
+                              a.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), cnt.data_ptr(), ks,
+                              _stream()), "mcl_proj_head_fwd")
+    return e, p, a, z, mean, rstd
+
+
+def proj_head_bwd_rows(de: Tensor, z: Tensor, mean: Tensor, rstd: Tensor, g: Tensor, p: Tensor, wf: Tensor, vec_params):
+    """dz, dp and the four column sums (d gamma, d beta, d bf, d bp); ``vec_params`` = the four Parameters in that order: one
+    that owns a dense fp32 .grad gets the sum added into it (None returned for it)."""
+    de = _rowmajor(de, "de")
+    M = de.shape[0]
+    dev = de.device
+    dz = torch.empty((M, HEAD_P), device=dev, dtype=torch.float32)
+    dp = torch.empty((M, HEAD_P), device=dev, dtype=torch.float32)
+    outs, ptrs, mask = [], [], 0
+    for i, q in enumerate(vec_params):
+        if q is not None and q.shape == (HEAD_P,) and _direct_grad_ok(q):
+            outs.append(None)
+            ptrs.append(q.grad.data_ptr())
+            mask |= 1 << i
+        else:
+            t = torch.empty((HEAD_P,), device=dev, dtype=torch.float32)
+            outs.append(t)
+            ptrs.append(t.data_ptr())
+    nrb = (M + 15) // 16
+    ws = torch.empty(nrb * 4 * HEAD_P, device=dev, dtype=torch.float32)
+    cnt = _head_counter_words(wf, nrb + 1)
+    check(_lib.lib().mcl_proj_head_bwd_rows(de.data_ptr(), de.stride(0), M, z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            g.data_ptr(), p.data_ptr(), wf.data_ptr(), wf.stride(0), dz.data_ptr(), dp.data_ptr(),
+                                            ptrs[0], ptrs[1], ptrs[2], ptrs[3], mask, ws.data_ptr(),
+                                            cnt.data_ptr() + 4 * nrb, _stream()), "mcl_proj_head_bwd_rows")
+    return dz, dp, outs
+
+
+def _wgrad_problem(dy: Tensor, x: Tensor, param: Tensor, dev):
+    """dW = dy^T x as a grouped-launch problem: (fields, tensor handed to autograd or None when it went into param.grad)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    f = dict(M=N, N=K, K=M, A=dy.data_ptr(), sAm=1, sAk=dy.stride(0), B=x.data_ptr(), sBk=x.stride(0), sBn=1)
+    if param is not None and param.shape == (N, K) and _direct_grad_ok(param):
+        f.update(C=param.grad.data_ptr(), ldc=K, flags=EPI_ACCUM)
+        return f, None
+    dW = torch.empty((N, K), device=dev, dtype=torch.float32)
+    f.update(C=dW.data_ptr(), ldc=K)
+    return f, dW
+
+
 class ProjectionHeadFn(torch.autograd.Function):
     """p = x Wp^T + bp ; E = LN(gelu(p) Wf^T + bf + p)   (dropout p=0, model.py:164)."""
 
     @staticmethod
     def forward(ctx, x, wp, bp, wf, bf, g, be):
         x = _rowmajor(x, "x")
+        ctx.fused = _fused_head_ok(x, wp, wf, (bp, bf, g, be))
+        if ctx.fused:
+            e, p, a, z, mean, rstd = proj_head_fwd(x, wp, bp, wf, bf, g, be)
+            ctx.save_for_backward(x, wp, wf, g, p, a, z, mean, rstd)
+            ctx.wparams = (wp, wf)
+            ctx.bparams = (bp, bf, g, be)
+            return e
         a, p = linear_fwd(x, wp, bp, gelu=True, save_pre=True)
         z, _ = linear_fwd(a, wf, bf, resid=p)
         e, mean, rstd = layernorm_fwd(z, g, be)
@@ -441,6 +547,17 @@ class ProjectionHeadFn(torch.autograd.Function):
     def backward(ctx, de):
         x, wp, wf, g, p, a, z, mean, rstd = ctx.saved_tensors
         q_bp, q_bf, q_g, q_be = ctx.bparams
+        if ctx.fused:
+            dz, dp, (dg, dbe, dbf, dbp) = proj_head_bwd_rows(de, z, mean, rstd, g, p, wf, (q_g, q_be, q_bf, q_bp))
+            f1, dwf = _wgrad_problem(dz, a, ctx.wparams[1], x.device)
+            f2, dwp = _wgrad_problem(dp, x, ctx.wparams[0], x.device)
+            probs, dx = [f1, f2], None
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+                probs.append(dict(M=x.shape[0], N=x.shape[1], K=HEAD_P, A=dp.data_ptr(), sAm=HEAD_P, sAk=1, B=wp.data_ptr(),
+                                  sBk=wp.stride(0), sBn=1, C=dx.data_ptr(), ldc=x.shape[1]))
+            gemm_group(probs)
+            return dx, dwp, dbp, dwf, dbf, dg, dbe
         dz, dg, dbe = layernorm_bwd(_rowmajor(de, "de"), z, g, mean, rstd, params=(q_g, q_be))
         dwf = linear_bwd_weight(dz, a, ctx.wparams[1])
         dbf = colsum(dz, q_bf)

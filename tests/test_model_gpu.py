@@ -70,7 +70,10 @@ def test_model_matches_reference_fixture(name, optimizer):
                         3e-5 * float(z["gradabs." + n]) + 1e-7, "gradsum " + n
         opt.step()
         tag = f"step{step}."
-        tol_p = 2e-6 if step == 0 else 3e-5
+        # Adam's first update is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 a gradient difference d moves the parameter by up to
+        # lr / eps * d = 1e4 d, so the summation-order noise of a gradient (a few 1e-10 here) shows as a few 1e-6 in one or two
+        # of the position-table elements (2.3e-6 seen with the single-launch projection head's other summation order)
+        tol_p = 4e-6 if step == 0 else 3e-5
         last = step == meta["steps"] - 1
         if fused and lazy and last:
             opt.materialize_tables()    # the fixture's untouched row (60000) has been replayed over all steps at once
