@@ -29,28 +29,7 @@ constexpr int MAX_KS = 16;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void st16_sc1(float* p, float4 v) {      // write-through 16-byte store (visible to every XCD once drained)
-  const f32x4 r = {v.x, v.y, v.z, v.w};
-  // (s_nop: a store of more than 8 bytes reads its data registers late -- the VALU write that may follow needs wait states the
-  //  compiler's hazard pass cannot insert for an instruction it does not see)
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(p), "v"(r) : "memory");
-}
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// Four 16-byte loads that bypass the non-coherent caches, all in flight together, and the wait for them, as ONE asm statement:
-// the compiler cannot see that such a load completes later, so nothing of it may be visible before the wait.
-__device__ __forceinline__ void ld4x16_sc1(const float* p0, const float* p1, const float* p2, const float* p3, f32x4& a, f32x4& b,
-                                           f32x4& c, f32x4& d) {
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
-      "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-      "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
-      "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
-      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-      : "memory");
-}
-
 // One BK-slice of a K-contiguous 256-row weight (row stride ld, k in [k0, k0 + 32) clipped to kend) -> 8 float4 per thread.
 template <bool VEC>
 __device__ __forceinline__ void load_w_kc(float4 (&r)[8], const float* __restrict__ W, long long ld, int k0, int kend, int tid) {
@@ -139,6 +118,12 @@ struct HeadF {
 
 constexpr int FWD_LDS_FLOATS = P * LDW + RB * LDW + 2 * RB * LDT + 4;     // weight slice + x slice + two activation tiles + flag
 
+// Everything here is a chain of dependent round trips to L2 / memory (~1 us each) with microseconds of arithmetic between them:
+// the weight slices travel through a PD-deep register pipeline (all of a short K slice's loads are in flight at once), the
+// second layer's first PD slices are requested before the partials are read back, and the partials of four K slices at a time.
+constexpr int PD = 4;
+typedef unsigned long long u64;
+
 template <bool VEC>
 __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -156,33 +141,44 @@ __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  float4 rw[8];
+  float4 rw[PD][8], rx[PD];
   const int nk = (kend - kbeg + BK - 1) / BK;
-  load_w_kc<VEC>(rw, h.wp, h.ldwp, kbeg, kend, tid);
-  float4 rx = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg, kend, tid);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_w_kc(rw, Ws, tid);
-    if (tid < 128) *reinterpret_cast<float4*>(Xs + (tid >> 3) * LDW + (tid & 7) * 4) = rx;
-    __syncthreads();
-    if (kt + 1 < nk) {
-      load_w_kc<VEC>(rw, h.wp, h.ldwp, kbeg + (kt + 1) * BK, kend, tid);
-      rx = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + (kt + 1) * BK, kend, tid);
+#pragma unroll
+  for (int u = 0; u < PD; ++u)
+    if (u < nk) {
+      load_w_kc<VEC>(rw[u], h.wp, h.ldwp, kbeg + u * BK, kend, tid);
+      rx[u] = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + u * BK, kend, tid);
     }
-    mma_slice_kc(acc, Xs, LDW, Ws, wave, lane);
-    __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int kt = kt0 + u;
+      if (kt < nk) {
+        store_w_kc(rw[u], Ws, tid);
+        if (tid < 128) *reinterpret_cast<float4*>(Xs + (tid >> 3) * LDW + (tid & 7) * 4) = rx[u];
+        __syncthreads();
+        if (kt + PD < nk) {
+          load_w_kc<VEC>(rw[u], h.wp, h.ldwp, kbeg + (kt + PD) * BK, kend, tid);
+          rx[u] = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + (kt + PD) * BK, kend, tid);
+        }
+        mma_slice_kc(acc, Xs, LDW, Ws, wave, lane);
+        __syncthreads();
+      }
+    }
   }
-  // (the second layer's first weight slice: requested now, in flight during the hand-over)
-  load_w_kc<VEC>(rw, h.wf, h.ldwf, 0, P, tid);
 
   acc_to_tile(acc, T0, wave, lane);
   __syncthreads();
-  float* mine = h.ws + ((long long)rb * h.ks + sl) * (RB * P);
+  // the 16 x 256 partial out, write-through: 8-byte stores, 512 contiguous bytes per wave instruction
+  u64* mine = reinterpret_cast<u64*>(h.ws + ((long long)rb * h.ks + sl) * (RB * P));
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int f = tid + NT * j, row = f >> 6, c4 = f & 63;
-    st16_sc1(mine + row * P + c4 * 4, *reinterpret_cast<const float4*>(T0 + row * LDT + c4 * 4));
+  for (int j = 0; j < 8; ++j) {
+    const int f = tid + NT * j, row = f >> 7, c2 = f & 127;
+    const float2 v = *reinterpret_cast<const float2*>(T0 + row * LDT + c2 * 2);
+    __hip_atomic_store(mine + row * (P / 2) + c2, ((u64)__float_as_uint(v.y) << 32) | (u64)__float_as_uint(v.x), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   }
-  drain();                                 // (also lands the weight prefetch: the stores are what matters)
+  drain();
   __syncthreads();
   if (tid == 0) {
     const unsigned ticket = __hip_atomic_fetch_add(h.cnt + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -191,31 +187,48 @@ __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
   __syncthreads();
   if (!s_last) return;
 
-  // ---- the row block's last arriver: p = sum of the slices in slice order + bias
-  const float* part = h.ws + (long long)rb * h.ks * (RB * P);
+  // ---- the row block's last arriver.  The second layer's first PD weight slices: requested now.
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int f = tid + NT * j, row = f >> 6, c4 = f & 63;
-    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (int u = 0; u < PD; ++u) load_w_kc<VEC>(rw[u], h.wf, h.ldwf, u * BK, P, tid);
+  // p = sum of the slices in slice order + bias
+  {
+    const u64* part = reinterpret_cast<const u64*>(h.ws + (long long)rb * h.ks * (RB * P));
+    float2 sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = make_float2(0.0f, 0.0f);
     for (int s0 = 0; s0 < h.ks; s0 += 4) {
-      f32x4 v[4];
-      const float* q[4];
+      u64 v[4][8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)        // (past the last slice: the last slice again, not added)
-        q[i] = part + (long long)min(s0 + i, h.ks - 1) * (RB * P) + row * P + c4 * 4;
-      ld4x16_sc1(q[0], q[1], q[2], q[3], v[0], v[1], v[2], v[3]);
+      for (int i = 0; i < 4; ++i) {        // (past the last slice: the last slice again, not added)
+        const u64* q = part + (long long)min(s0 + i, h.ks - 1) * (RB * P / 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int f = tid + NT * j;
+          v[i][j] = __hip_atomic_load(q + (f >> 7) * (P / 2) + (f & 127), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (s0 + i < h.ks) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+        if (s0 + i < h.ks) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            sum[j].x += __uint_as_float((unsigned)v[i][j]);
+            sum[j].y += __uint_as_float((unsigned)(v[i][j] >> 32));
+          }
+        }
     }
-    const float4 b = *reinterpret_cast<const float4*>(h.bp + c4 * 4);
-    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-    const float4 g = make_float4(gelu_erf(s.x), gelu_erf(s.y), gelu_erf(s.z), gelu_erf(s.w));
-    *reinterpret_cast<float4*>(T0 + row * LDT + c4 * 4) = s;
-    *reinterpret_cast<float4*>(T1 + row * LDT + c4 * 4) = g;
-    if (m0 + row < h.M) {
-      *reinterpret_cast<float4*>(h.p + (long long)(m0 + row) * P + c4 * 4) = s;
-      *reinterpret_cast<float4*>(h.a + (long long)(m0 + row) * P + c4 * 4) = g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = tid + NT * j, row = f >> 7, c2 = f & 127;
+      const float2 b = *reinterpret_cast<const float2*>(h.bp + c2 * 2);
+      const float2 s = make_float2(sum[j].x + b.x, sum[j].y + b.y);
+      const float2 g = make_float2(gelu_erf(s.x), gelu_erf(s.y));
+      *reinterpret_cast<float2*>(T0 + row * LDT + c2 * 2) = s;
+      *reinterpret_cast<float2*>(T1 + row * LDT + c2 * 2) = g;
+      if (m0 + row < h.M) {
+        *reinterpret_cast<float2*>(h.p + (long long)(m0 + row) * P + c2 * 2) = s;
+        *reinterpret_cast<float2*>(h.a + (long long)(m0 + row) * P + c2 * 2) = g;
+      }
     }
   }
   if (tid == 0) __hip_atomic_store(h.cnt + rb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -223,12 +236,16 @@ __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
   // ---- phase 2: z = gelu(p) Wf^T + bf + p   (K = 256)
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  for (int kt = 0; kt < P / BK; ++kt) {
-    store_w_kc(rw, Ws, tid);
-    __syncthreads();                       // (first pass: also publishes T0 / T1)
-    if (kt + 1 < P / BK) load_w_kc<VEC>(rw, h.wf, h.ldwf, (kt + 1) * BK, P, tid);
-    mma_slice_kc(acc, T1 + kt * BK, LDT, Ws, wave, lane);
-    __syncthreads();
+  for (int kt0 = 0; kt0 < P / BK; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int kt = kt0 + u;
+      store_w_kc(rw[u], Ws, tid);
+      __syncthreads();                     // (first pass: also publishes T0 / T1)
+      if (kt + PD < P / BK) load_w_kc<VEC>(rw[u], h.wf, h.ldwf, (kt + PD) * BK, P, tid);
+      mma_slice_kc(acc, T1 + kt * BK, LDT, Ws, wave, lane);
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -307,22 +324,20 @@ __global__ __launch_bounds__(NT) void proj_head_bwd_rows_kernel(const HeadB h) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rb = blockIdx.x, m0 = rb * RB;
 
-  // the first weight slice (32 rows of Wf, 256 contiguous columns each): 8 float4 per thread
-  float4 rw[8];
-  auto load_w = [&](int n0) {
-#pragma unroll
-    for (int hh = 0; hh < 8; ++hh)
-      rw[hh] = *reinterpret_cast<const float4*>(h.wf + (long long)(n0 + (tid >> 6) + 4 * hh) * h.ldwf + (tid & 63) * 4);
-  };
-  auto load_w_scalar = [&](int n0) {
+  // the first PD weight slices (32 rows of Wf each, 256 contiguous columns per row; 8 float4 per thread and slice): requested
+  // before anything else -- the LayerNorm backward below runs under their latency
+  float4 rw[PD][8];
+  const bool vec = ((reinterpret_cast<uintptr_t>(h.wf) & 15u) == 0) && (h.ldwf % 4 == 0);
+  auto load_w = [&](float4 (&r)[8], int n0) {
 #pragma unroll
     for (int hh = 0; hh < 8; ++hh) {
       const float* q = h.wf + (long long)(n0 + (tid >> 6) + 4 * hh) * h.ldwf + (tid & 63) * 4;
-      rw[hh] = make_float4(q[0], q[1], q[2], q[3]);
+      if (vec) r[hh] = *reinterpret_cast<const float4*>(q);
+      else     r[hh] = make_float4(q[0], q[1], q[2], q[3]);
     }
   };
-  const bool vec = ((reinterpret_cast<uintptr_t>(h.wf) & 15u) == 0) && (h.ldwf % 4 == 0);
-  if (vec) load_w(0); else load_w_scalar(0);
+#pragma unroll
+  for (int u = 0; u < PD; ++u) load_w(rw[u], u * BK);
 
   // ---- LayerNorm backward, row-local: 16 threads per row
   {
@@ -380,25 +395,29 @@ __global__ __launch_bounds__(NT) void proj_head_bwd_rows_kernel(const HeadB h) {
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  for (int kt = 0; kt < P / BK; ++kt) {
+  for (int kt0 = 0; kt0 < P / BK; kt0 += PD) {
 #pragma unroll
-    for (int hh = 0; hh < 8; ++hh) *reinterpret_cast<float4*>(Ws + ((tid >> 6) + 4 * hh) * LDT + (tid & 63) * 4) = rw[hh];
-    __syncthreads();
-    if (kt + 1 < P / BK) { if (vec) load_w((kt + 1) * BK); else load_w_scalar((kt + 1) * BK); }
+    for (int u = 0; u < PD; ++u) {
+      const int kt = kt0 + u;
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      const int ko = kc * 16 + 4 * (lane >> 4);
-      const float4 a = *reinterpret_cast<const float4*>(Dz + (lane & 15) * LDT + kt * BK + ko);
+      for (int hh = 0; hh < 8; ++hh) *reinterpret_cast<float4*>(Ws + ((tid >> 6) + 4 * hh) * LDT + (tid & 63) * 4) = rw[u][hh];
+      __syncthreads();
+      if (kt + PD < P / BK) load_w(rw[u], (kt + PD) * BK);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float* b = Ws + ko * LDT + wave * 64 + t * 16 + (lane & 15);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[LDT], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2 * LDT], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3 * LDT], acc[t], 0, 0, 0);
+      for (int kc = 0; kc < 2; ++kc) {
+        const int ko = kc * 16 + 4 * (lane >> 4);
+        const float4 a = *reinterpret_cast<const float4*>(Dz + (lane & 15) * LDT + kt * BK + ko);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float* b = Ws + ko * LDT + wave * 64 + t * 16 + (lane & 15);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[LDT], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2 * LDT], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3 * LDT], acc[t], 0, 0, 0);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -434,11 +453,21 @@ __global__ __launch_bounds__(NT) void proj_head_bwd_rows_kernel(const HeadB h) {
   __syncthreads();
   if (!s_last) return;
   float tot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  for (int b = 0; b < h.nrb; ++b)
+  for (int b0 = 0; b0 < h.nrb; b0 += 8) {          // eight blocks' partials in flight at a time
+    unsigned v[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      tot[i] += __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(h.ws + ((long long)b * 4 + i) * P + tid),
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[b][i] = __hip_atomic_load(reinterpret_cast<const unsigned*>(h.ws + ((long long)min(b0 + b, h.nrb - 1) * 4 + i) * P + tid),
+                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b0 + b < h.nrb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tot[i] += __uint_as_float(v[b][i]);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     if (h.out[i]) h.out[i][tid] = ((h.accumulate >> i) & 1) ? h.out[i][tid] + tot[i] : tot[i];

@@ -39,8 +39,15 @@ def main():
         step(batches[i % 4])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    from mclstexp_amd import kernel_audit
+    ks = kernel_audit.step_kernels(lambda: step(batches[0]))
+    ks = {k: v for k, v in ks.items() if not any(h in k for h in kernel_audit.RUNTIME_HELPERS)}
     print(json.dumps({"workload": "spot branch + heads + InfoNCE + Adam (identity image encoder), one stream",
-                      "batch": B, "genes": G, "split_k": ops.SPLIT_K, "ms_per_step": round(dt * 1e3, 4)}), flush=True)
+                      "batch": B, "genes": G, "split_k": ops.SPLIT_K, "fused_head": ops.FUSED_HEAD,
+                      "ms_per_step": round(dt * 1e3, 4), "kernel_launches_per_step": sum(ks.values()),
+                      "kernels": dict(sorted(((k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-48:], v)
+                                               for k, v in ks.items()), key=lambda kv: -kv[1]))}),
+          flush=True)
 
 
 if __name__ == "__main__":
