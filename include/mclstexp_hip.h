@@ -82,6 +82,10 @@ typedef struct mcl_gemm_args {
    * candidate list: pos = atomic flt_cnt[i]++ (zero on entry), flt_val[i * flt_cap + pos] = value, flt_idx[...] = j when
    * pos < flt_cap (flt_cnt keeps counting past the capacity: the caller sees the overflow).  batch 1, no split-K, no epilogue. */
   const float* flt_thr; int32_t* flt_cnt; float* flt_val; int32_t* flt_idx; int32_t flt_cap;
+  /* ABI 9: split-K in ONE launch.  counters != NULL (and ksplit > 1, 64x64 tiles): ceil(M/64) * ceil(N/64) * batch uint32, ZERO on
+   * entry and left zero -- the last K slice to arrive at a tile adds the slices in slice order and applies the epilogue itself
+   * (bit-identical to the two-launch form); one counter array per concurrently running call (e.g. per stream).  NULL: two launches. */
+  uint32_t* counters;
 } mcl_gemm_args;
 
 int mcl_gemm(const mcl_gemm_args* args, mcl_stream_t stream);

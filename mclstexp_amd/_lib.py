@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
         ("compute", c_i), ("ksplit", c_i),
         ("workspace", c_p),
         ("flt_thr", c_p), ("flt_cnt", c_p), ("flt_val", c_p), ("flt_idx", c_p), ("flt_cap", c_i),
+        ("counters", c_p),
     ]
 
 

@@ -35,6 +35,7 @@ struct GemmP {
   const float* aux; long long ldaux;
   int batch, ksplit, kchunk;     // split-K: slice s covers k in [s*kchunk, min(K, (s+1)*kchunk)), kchunk % BK == 0
   float* ws;                     // split-K partials [ksplit][batch][M][N]
+  unsigned* cnt;                 // split-K, one launch: arrival counter per (batch, tile) -- NULL: the two-launch form
   // threshold filter instead of a C store (retrieval): alpha * acc >= flt_thr[row] appends (value, col) to the row's list
   const float* flt_thr; int* flt_cnt; float* flt_val; int* flt_idx; int flt_cap;
 };
@@ -249,6 +250,59 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
       }
     return;
   }
+  if (TM == 1 && p.ksplit > 1 && p.cnt) {
+    // Split-K in ONE launch: the partial goes out with write-through stores, the workgroup drains them and takes a ticket on its
+    // tile's counter; the LAST slice to arrive adds all slices in slice order (the order of gemm_splitk_epilogue_kernel: the
+    // result is the same bit for bit, whoever is last) and runs the epilogue below.  Nobody waits for anybody; the counter is
+    // left at zero.  (A second launch costs the spot path ~8 us per product: 25 of them per step.)
+    const int col = n0 + wn * 32 + (lane & 31);
+    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    const long long MN = (long long)p.M * p.N;
+    unsigned* W = reinterpret_cast<unsigned*>(p.ws) + ((long long)ksl * p.batch + bz) * MN;
+    if (col < p.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < p.M)
+          __hip_atomic_store(W + (long long)row * p.N + col, __float_as_uint(acc[0][0][r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* s_flag = reinterpret_cast<int*>(As);
+    if (tid == 0) {
+      unsigned* c = p.cnt + ((long long)bz * gridDim.y + by) * gridDim.x + bx;
+      const unsigned ticket = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_flag = (ticket == (unsigned)p.ksplit - 1u);
+      if (*s_flag) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    if (col < p.N) {
+      const unsigned* W0 = reinterpret_cast<const unsigned*>(p.ws) + (long long)bz * MN + col;
+      for (int s0 = 0; s0 < p.ksplit; s0 += 4) {        // four slices' elements in flight
+        unsigned v[4][16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned* Ws_ = W0 + (long long)min(s0 + i, p.ksplit - 1) * p.batch * MN;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1);
+            v[i][r] = __hip_atomic_load(Ws_ + (long long)row * p.N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (s0 + i < p.ksplit) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += __uint_as_float(v[i][r]);
+          }
+      }
+    }
+  }
+  const bool merged = TM == 1 && p.ksplit > 1 && p.cnt;
   // epilogue: acc[i][j][r] -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the wave's (i, j) 32x32 block
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti)
@@ -257,7 +311,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
       const int col = n0 + (wn * TM + tj) * 32 + (lane & 31);
       const int rbase = m0 + (wm * TM + ti) * 32 + 4 * (lane >> 5);
       if (col >= p.N) continue;
-      if (p.ksplit > 1) {   // raw partial of this K slice; the epilogue runs in gemm_splitk_epilogue_kernel
+      if (p.ksplit > 1 && !merged) {   // raw partial of this K slice; the epilogue runs in gemm_splitk_epilogue_kernel
         float* __restrict__ W = p.ws + ((long long)ksl * p.batch + bz) * p.M * p.N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -347,8 +401,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmP p
   }
 }
 
-template <bool AKC, bool BKC, bool VEC>
-void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
+// 128 x 128 tiles?
+bool mcl_gemm_wide_tiles(const GemmP& p) {
+  const int batch = p.batch;
   // 128 x 128 tiles once they alone fill the chip twice over (and no split-K: that is the skinny-problem form)
   const long long big_tiles = (long long)((p.N + 2 * BN - 1) / (2 * BN)) * ((p.M + 2 * BM - 1) / (2 * BM)) * batch;
   // ... or a long reduction cut into K slices over a mid-sized output (mcl_gemm_auto_ksplit's second rule)
@@ -356,7 +411,12 @@ void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
   // (only where a 128-wide tile is not mostly padding: the generic convolutions' N = 32 / 128 outputs stay on 64 x 64 tiles --
   //  fp32 DenseNet step 105 vs 115 ms with 128 x 128 tiles there)
   const bool wide = p.N >= 640 && p.M >= 256 && ((p.N + 127) / 128) * 128 - p.N <= p.N / 8;
-  if (wide && ((p.ksplit == 1 && big_tiles >= 512) || (p.ksplit > 1 && tiles64 >= 128 && p.K >= 8192 && big_tiles * p.ksplit >= 256))) {
+  return wide && ((p.ksplit == 1 && big_tiles >= 512) || (p.ksplit > 1 && tiles64 >= 128 && p.K >= 8192 && big_tiles * p.ksplit >= 256));
+}
+
+template <bool AKC, bool BKC, bool VEC>
+void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
+  if (mcl_gemm_wide_tiles(p)) {
     dim3 grid((p.N + 2 * BN - 1) / (2 * BN), (p.M + 2 * BM - 1) / (2 * BM), batch * p.ksplit), block(NT);
     if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 2>), grid, block, 0, st, p);
     else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 2>), grid, block, 0, st, p);
@@ -412,6 +472,7 @@ static int gemm_prepare(const mcl_gemm_args* caller_args, mcl_gemm_args* a, Gemm
   p.resid = a->resid; p.ldr = a->ldr; p.sRb = a->sRb;
   p.pre_out = a->pre_out; p.ldp = a->ldp; p.aux = a->aux; p.ldaux = a->ldaux;
   p.batch = a->batch; p.ksplit = ksplit; p.ws = a->workspace;
+  p.cnt = ksplit > 1 ? a->counters : nullptr;
   p.flt_thr = a->flt_thr; p.flt_cnt = a->flt_cnt; p.flt_val = a->flt_val; p.flt_idx = a->flt_idx; p.flt_cap = a->flt_cap;
   p.kchunk = ksplit > 1 ? (((a->K + ksplit - 1) / ksplit + BK - 1) / BK) * BK : a->K;
   // (the k-contiguous reading is preferred when a dimension of extent-1 stride is ambiguous)
@@ -465,7 +526,7 @@ extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
   else if (AKC && !BKC) launch1<true, false>(p, a->batch, vec, bf16, st);
   else if (!AKC && BKC) launch1<false, true>(p, a->batch, vec, bf16, st);
   else launch1<false, false>(p, a->batch, vec, bf16, st);
-  if (ksplit > 1) {
+  if (ksplit > 1 && !(p.cnt && !mcl_gemm_wide_tiles(p))) {       // (the one-launch split-K exists for the 64 x 64 tiles)
     const long long total = (long long)a->M * a->N * a->batch;
     const unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(gemm_splitk_epilogue_kernel, dim3(nb), dim3(256), 0, st, p);

@@ -83,6 +83,26 @@ def _p(t: Optional[Tensor]) -> Optional[int]:
 
 # --------------------------------------------------------------------------- GEMM
 SPLIT_K = True
+# Round 6: the slices' merge + epilogue inside the product's own launch (mcl_gemm_args.counters: the last slice to arrive at a
+# tile does it, csrc/gemm.hip) instead of a second launch; bit-identical, 86 -> 70 launches per spot-branch step -- and SLOWER:
+# 0.998 vs 0.935 ms/step (write-through partials + drain + ticket + a one-workgroup merge per tile cost more than the 5 us launch
+# they replace: profiles/r06_spot_branch.json).  Off by default; MCL_GEMM_SPLITK_MERGE=1 turns it on.
+SPLIT_K_ONE_LAUNCH = os.environ.get("MCL_GEMM_SPLITK_MERGE", "0") == "1"
+_splitk_cnt = {}
+
+
+def _splitk_counters(device, n: int) -> Optional[Tensor]:
+    """Arrival counters of the one-launch split-K: zero before the first use, left zero by every launch; one array per
+    (device, stream) -- launches on one stream run one after the other, lanes on different streams never share."""
+    if n > 65536:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _splitk_cnt.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 4096), device=device, dtype=torch.int32)
+        check(_lib.lib().mcl_fill_zero(t.data_ptr(), t.numel() * 4, _stream()), "mcl_fill_zero")
+        _splitk_cnt[key] = t
+    return t
 
 
 def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, sAb: int, B: Tensor, sBk: int,
@@ -113,6 +133,8 @@ def gemm_raw(M: int, N: int, K: int, batch: int, A: Tensor, sAm: int, sAk: int, 
     if ks > 1:    # skinny problem (M = a batch of spots): K slices + fixed-order merge fill the chip
         ws = torch.empty(ks * batch * M * N, device=Cmat.device, dtype=torch.float32)
         a.ksplit, a.workspace = ks, ws.data_ptr()
+        if SPLIT_K_ONE_LAUNCH:
+            a.counters = _p(_splitk_counters(Cmat.device, ((M + 63) // 64) * ((N + 63) // 64) * batch))
     check(_lib.lib().mcl_gemm(C.byref(a), _stream()), "mcl_gemm")
 
 
@@ -438,7 +460,8 @@ def _head_counter_words(owner: Tensor, n: int) -> Tensor:
     key = (owner.device.index, owner.data_ptr())
     t = _head_counters.get(key)
     if t is None or t.numel() < n:
-        t = torch.zeros(max(n, 1024), device=owner.device, dtype=torch.int32)
+        t = torch.empty(max(n, 1024), device=owner.device, dtype=torch.int32)
+        check(_lib.lib().mcl_fill_zero(t.data_ptr(), t.numel() * 4, _stream()), "mcl_fill_zero")
         _head_counters[key] = t
     return t
 

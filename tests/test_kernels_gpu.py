@@ -95,6 +95,41 @@ def test_gemm_splitk_matches_one_pass_and_is_deterministic(ops):
     assert_close_scaled(C3.cpu(), A3.cpu().double() @ B3.cpu().double(), 2e-6, what="batched split-K")
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(128, 1536, 1000, 1), (128, 256, 1024, 1), (33, 171, 785, 1), (40, 70, 500, 3), (128, 1000, 512, 1)])
+def test_gemm_splitk_one_launch_equals_two_launches(ops, M, N, K, batch):
+    """The last-arriver merge inside the product's launch == partials + a second launch, bit for bit (same slice order), with
+    every epilogue; repeated calls find the arrival counters clean."""
+    from mclstexp_amd import _lib
+    assert _lib.lib().mcl_gemm_auto_ksplit(M, N, K, batch) > 1
+    A, B = _rand(batch, M, K, seed=1).to(DEV), _rand(batch, K, N, seed=2, scale=1 / math.sqrt(K)).to(DEV)
+    bias, resid, aux = _rand(N, seed=3).to(DEV), _rand(M, N, seed=4).to(DEV), _rand(M, N, seed=5).to(DEV)
+
+    def run(one, **kw):
+        ops.SPLIT_K_ONE_LAUNCH = one
+        try:
+            Cm = torch.full((batch, M, N), 0.5, device=DEV)
+            pre = torch.empty(M, N, device=DEV) if kw.pop("pre", False) else None
+            ops.gemm_raw(M, N, K, batch, A, K, 1, M * K, B, N, 1, K * N, Cm, N, M * N, pre_out=pre, ldp=N if pre is not None else 0,
+                         **kw)
+            torch.cuda.synchronize()
+            return Cm, pre
+        finally:
+            ops.SPLIT_K_ONE_LAUNCH = False
+
+    cases = [dict(), dict(flags=_lib.EPI_ACCUM, alpha=0.5)]
+    if batch == 1:
+        cases += [dict(flags=_lib.EPI_GELU, bias=bias, resid=resid, ldr=N, pre=True),
+                  dict(flags=_lib.EPI_GELU_BWD, aux=aux, ldaux=N, resid=resid, ldr=N)]
+    for kw in cases:
+        two = run(False, **dict(kw))
+        for _ in range(3):
+            one = run(True, **dict(kw))
+            assert torch.equal(one[0], two[0]), kw
+            if two[1] is not None:
+                assert torch.equal(one[1], two[1]), kw
+    assert_close_scaled(run(True)[0].cpu(), A.cpu().double() @ B.cpu().double(), 2e-6, what="one-launch split-K")
+
+
 def test_linear_bwd_weight_accumulates_into_param_grad(ops):
     """Spot-path weight gradients add straight into an existing fp32 .grad (FusedAdam's flat bucket), also through the
     split-K second pass; without a .grad they are returned."""
