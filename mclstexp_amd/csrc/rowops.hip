@@ -110,6 +110,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// Up to four column sums of `rows` rows each as one launch (a Transformer layer's bias gradients: blockIdx.y picks the problem;
+// per problem the same code and summation order as colsum_kernel -> bit-identical to separate launches).
+struct ColsumGroup {
+  const float* x[4]; long long ldx[4]; float* out[4]; int cols[4]; int accumulate[4];
+  int rows;
+};
+__global__ __launch_bounds__(256) void colsum_group_kernel(const ColsumGroup g) {
+  __shared__ float sm[4][64];
+  const int q = blockIdx.y;
+  const float* __restrict__ x = g.x[q];
+  const long long ldx = g.ldx[q];
+  const int cols = g.cols[q];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= cols) return;
+  float a = 0.0f;
+  if (c < cols)
+    for (int r = grp; r < g.rows; r += 4) a += x[(long long)r * ldx + c];
+  sm[grp][lane] = a;
+  __syncthreads();
+  if (grp == 0 && c < cols) {
+    const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    float* out = g.out[q];
+    out[c] = g.accumulate[q] ? out[c] + v : v;
+  }
+}
+
 // The same column reductions over MANY rows (the fp32 ViT: 6 400 - 25 216 token rows; the one-block-per-64-columns forms above
 // are written for the spot branch's 128 rows and serialise everything else on a dozen workgroups): blockIdx.y owns RCHUNK rows
 // and writes a partial per column; a second launch adds the partials in chunk order (deterministic).  HAS_X: the LayerNorm
@@ -269,6 +296,24 @@ extern "C" int mcl_colsum_ws(const float* x, int64_t ldx, float* out, int32_t ro
   } else {
     hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, x, ldx, out, rows, cols, accumulate);
   }
+  MCL_CHECK_LAUNCH();
+  return MCL_OK;
+}
+
+extern "C" int mcl_colsum_group(int32_t n, const float* const* x, const int64_t* ldx, float* const* out, const int32_t* cols,
+                                const int32_t* accumulate, int32_t rows, mcl_stream_t stream) {
+  MCL_CLEAR_ERROR();
+  if (n <= 0 || n > 4 || !x || !ldx || !out || !cols || !accumulate || rows <= 0 || rows > 1024) return MCL_EINVAL;
+  ColsumGroup g;
+  int maxc = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int j = i < n ? i : 0;
+    if (!x[j] || !out[j] || cols[j] <= 0) return MCL_EINVAL;
+    g.x[i] = x[j]; g.ldx[i] = ldx[j]; g.out[i] = out[j]; g.cols[i] = cols[j]; g.accumulate[i] = accumulate[j];
+    if (i < n && cols[j] > maxc) maxc = cols[j];
+  }
+  g.rows = rows;
+  hipLaunchKernelGGL(colsum_group_kernel, dim3((maxc + 63) / 64, n), dim3(256), 0, mcl_stream(stream), g);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

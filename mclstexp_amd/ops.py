@@ -218,6 +218,30 @@ def colsum(x: Tensor, param: Optional[Tensor] = None) -> Optional[Tensor]:
     return out
 
 
+def colsum_group(items):
+    """``items``: up to four (x, bias Parameter or None) pairs over the same rows -> one launch; returns the list of tensors for
+    autograd (None where the sums went straight into the parameter's .grad)."""
+    n = len(items)
+    xs = [_rowmajor(x, "x") for x, _ in items]
+    rows = xs[0].shape[0]
+    outs, ptrs, acc = [], [], []
+    for x, q in zip(xs, (q for _, q in items)):
+        assert x.shape[0] == rows
+        if q is not None and q.shape == (x.shape[1],) and _direct_grad_ok(q):
+            outs.append(None)
+            ptrs.append(q.grad.data_ptr())
+            acc.append(1)
+        else:
+            t = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+            outs.append(t)
+            ptrs.append(t.data_ptr())
+            acc.append(0)
+    check(_lib.lib().mcl_colsum_group(n, (C.c_void_p * n)(*[x.data_ptr() for x in xs]), (C.c_int64 * n)(*[x.stride(0) for x in xs]),
+                                      (C.c_void_p * n)(*ptrs), (C.c_int32 * n)(*[x.shape[1] for x in xs]), (C.c_int32 * n)(*acc),
+                                      rows, _stream()), "mcl_colsum_group")
+    return outs
+
+
 def _rowred_ws(rows: int, cols: int, device) -> Optional[Tensor]:
     """Chunk-partial workspace of the many-row column reductions (None for the spot branch's few rows: the one-launch forms)."""
     if rows <= 1024:
@@ -367,6 +391,14 @@ def attention_core_bwd_unfused(dout: Tensor, qkv: Tensor, P: Tensor, heads: int,
 
 
 # --------------------------------------------------------------------------- attn_block (model.py:60-69)
+# Round 6: a spot-branch layer's four weight gradients as one grouped launch, its bias gradients as another (A/B: 0 = separate).
+GROUP_LAYER_GRADS = os.environ.get("MCL_GROUP_LAYER_GRADS", "1") != "0"
+
+
+def _mode_of(compute):
+    return _compute_mode if compute is None else compute
+
+
 class AttnBlockFn(torch.autograd.Function):
     """One pre-norm Transformer layer:
         x1 = to_out(attn(LN1(x))) + x ;  x2 = W2 gelu(W1 LN2(x1) + b1) + b2 + x1
@@ -397,6 +429,33 @@ class AttnBlockFn(torch.autograd.Function):
         (x, g1, wqkv, wo, g2, w1, w2, mean1, rstd1, u1, qkv, P, o, x1, mean2, rstd2, u2, pre, h) = ctx.saved_tensors
         p_qkv, p_o, p_1, p_2 = ctx.wparams
         q_bo, q_b1, q_b2, q_g1, q_be1, q_g2, q_be2, q_bqkv = ctx.bparams
+        rows = x.shape[0]
+        if (GROUP_LAYER_GRADS and _mode_of(ctx.compute) == COMPUTE_F32 and rows <= 1024
+                and all(_lib.lib().mcl_gemm_auto_ksplit(w.shape[0], w.shape[1], rows, 1) == 1 for w in (wqkv, wo, w1, w2))):
+            # The spot branch (rows = one batch of spots): the data-gradient chain first, then the four weight gradients as ONE
+            # grouped launch and the bias gradients as another -- 2 launches where they were 7 (K = rows <= 255: none of them
+            # is a split-K problem; each result is bit-identical to its separate launch).
+            with forced_compute(ctx.compute):
+                dx2 = _rowmajor(dx2, "dx2")
+                dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
+                du2 = linear_bwd_data(dpre, w1)
+                dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2, params=(q_g2, q_be2))
+                do = linear_bwd_data(dx1, wo)
+                dqkv = attention_core_bwd(do, qkv, o, P, ctx.heads, ctx.dim_head, ctx.nseq)
+                du1 = linear_bwd_data(dqkv, wqkv)
+                dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, params=(q_g1, q_be1))
+                probs, dws = [], []
+                for dy_, x_, par in ((dx2, h, p_2), (dpre, u2, p_1), (dx1, o, p_o), (dqkv, u1, p_qkv)):
+                    f, t = _wgrad_problem(_rowmajor(dy_, "dy"), x_, par, x.device)
+                    probs.append(f)
+                    dws.append(t)
+                gemm_group(probs)
+                dw2, dw1, dwo, dwqkv = dws
+                items = [(dx2, q_b2), (dpre, q_b1), (dx1, q_bo)] + ([(dqkv, q_bqkv)] if q_bqkv is not None else [])
+                sums = colsum_group(items)
+                db2, db1, dbo = sums[:3]
+                dbqkv = sums[3] if q_bqkv is not None else None
+            return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None, dbqkv, None, None, None
         with forced_compute(ctx.compute):
             dx2 = _rowmajor(dx2, "dx2")
             # ff: x2 = h W2^T + b2 + x1

@@ -391,6 +391,37 @@ def test_attn_block_and_head_vs_oracle(ops, B, G):
             assert_close_scaled(pd[k].grad.cpu(), pr[k].grad, 2e-5, what="grad " + k)
 
 
+@pytest.mark.parametrize("B,G,direct", [(128, 1000, True), (33, 171, False), (8, 785, True)])
+def test_attn_block_grouped_gradient_launches_equal_separate_ones(ops, B, G, direct):
+    """A spot layer's weight gradients as one mcl_gemm_group launch and its bias gradients as one mcl_colsum_group launch ==
+    the seven separate launches, bit for bit (also when they add into the parameters' .grad)."""
+    from mclstexp_amd import synth
+    params = synth.make_params(G, 1024, layers=1, with_tables=False)
+    q = "spot_encoder.0."
+    names = [q + n for n in ("attn.norm.weight", "attn.norm.bias", "attn.fn.to_qkv.weight", "attn.fn.to_out.0.weight",
+                             "attn.fn.to_out.0.bias", "ff.norm.weight", "ff.norm.bias", "ff.fn.net.0.weight", "ff.fn.net.0.bias",
+                             "ff.fn.net.3.weight", "ff.fn.net.3.bias")]
+    x, dy = _rand(B, G, seed=1, scale=2.0), _rand(B, G, seed=2)
+
+    def run(grouped):
+        ops.GROUP_LAYER_GRADS = grouped
+        try:
+            pd = [params[n].to(DEV).requires_grad_(True) for n in names]
+            if direct:
+                for t in pd:
+                    t.grad = torch.full_like(t, 0.125)
+            xd = x.to(DEV).requires_grad_(True)
+            ops.AttnBlockFn.apply(xd, *pd, 8, 64).backward(dy.to(DEV))
+            torch.cuda.synchronize()
+            return [xd.grad] + [t.grad for t in pd]
+        finally:
+            ops.GROUP_LAYER_GRADS = True
+
+    a, b = run(True), run(False)
+    for n, u, v in zip(["x"] + names, a, b):
+        assert torch.equal(u, v), n
+
+
 # ------------------------------------------------------------------ fused InfoNCE (bf16 MFMA, logits never in HBM)
 def _fused_ref(a, b, inv_t, diag_off, lse_b=None):
     """fp64 reference on the bf16-rounded operands: (lse, diag, dA/coef given lse_b)."""
