@@ -191,11 +191,14 @@ int mcl_softmax_rows_bwd(const float* p, float* dp, int64_t ld, int32_t n_rows, 
 /* ---------------------------------------------------------------- bias gradient
  * out[n] = sum_m x[m,n]  (nn.Linear bias backward).                                           */
 int mcl_colsum(const float* x, int64_t ldx, float* out, int32_t rows, int32_t cols, int32_t accumulate, mcl_stream_t stream);
-/* n <= 4 column sums over the same number of rows (<= 1024) as ONE launch: x[i] (rows, cols[i]) row stride ldx[i] -> out[i]
- * (accumulate[i] != 0: +=).  Host arrays of n entries; per problem bit-identical to mcl_colsum.  (A Transformer layer's three bias
- * gradients, model.py:23,27,45.)                                                                                              */
-int mcl_colsum_group(int32_t n, const float* const* x, const int64_t* ldx, float* const* out, const int32_t* cols,
-                     const int32_t* accumulate, int32_t rows, mcl_stream_t stream);
+/* n <= 6 column reductions over the same number of rows (<= 1024) as ONE launch -- a Transformer layer's bias gradients and
+ * LayerNorm parameter gradients (model.py:13,17,23,27,45).  Host arrays of n entries.  x[i] == NULL: out0[i][c] (+)= sum_r a[i][r, c]
+ * (mcl_colsum).  x[i] != NULL: out0[i][c] (+)= sum_r a[i][r, c] * (x[i][r, c] - mean[i][r]) * rstd[i][r] and out1[i][c] (+)=
+ * sum_r a[i][r, c] (the dgamma / dbeta of mcl_layernorm_bwd, which computes dx alone when its dgamma and dbeta are both NULL).
+ * accumulate[i] != 0: +=.  Per problem bit-identical to the separate launches.                                              */
+int mcl_colred_group(int32_t n, const float* const* a, const int64_t* lda, const float* const* x, const int64_t* ldx,
+                     const float* const* mean, const float* const* rstd, float* const* out0, float* const* out1,
+                     const int32_t* cols, const int32_t* accumulate, int32_t rows, mcl_stream_t stream);
 /* ABI 7: the two column reductions above for MANY rows (the fp32 ViT's 6 400 - 25 216 token rows).  With a workspace of
  * mcl_rowred_workspace_floats(rows, cols) floats and rows > 1024 the rows are reduced in 128-row chunks on a 2-D grid and the
  * chunk partials added in chunk order by a second launch (deterministic); otherwise exactly the calls above. */

@@ -87,7 +87,8 @@ PROTOTYPES = {
     "mcl_softmax_rows_fwd": [c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_softmax_rows_bwd": [c_p, c_p, c_l, c_i, c_i, c_f, c_p],
     "mcl_colsum": [c_p, c_l, c_p, c_i, c_i, c_i, c_p],
-    "mcl_colsum_group": [c_i, C.POINTER(c_p), C.POINTER(c_l), C.POINTER(c_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_p],
+    "mcl_colred_group": [c_i, C.POINTER(c_p), C.POINTER(c_l), C.POINTER(c_p), C.POINTER(c_l), C.POINTER(c_p), C.POINTER(c_p),
+                         C.POINTER(c_p), C.POINTER(c_p), C.POINTER(c_i), C.POINTER(c_i), c_i, c_p],
     "mcl_soft_clip_mid": [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
     "mcl_symmetrize": [c_p, c_i, c_p, c_p],
     "mcl_colsum_ws": [c_p, c_l, c_p, c_i, c_i, c_i, c_p, c_p],

@@ -110,30 +110,55 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
-// Up to four column sums of `rows` rows each as one launch (a Transformer layer's bias gradients: blockIdx.y picks the problem;
-// per problem the same code and summation order as colsum_kernel -> bit-identical to separate launches).
-struct ColsumGroup {
-  const float* x[4]; long long ldx[4]; float* out[4]; int cols[4]; int accumulate[4];
+// Up to six column reductions over the same `rows` rows as one launch (a Transformer layer's bias gradients and LayerNorm
+// parameter gradients: blockIdx.y picks the problem).  Kind "sum": out0[c] (+)= sum_r a[r, c].  Kind "LayerNorm" (x != NULL):
+// out0[c] (+)= sum_r a[r, c] * xhat[r, c], out1[c] (+)= sum_r a[r, c].  Per problem the code and summation order of colsum_kernel /
+// layernorm_bwd_dgb_kernel -> bit-identical to the separate launches.
+constexpr int COLRED_MAX = 6;
+struct ColredGroup {
+  const float* a[COLRED_MAX]; long long lda[COLRED_MAX];
+  const float* x[COLRED_MAX]; long long ldx[COLRED_MAX];
+  const float* mean[COLRED_MAX]; const float* rstd[COLRED_MAX];
+  float* out0[COLRED_MAX]; float* out1[COLRED_MAX];
+  int cols[COLRED_MAX]; int accumulate[COLRED_MAX];
   int rows;
 };
-__global__ __launch_bounds__(256) void colsum_group_kernel(const ColsumGroup g) {
-  __shared__ float sm[4][64];
+__global__ __launch_bounds__(256) void colred_group_kernel(const ColredGroup g) {
+  __shared__ float sg[4][64], sb[4][64];
   const int q = blockIdx.y;
-  const float* __restrict__ x = g.x[q];
-  const long long ldx = g.ldx[q];
   const int cols = g.cols[q];
+  if ((int)blockIdx.x * 64 >= cols) return;
+  const float* __restrict__ a = g.a[q];
+  const float* __restrict__ x = g.x[q];
+  const long long lda = g.lda[q], ldx = g.ldx[q];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  if (blockIdx.x * 64 >= cols) return;
-  float a = 0.0f;
-  if (c < cols)
-    for (int r = grp; r < g.rows; r += 4) a += x[(long long)r * ldx + c];
-  sm[grp][lane] = a;
+  float ag = 0.0f, ab = 0.0f;
+  if (c < cols) {
+    if (x) {
+      const float* __restrict__ mean = g.mean[q];
+      const float* __restrict__ rstd = g.rstd[q];
+      for (int r = grp; r < g.rows; r += 4) {
+        const float d = a[(long long)r * lda + c];
+        ag += d * (x[(long long)r * ldx + c] - mean[r]) * rstd[r];
+        ab += d;
+      }
+    } else {
+      for (int r = grp; r < g.rows; r += 4) ag += a[(long long)r * lda + c];
+    }
+  }
+  sg[grp][lane] = ag;
+  sb[grp][lane] = ab;
   __syncthreads();
   if (grp == 0 && c < cols) {
-    const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-    float* out = g.out[q];
-    out[c] = g.accumulate[q] ? out[c] + v : v;
+    const float v = (sg[0][lane] + sg[1][lane]) + (sg[2][lane] + sg[3][lane]);
+    float* o0 = g.out0[q];
+    o0[c] = g.accumulate[q] ? o0[c] + v : v;
+    if (x) {
+      const float w = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+      float* o1 = g.out1[q];
+      o1[c] = g.accumulate[q] ? o1[c] + w : w;
+    }
   }
 }
 
@@ -257,9 +282,11 @@ extern "C" int mcl_layernorm_bwd_ws(const float* dy, int64_t lddy, const float* 
                                     int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate_params, int32_t rows,
                                     int32_t cols, float* workspace, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || cols <= 0) return MCL_EINVAL;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || (!dgamma != !dbeta) || rows <= 0 || cols <= 0) return MCL_EINVAL;
   hipStream_t st = mcl_stream(stream);
-  if (workspace && rows > 1024) {
+  if (!dgamma) {
+    // (dx only: the parameter gradients are part of a grouped column-reduction launch, mcl_colred_group)
+  } else if (workspace && rows > 1024) {
     const int nch = (rows + RCHUNK - 1) / RCHUNK;
     hipLaunchKernelGGL(colred_chunk_kernel<true>, dim3((cols + 63) / 64, nch), dim3(256), 0, st, dy, (long long)lddy, x,
                        (long long)ldx, mean, rstd, workspace, rows, cols);
@@ -300,20 +327,25 @@ extern "C" int mcl_colsum_ws(const float* x, int64_t ldx, float* out, int32_t ro
   return MCL_OK;
 }
 
-extern "C" int mcl_colsum_group(int32_t n, const float* const* x, const int64_t* ldx, float* const* out, const int32_t* cols,
-                                const int32_t* accumulate, int32_t rows, mcl_stream_t stream) {
+extern "C" int mcl_colred_group(int32_t n, const float* const* a, const int64_t* lda, const float* const* x, const int64_t* ldx,
+                                const float* const* mean, const float* const* rstd, float* const* out0, float* const* out1,
+                                const int32_t* cols, const int32_t* accumulate, int32_t rows, mcl_stream_t stream) {
   MCL_CLEAR_ERROR();
-  if (n <= 0 || n > 4 || !x || !ldx || !out || !cols || !accumulate || rows <= 0 || rows > 1024) return MCL_EINVAL;
-  ColsumGroup g;
+  if (n <= 0 || n > COLRED_MAX || !a || !lda || !x || !ldx || !mean || !rstd || !out0 || !out1 || !cols || !accumulate || rows <= 0 ||
+      rows > 1024)
+    return MCL_EINVAL;
+  ColredGroup g;
   int maxc = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < COLRED_MAX; ++i) {
     const int j = i < n ? i : 0;
-    if (!x[j] || !out[j] || cols[j] <= 0) return MCL_EINVAL;
-    g.x[i] = x[j]; g.ldx[i] = ldx[j]; g.out[i] = out[j]; g.cols[i] = cols[j]; g.accumulate[i] = accumulate[j];
+    if (!a[j] || !out0[j] || cols[j] <= 0) return MCL_EINVAL;
+    if (x[j] && (!mean[j] || !rstd[j] || !out1[j])) return MCL_EINVAL;
+    g.a[i] = a[j]; g.lda[i] = lda[j]; g.x[i] = x[j]; g.ldx[i] = ldx[j]; g.mean[i] = mean[j]; g.rstd[i] = rstd[j];
+    g.out0[i] = out0[j]; g.out1[i] = out1[j]; g.cols[i] = cols[j]; g.accumulate[i] = accumulate[j];
     if (i < n && cols[j] > maxc) maxc = cols[j];
   }
   g.rows = rows;
-  hipLaunchKernelGGL(colsum_group_kernel, dim3((maxc + 63) / 64, n), dim3(256), 0, mcl_stream(stream), g);
+  hipLaunchKernelGGL(colred_group_kernel, dim3((maxc + 63) / 64, n), dim3(256), 0, mcl_stream(stream), g);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
 }

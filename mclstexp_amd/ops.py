@@ -218,28 +218,43 @@ def colsum(x: Tensor, param: Optional[Tensor] = None) -> Optional[Tensor]:
     return out
 
 
-def colsum_group(items):
-    """``items``: up to four (x, bias Parameter or None) pairs over the same rows -> one launch; returns the list of tensors for
-    autograd (None where the sums went straight into the parameter's .grad)."""
-    n = len(items)
-    xs = [_rowmajor(x, "x") for x, _ in items]
-    rows = xs[0].shape[0]
-    outs, ptrs, acc = [], [], []
-    for x, q in zip(xs, (q for _, q in items)):
+def colred_group(sums, norms=()):
+    """One launch for a layer's column reductions.  ``sums``: (x, bias Parameter or None) pairs -> bias gradients;
+    ``norms``: (dy, x, mean, rstd, (weight, bias) Parameters) -> LayerNorm parameter gradients.  Returns (list of bias-gradient
+    tensors, list of (dgamma, dbeta)) for autograd -- None where the sums went straight into the parameters' .grad."""
+    a, lda, xs, ldx, mean, rstd, o0, o1, cols, acc = ([] for _ in range(10))
+    out_s, out_n = [], []
+    rows = None
+    for x, q in sums:
+        x = _rowmajor(x, "x")
+        rows = x.shape[0] if rows is None else rows
         assert x.shape[0] == rows
-        if q is not None and q.shape == (x.shape[1],) and _direct_grad_ok(q):
-            outs.append(None)
-            ptrs.append(q.grad.data_ptr())
-            acc.append(1)
+        direct = q is not None and q.shape == (x.shape[1],) and _direct_grad_ok(q)
+        t = q.grad if direct else torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+        out_s.append(None if direct else t)
+        a.append(x.data_ptr()); lda.append(x.stride(0)); xs.append(None); ldx.append(0); mean.append(None); rstd.append(None)
+        o0.append(t.data_ptr()); o1.append(None); cols.append(x.shape[1]); acc.append(int(direct))
+    for dy, x, mu, rs, params in norms:
+        dy, x = _rowmajor(dy, "dy"), _rowmajor(x, "x")
+        rows = x.shape[0] if rows is None else rows
+        assert x.shape[0] == rows and dy.shape == x.shape
+        n = x.shape[1]
+        direct = (params is not None and params[0].shape == (n,) and params[1].shape == (n,)
+                  and _direct_grad_ok(params[0]) and _direct_grad_ok(params[1]))
+        if direct:
+            dg, db = params[0].grad, params[1].grad
         else:
-            t = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
-            outs.append(t)
-            ptrs.append(t.data_ptr())
-            acc.append(0)
-    check(_lib.lib().mcl_colsum_group(n, (C.c_void_p * n)(*[x.data_ptr() for x in xs]), (C.c_int64 * n)(*[x.stride(0) for x in xs]),
-                                      (C.c_void_p * n)(*ptrs), (C.c_int32 * n)(*[x.shape[1] for x in xs]), (C.c_int32 * n)(*acc),
-                                      rows, _stream()), "mcl_colsum_group")
-    return outs
+            dg = torch.empty((n,), device=x.device, dtype=torch.float32)
+            db = torch.empty((n,), device=x.device, dtype=torch.float32)
+        out_n.append((None, None) if direct else (dg, db))
+        a.append(dy.data_ptr()); lda.append(dy.stride(0)); xs.append(x.data_ptr()); ldx.append(x.stride(0))
+        mean.append(mu.data_ptr()); rstd.append(rs.data_ptr())
+        o0.append(dg.data_ptr()); o1.append(db.data_ptr()); cols.append(n); acc.append(int(direct))
+    n = len(a)
+    vp, i64, i32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+    check(_lib.lib().mcl_colred_group(n, vp(*a), i64(*lda), vp(*xs), i64(*ldx), vp(*mean), vp(*rstd), vp(*o0), vp(*o1), i32(*cols),
+                                      i32(*acc), rows, _stream()), "mcl_colred_group")
+    return out_s, out_n
 
 
 def _rowred_ws(rows: int, cols: int, device) -> Optional[Tensor]:
@@ -263,13 +278,21 @@ def layernorm_fwd(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = LN_EPS) -
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor,
-                  dx_add: Optional[Tensor] = None, params: Optional[Tuple[Tensor, Tensor]] = None
+                  dx_add: Optional[Tensor] = None, params: Optional[Tuple[Tensor, Tensor]] = None, dx_only: bool = False
                   ) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
     """``params`` = (weight, bias) Parameters: when both own a dense fp32 .grad, dgamma / dbeta are added straight into them
-    and (dx, None, None) is returned."""
+    and (dx, None, None) is returned.  ``dx_only``: the parameter gradients are left to a grouped launch (colred_group)."""
     dy, x = _rowmajor(dy, "dy"), _rowmajor(x, "x")
     rows, cols = x.shape
     dx = torch.empty((rows, cols), device=x.device, dtype=torch.float32)
+    if dx_only:
+        if dx_add is not None:
+            dx_add = _rowmajor(dx_add, "dx_add")
+        check(_lib.lib().mcl_layernorm_bwd_ws(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), _p(dx_add),
+                                              dx_add.stride(0) if dx_add is not None else 0, dx.data_ptr(), cols, None, None, 0,
+                                              rows, cols, None, _stream()), "mcl_layernorm_bwd")
+        return dx, None, None
     direct = (params is not None and params[0].shape == (cols,) and params[1].shape == (cols,)
               and _direct_grad_ok(params[0]) and _direct_grad_ok(params[1]))
     if direct:
@@ -433,17 +456,17 @@ class AttnBlockFn(torch.autograd.Function):
         if (GROUP_LAYER_GRADS and _mode_of(ctx.compute) == COMPUTE_F32 and rows <= 1024
                 and all(_lib.lib().mcl_gemm_auto_ksplit(w.shape[0], w.shape[1], rows, 1) == 1 for w in (wqkv, wo, w1, w2))):
             # The spot branch (rows = one batch of spots): the data-gradient chain first, then the four weight gradients as ONE
-            # grouped launch and the bias gradients as another -- 2 launches where they were 7 (K = rows <= 255: none of them
-            # is a split-K problem; each result is bit-identical to its separate launch).
+            # grouped launch and the bias + LayerNorm parameter gradients as another -- 2 launches where they were 9 (K = rows <=
+            # 255: none of them is a split-K problem; each result is bit-identical to its separate launch).
             with forced_compute(ctx.compute):
                 dx2 = _rowmajor(dx2, "dx2")
                 dpre = linear_bwd_data(dx2, w2, gelu_bwd_aux=pre)
                 du2 = linear_bwd_data(dpre, w1)
-                dx1, dg2, dbe2 = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2, params=(q_g2, q_be2))
+                dx1, _, _ = layernorm_bwd(du2, x1, g2, mean2, rstd2, dx_add=dx2, dx_only=True)
                 do = linear_bwd_data(dx1, wo)
                 dqkv = attention_core_bwd(do, qkv, o, P, ctx.heads, ctx.dim_head, ctx.nseq)
                 du1 = linear_bwd_data(dqkv, wqkv)
-                dx, dg1, dbe1 = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, params=(q_g1, q_be1))
+                dx, _, _ = layernorm_bwd(du1, x, g1, mean1, rstd1, dx_add=dx1, dx_only=True)
                 probs, dws = [], []
                 for dy_, x_, par in ((dx2, h, p_2), (dpre, u2, p_1), (dx1, o, p_o), (dqkv, u1, p_qkv)):
                     f, t = _wgrad_problem(_rowmajor(dy_, "dy"), x_, par, x.device)
@@ -452,7 +475,8 @@ class AttnBlockFn(torch.autograd.Function):
                 gemm_group(probs)
                 dw2, dw1, dwo, dwqkv = dws
                 items = [(dx2, q_b2), (dpre, q_b1), (dx1, q_bo)] + ([(dqkv, q_bqkv)] if q_bqkv is not None else [])
-                sums = colsum_group(items)
+                sums, ((dg2, dbe2), (dg1, dbe1)) = colred_group(items, [(du2, x1, mean2, rstd2, (q_g2, q_be2)),
+                                                                        (du1, x, mean1, rstd1, (q_g1, q_be1))])
                 db2, db1, dbo = sums[:3]
                 dbqkv = sums[3] if q_bqkv is not None else None
             return dx, dg1, dbe1, dwqkv, dwo, dbo, dg2, dbe2, dw1, db1, dw2, db2, None, None, dbqkv, None, None, None
