@@ -16,5 +16,7 @@ cp gpurun_out/head_overlap_modes.txt profiles/${R}_overlap_modes.txt
 cp gpurun_out/head_pmc_hbm_traffic.txt profiles/${R}_pmc_hbm_traffic.txt
 cp gpurun_out/head_spot.json profiles/${R}_spot_branch.json
 cp gpurun_out/head_gemm.jsonl profiles/${R}_gemm_bf16_microbench.jsonl
+cp gpurun_out/head_proj_head.jsonl profiles/${R}_proj_head_microbench.jsonl
+cp gpurun_out/head_step_stamps.txt profiles/${R}_step_stamps.txt
 cp gpurun_out/head_kernel_traffic.json profiles/kernel_traffic.json
 ls -la profiles/${R}_* | wc -l

@@ -26,6 +26,10 @@ python tools/bench_infonce.py --unfused > gpurun_out/head_infonce.jsonl 2>/dev/n
 python tools/bench_dense_layer.py --json gpurun_out/head_dense.jsonl > /dev/null 2>&1
 python tools/bench_gemm_bf16.py > gpurun_out/head_gemm.jsonl 2>/dev/null
 python tools/bench_spot_path.py > gpurun_out/head_spot.json 2>/dev/null
+MCL_FUSED_HEAD=0 MCL_GROUP_LAYER_GRADS=0 python tools/bench_spot_path.py >> gpurun_out/head_spot.json 2>/dev/null
+MCL_GEMM_SPLITK_MERGE=1 python tools/bench_spot_path.py >> gpurun_out/head_spot.json 2>/dev/null
+python tools/bench_proj_head.py > gpurun_out/head_proj_head.jsonl 2>/dev/null
+MCL_STAMPS=1 python tools/step_stamps.py --steps 30 > gpurun_out/head_step_stamps.txt 2>/dev/null
 MCL_FORCE_DIST=1 python bench.py --steps 100 --warmup 20 --no_cpu_baseline --profile_steps 0 > gpurun_out/head_bench_dp_size1.json 2>/dev/null
 MCL_FORCE_DIST=1 MCL_GRAD_WIRE=bf16 MCL_GRAD_BUCKETS=4 python bench.py --steps 60 --warmup 15 --no_cpu_baseline --profile_steps 0 > gpurun_out/head_bench_dp_size1_bf16wire.json 2>/dev/null
 # per-layer kernel durations of one step (serial trace)
