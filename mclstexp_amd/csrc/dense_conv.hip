@@ -1019,23 +1019,28 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
 
 // Weight gradient of conv0:  dW[co][ky][kx][c] (+)= sum_p dy[p][co] * x[n, 2 oy - 3 + ky, 2 ox - 3 + kx, c]  (the
 // channels-last parameter's .grad).  GEMM M = 64 (co), N = 7 x 24 (k, as in the forward), K = pixels.  Same
-// tiles and input slab as the forward; dy is staged TRANSPOSED ([co][pixel]) so that an A fragment (8 consecutive pixels
-// of one channel) is one ds_read_b128; a B fragment (8 consecutive pixels of one k column) is 8 strided 2-byte reads of
-// the slab (12 bytes apart).  Wave w owns co tile w & 1 and k tiles 3 (w >> 1) .. + 2; accumulators persist over the
+// tiles and input slab as the forward; the dy tile lies in LDS as in memory ([pixel][co], 16-byte stores) and an A fragment
+// (8 consecutive pixels of one channel) is two transposing reads (round 6; the [co][pixel] tile of rounds 1-5 took 56 two-byte
+// LDS stores per thread and tile, and its staging loops waited for every 16-byte load alone: 148 -> 108 us at 128 x 224^2);
+// a B fragment (8 consecutive pixels of one k column) is 8 strided 2-byte reads of the slab (12 bytes apart).  Wave w owns co tile w & 1 and k tiles 3 (w >> 1) .. + 2; accumulators persist over the
 // workgroup's tiles.  Each output row of the tile is padded to a multiple of 16 pixels in the transposed dy tile (zero
 // columns: a 16-pixel k-step never straddles output rows, and OW = 56 -- 112-pixel her2st patches -- works).
 // The workgroup's fp32 partial (64 x 7 x 21) goes to its workspace slot (fixed-order merge launch: deterministic).
 __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
                                                            const bf16_t* __restrict__ dy, float* __restrict__ dW,
-                                                           int ntile, float* __restrict__ wpart) {
+                                                           int ntile, float* __restrict__ wpart, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int OH = H >> 1, OW = W >> 1;
   const int PW = (W + 6) * 3 + 8;
   const int OWp = (OW + 15) & ~15;
-  const int npix = 2 * OW, PP = 2 * OWp + 8;
+  const int npix = 2 * OW;
   bf16_t* slab = reinterpret_cast<bf16_t*>(lds);
   const int slab_bytes = (9 * PW * 2 + 15) & ~15;
-  bf16_t* dyT = reinterpret_cast<bf16_t*>(lds + slab_bytes);                 // [64][PP]
+  // dy tile as it lies in memory: [2 * OWp padded pixels][64 co], 128-byte rows, 16-byte chunk c of row r at physical chunk
+  // c ^ (((r >> 1) & 1) << 2) (the four rows of a transposing read then cover all 64 banks).  A fragments -- 8 consecutive pixels
+  // of one channel -- are two ds_read_b64_tr_b16; the former [co][pixel] tile cost 56 two-byte LDS stores per thread and tile.
+  unsigned char* dyt = lds + slab_bytes;
+  typedef short v4s __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int mt = wave & 1, kt0 = (wave >> 1) * 3;
@@ -1054,35 +1059,57 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // the pad columns of the transposed dy tile stay zero for every tile
-  for (int i = tid; i < (C0_OUT * PP * 2) / 16; i += 256)
-    reinterpret_cast<uint4*>(lds + slab_bytes)[i] = make_uint4(0u, 0u, 0u, 0u);
+  // the pad columns of the transposed dy tile and the pads of the input slab stay zero for every tile: zeroed once
+  for (int i = tid; i < (slab_bytes + 2 * OWp * 128) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+  // this lane's transposing-read offset inside the dy tile for tile row 0 (16-lane group: lane i supplies row i >> 2, 8-byte
+  // piece i & 3 of the group's 16 channels)
+  const int i16 = lane & 15, q4 = i16 >> 2;
+  const int lch = (mt * 32 + 16 * ((lane >> 4) & 1)) / 8 + ((i16 & 3) >> 1);
+  const unsigned a_off = (unsigned)(q4 * 128 + ((lch ^ (((q4 >> 1) & 1) << 2)) << 4) + (i16 & 1) * 8);
+  // A tile's dy rows (npix * 8 16-byte chunks: 7 per thread at 224^2) and input rows (9 * cpr chunks: 3 per thread) are requested
+  // together, unconditionally, into registers at the top of the tile.  (Keeping them in flight ACROSS the MFMA loop was tried:
+  // the kernel then sits at its 256-register cap and the compiler parks each loaded chunk in an AGPR behind a vmcnt(0).)
+  constexpr int NDY = 8, NX = 4;                         // chunks per thread (W <= 256)
+  const int cpr = (W * 6) >> 4;
+  u32x4 rdy[NDY];
+  uint4 rx[NX];
+  unsigned xvalid = 0;                                   // bit u: rx[u] is a row inside the image
+  // (every load is unconditional, from a clamped address: a load inside a branch is followed by the compiler's vmcnt(0) at the
+  //  join, which serialises the tile's loads -- what the former staging loops did)
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int n = tile / (OH >> 1), oy0 = (tile % (OH >> 1)) * 2;
-    __syncthreads();
-    for (int i = tid; i < slab_bytes / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
-    // dy tile, transposed: chunk c = (pixel, 8 channels)
+    // all of the tile's loads in flight at once (registers: not live in the loop)
     const bf16_t* dyo = dy + ((long long)(n * OH + oy0) * OW) * C0_OUT;
-    for (int c = tid; c < npix * 8; c += 256) {
-      const int px = c >> 3, c8 = c & 7;
-      const int pc = px < OW ? px : px - OW + OWp;            // column in the padded [2][OWp] pixel layout
-      const uint4 v = reinterpret_cast<const uint4*>(dyo)[c];
-      const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        dyT[(c8 * 8 + 2 * i) * PP + pc] = (bf16_t)(wv[i] & 0xFFFFu);
-        dyT[(c8 * 8 + 2 * i + 1) * PP + pc] = (bf16_t)(wv[i] >> 16);
-      }
-    }
-    __syncthreads();
-    const int cpr = (W * 6) >> 4;
-    for (int c = tid; c < 9 * cpr; c += 256) {
+    for (int u = 0; u < NDY; ++u) rdy[u] = reinterpret_cast<const u32x4*>(dyo)[min(tid + 256 * u, npix * 8 - 1)];
+    xvalid = 0;
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int c = min(tid + 256 * u, 9 * cpr - 1);
       const int r = c / cpr, cc = c % cpr;
       const int iy = 2 * oy0 - 3 + r;
-      if (iy >= 0 && iy < H) {
-        const uint4 v = *reinterpret_cast<const uint4*>(x + ((long long)(n * H + iy) * W) * 3 + cc * 8);
-        bf16_t* d = slab + r * PW + 9 + cc * 8;
-        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+      xvalid |= (iy >= 0 && iy < H) ? (1u << u) : 0u;
+      rx[u] = *reinterpret_cast<const uint4*>(x + ((long long)(n * H + min(max(iy, 0), H - 1)) * W) * 3 + cc * 8);
+    }
+    __syncthreads();                                     // the previous tile's loop is done with LDS
+    // dy tile, transposed: chunk c = (pixel, 8 channels)
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int c = tid + 256 * u;
+      if (c < npix * 8 && !(dbg & 1)) {
+        const int px = c >> 3, c8 = c & 7;
+        const int pc = px < OW ? px : px - OW + OWp;            // row in the padded [2][OWp] pixel layout
+        *reinterpret_cast<u32x4*>(dyt + pc * 128 + ((c8 ^ (((pc >> 1) & 1) << 2)) << 4)) = rdy[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int c = tid + 256 * u;
+      if (c < 9 * cpr && !(dbg & 2)) {
+        const int r = c / cpr, cc = c % cpr;
+        bf16_t* d = slab + r * PW + 9 + cc * 8;          // odd element offset: 2-byte stores
+        const bool ok = (xvalid >> u) & 1u;              // (a row outside the image: zeros)
+        const unsigned wv[4] = {ok ? rx[u].x : 0u, ok ? rx[u].y : 0u, ok ? rx[u].z : 0u, ok ? rx[u].w : 0u};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           d[2 * i] = (bf16_t)(wv[i] & 0xFFFFu);
@@ -1092,9 +1119,14 @@ __global__ __launch_bounds__(256, 2) void conv0_wrw_kernel(const bf16_t* __restr
     }
     __syncthreads();
 
-    for (int p0 = 0; p0 < 2 * OWp; p0 += 16) {           // k-step: (padded) pixels p0 .. p0 + 15 of one output row
+    for (int p0 = 0; p0 < 2 * OWp && !(dbg & 4); p0 += 16) {           // k-step: (padded) pixels p0 .. p0 + 15 of one output row
       const int rr = p0 / OWp, ox0 = p0 - rr * OWp;
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dyT + (mt * 32 + l31) * PP + p0 + 8 * h);
+      const unsigned char* ap = dyt + (p0 + 8 * h) * 128 + a_off;
+      const v4s alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(ap));
+      const v4s ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(ap + 4 * 128));
+      bf16x8 a;
+      a[0] = alo[0]; a[1] = alo[1]; a[2] = alo[2]; a[3] = alo[3];
+      a[4] = ahi[0]; a[5] = ahi[1]; a[6] = ahi[2]; a[7] = ahi[3];
       const bf16_t* brow = slab + (2 * rr) * PW + 6 * (ox0 + 8 * h);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
@@ -1184,7 +1216,7 @@ extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, con
   const int OH = H / 2, OW = W / 2, OWp = (OW + 15) & ~15;
   const int ntile = N * (OH / 2);
   const int PW = (W + 6) * 3 + 8;
-  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + (size_t)C0_OUT * (2 * OWp + 8) * 2;
+  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + (size_t)2 * OWp * 128;
   static mcl_device_once attr_once;
   if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_wrw_kernel),
@@ -1192,8 +1224,10 @@ extern "C" int mcl_conv0_wrw(const void* x, int32_t N, int32_t H, int32_t W, con
   }
   hipStream_t st = mcl_stream(stream);
   const int grid = conv0_wrw_grid(ntile);
+  // timing ablations for tools/bench_stem.py (results invalid): 1 no dy tile, 2 no input slab, 4 no MFMA loop
+  static const int dbg = getenv("MCL_CONV0_WRW_DBG") ? atoi(getenv("MCL_CONV0_WRW_DBG")) : 0;
   hipLaunchKernelGGL(conv0_wrw_kernel, dim3(grid), dim3(256), lds_bytes, st, (const bf16_t*)x, N, H, W,
-                     (const bf16_t*)dy, dW, ntile, workspace);
+                     (const bf16_t*)dy, dW, ntile, workspace, dbg);
   mcl_launch_wrw_merge(workspace, grid, (long long)C0_OUT * C0_K * 21, dW, accumulate_w, st);
   MCL_CHECK_LAUNCH();
   return MCL_OK;
