@@ -98,6 +98,14 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
       m[i] = -INFINITY;
       am[i] = 0;
     }
+    // the nine taps: loaded unconditionally from clamped coordinates (all in flight together; a load inside the bounds branch
+    // is followed by a vmcnt(0) at the join -- nine dependent round trips per output chunk), a tap outside the map is skipped
+    uint4 tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = min(max(2 * oy - 1 + t / 3, 0), H - 1), ix = min(max(2 * ox - 1 + t % 3, 0), W - 1);
+      tap[t] = *reinterpret_cast<const uint4*>(x + ((((long long)n * H + iy) * W + ix) * C8 + c8) * 8);
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const bf16_t* __res
         const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
           float v[8];
-          unpack8(*reinterpret_cast<const uint4*>(x + ((((long long)n * H + iy) * W + ix) * C8 + c8) * 8), v);
+          unpack8(tap[ky * 3 + kx], v);
           if (BN) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.0f);
@@ -140,24 +148,85 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const unsigned char
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
-    // windows oy with 2*oy-1 <= iy <= 2*oy+1  <=>  iy/2 <= oy <= (iy+1)/2   (iy >= 0)
-    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
-      if (oy >= OH) continue;
-      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-        if (ox >= OW) continue;
-        const long long oq = ((((long long)n * OH + oy) * OW + ox) * C8 + c8) * 8;
-        const uint2 pk = *reinterpret_cast<const uint2*>(idx + oq);
-        const unsigned me = (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));   // my position in that window
-        float gv[8];
-        unpack8(*reinterpret_cast<const uint4*>(dy + (((long long)n * OH + oy) * OW + ox) * lddy + c8 * 8), gv);
+    // windows oy with 2*oy-1 <= iy <= 2*oy+1  <=>  iy/2 <= oy <= (iy+1)/2   (iy >= 0): one window per axis for an even
+    // coordinate, two for an odd one.  All four candidate windows are loaded unconditionally from clamped addresses (a load
+    // inside a branch is followed by a vmcnt(0) at the join: four dependent round trips per output chunk); a window that does
+    // not exist gets the position code 255, which no recorded arg-max equals.  Same order of additions as the loop form.
+    uint2 pk[4];
+    uint4 g[4];
+    unsigned me[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (((pk.x >> (8 * i)) & 0xFFu) == me) acc[i] += gv[i];
-          if (((pk.y >> (8 * i)) & 0xFFu) == me) acc[4 + i] += gv[4 + i];
-        }
+    for (int w = 0; w < 4; ++w) {
+      const int ay = w >> 1, ax = w & 1;
+      const int oy = iy / 2 + ay, ox = ix / 2 + ax;
+      const bool valid = (ay == 0 || (iy & 1)) && (ax == 0 || (ix & 1)) && oy < OH && ox < OW;
+      const int oyc = min(oy, OH - 1), oxc = min(ox, OW - 1);
+      const long long op = ((long long)n * OH + oyc) * OW + oxc;
+      pk[w] = *reinterpret_cast<const uint2*>(idx + (op * C8 + c8) * 8);
+      g[w] = *reinterpret_cast<const uint4*>(dy + op * lddy + c8 * 8);
+      me[w] = valid ? (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1))) : 255u;   // my position in that window
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float gv[8];
+      unpack8(g[w], gv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (((pk[w].x >> (8 * i)) & 0xFFu) == me[w]) acc[i] += gv[i];
+        if (((pk[w].y >> (8 * i)) & 0xFFu) == me[w]) acc[4 + i] += gv[4 + i];
       }
     }
     *reinterpret_cast<uint4*>(dx + q * 8) = pack8(acc);
+  }
+}
+
+// The same for even H and W, one thread per 2 x 2 block of input pixels (x 8 channels): the four pixels' windows are the SAME
+// four pooled pixels (a + {0,1}, b + {0,1}), so every recorded arg-max byte and every dy chunk is loaded once per block instead
+// of once per pixel that might own it (2.25 window loads per pixel -> 1: the one-pixel form moves 9 TB/s through the texture
+// path for 0.3 GB of HBM traffic).  Per output the additions run in the window order of the form above: bit-identical.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_quad_kernel(const unsigned char* __restrict__ idx,
+                                                                  const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                                  int N, int H, int W, int OH, int OW, int C8, long long lddy) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const long long total = (long long)N * H2 * W2 * C8;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
+    const int c8 = (int)(q % C8);
+    const long long p = q / C8;
+    const int b = (int)(p % W2), a = (int)((p / W2) % H2), n = (int)(p / ((long long)W2 * H2));
+    uint2 pk[4];
+    uint4 g[4];
+    bool valid[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                          // unconditional loads from clamped addresses
+      const int oy = a + (w >> 1), ox = b + (w & 1);
+      valid[w] = oy < OH && ox < OW;
+      const long long op = ((long long)n * OH + min(oy, OH - 1)) * OW + min(ox, OW - 1);
+      pk[w] = *reinterpret_cast<const uint2*>(idx + (op * C8 + c8) * 8);
+      g[w] = *reinterpret_cast<const uint4*>(dy + op * lddy + c8 * 8);
+    }
+    float gv[4][8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) unpack8(g[w], gv[w]);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {                          // output pixel (2a + oyy, 2b + oxx)
+      const int oyy = o >> 1, oxx = o & 1;
+      float acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int ay = w >> 1, ax = w & 1;
+        if (ay > oyy || ax > oxx) continue;                // (an even coordinate lies in one window along its axis)
+        const unsigned me = valid[w] ? (unsigned)((oyy - 2 * ay + 1) * 3 + (oxx - 2 * ax + 1)) : 255u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (((pk[w].x >> (8 * i)) & 0xFFu) == me) acc[i] += gv[w][i];
+          if (((pk[w].y >> (8 * i)) & 0xFFu) == me) acc[4 + i] += gv[w][4 + i];
+        }
+      }
+      const long long ip = ((long long)n * H + 2 * a + oyy) * W + 2 * b + oxx;
+      *reinterpret_cast<uint4*>(dx + (ip * C8 + c8) * 8) = pack8(acc);
+    }
   }
 }
 
@@ -226,6 +295,12 @@ extern "C" int mcl_maxpool3s2_nhwc_bf16_bwd_ld(const void* idx, const void* dy, 
   if ((C % 8) || (lddy % 8)) return MCL_EUNSUPPORTED;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   const long long total = (long long)N * H * W * (C / 8);
+  if (!(H & 1) && !(W & 1)) {
+    hipLaunchKernelGGL(maxpool3s2_bwd_quad_kernel, dim3(blocks_for(total / 4)), dim3(256), 0, mcl_stream(stream),
+                       (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8, (long long)lddy);
+    MCL_CHECK_LAUNCH();
+    return MCL_OK;
+  }
   hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, mcl_stream(stream),
                      (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, OH, OW, C / 8, (long long)lddy);
   MCL_CHECK_LAUNCH();

@@ -53,6 +53,18 @@ def main():
                                                                          mean.data_ptr(), var.data_ptr(), rstd.data_ptr(), st()))), 2)
     out["conv0_wrw_us"] = round(timed(lambda: _lib.check(L.mcl_conv0_wrw(x.data_ptr(), B, H, H, dy.data_ptr(), wsw.data_ptr(), dW.data_ptr(), 1,
                                                                          st()))), 2)
+    OH = H // 4
+    yp = torch.empty(B, OH, OH, 64, device=dev, dtype=torch.bfloat16)
+    idx = torch.empty(B, OH, OH, 64, device=dev, dtype=torch.uint8)
+    _lib.check(L.mcl_maxpool3s2_nhwc_bf16_fwd(y.data_ptr(), yp.data_ptr(), idx.data_ptr(), B, H // 2, H // 2, 64, st()))
+    ga, be_ = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    out["bn_act_maxpool_fwd_us"] = round(timed(lambda: _lib.check(L.mcl_bn_act_maxpool_fwd(y.data_ptr(), B, H // 2, H // 2, 64, ga.data_ptr(), be_.data_ptr(),
+                                                                                          mean.data_ptr(), rstd.data_ptr(), yp.data_ptr(), idx.data_ptr(),
+                                                                                          st()))), 2)
+    gbuf = torch.randn(B, OH, OH, 256, device=dev).bfloat16()          # dy = the first 64 channels of the block's gradient buffer
+    dxp = torch.empty(B, H // 2, H // 2, 64, device=dev, dtype=torch.bfloat16)
+    out["maxpool_bwd_us"] = round(timed(lambda: _lib.check(L.mcl_maxpool3s2_nhwc_bf16_bwd_ld(idx.data_ptr(), gbuf.data_ptr(), 256, dxp.data_ptr(),
+                                                                                             B, H // 2, H // 2, 64, st()))), 2)
     out["MCL_CONV0_WRW_DBG"] = os.environ.get("MCL_CONV0_WRW_DBG", "0")
     print(json.dumps(out), flush=True)
 
