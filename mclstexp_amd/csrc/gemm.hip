@@ -48,23 +48,32 @@ __device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-e
 
 // Stage one (rows x BK) operand slice into regs: the operand is addressed as X[r*sr + k*sk] with
 // r in [r0, r0+64) and k in [k0, k0+BK).  KC: contiguous along k (sk == 1) else along r (sr == 1).
-// Each thread carries 8 floats.  VEC: 16-byte loads allowed.
+// Each thread carries 8 floats.  VEC: 16-byte loads allowed (host: bases and leading dimensions 16-byte aligned AND the extent
+// along the contiguous dimension a multiple of 4, so a chunk is inside the operand or outside it as a whole).
+// Every load is UNCONDITIONAL, from an address clamped into the operand; what lies outside is zeroed when the registers are
+// written to LDS (``ok``: one bit per element).  A load inside a bounds branch is followed by the compiler's vmcnt(0) at the
+// join: the four loads of a slice then waited for one another, and the prefetch of the next slice ended before the MFMAs began.
 template <bool KC, bool VEC>
-__device__ __forceinline__ void load_slice(float (&reg)[8], const float* __restrict__ X, long long sr, long long sk,
-                                           int r0, int k0, int R, int K, int tid) {
+__device__ __forceinline__ unsigned load_slice(float (&reg)[8], const float* __restrict__ X, long long sr, long long sk,
+                                               int r0, int k0, int R, int K, int tid) {
+  unsigned ok = 0;
   if (KC) {
     // 64 rows x 32 k: 8 float4 per row -> thread t: row = t/8 + 32*h, kq = (t%8)*4
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = r0 + (tid >> 3) + 32 * h;
       const int k = k0 + (tid & 7) * 4;
-      const float* p = X + (long long)r * sr + k;
-      if (VEC && r < R && k + 3 < K) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
+      const int rc = min(r, R - 1);
+      if (VEC) {
+        const float4 v = *reinterpret_cast<const float4*>(X + (long long)rc * sr + min(k, K - 4));
         reg[h * 4 + 0] = v.x; reg[h * 4 + 1] = v.y; reg[h * 4 + 2] = v.z; reg[h * 4 + 3] = v.w;
+        ok |= (r < R && k < K) ? (0xFu << (4 * h)) : 0u;
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) reg[h * 4 + i] = (r < R && k + i < K) ? p[i] : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+          reg[h * 4 + i] = X[(long long)rc * sr + min(k + i, K - 1)];
+          ok |= (r < R && k + i < K) ? (1u << (4 * h + i)) : 0u;
+        }
       }
     }
   } else {
@@ -73,34 +82,39 @@ __device__ __forceinline__ void load_slice(float (&reg)[8], const float* __restr
     for (int h = 0; h < 2; ++h) {
       const int k = k0 + (tid >> 4) + 16 * h;
       const int r = r0 + (tid & 15) * 4;
-      const float* p = X + (long long)k * sk + r;
-      if (VEC && k < K && r + 3 < R) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
+      const int kc = min(k, K - 1);
+      if (VEC) {
+        const float4 v = *reinterpret_cast<const float4*>(X + (long long)kc * sk + min(r, R - 4));
         reg[h * 4 + 0] = v.x; reg[h * 4 + 1] = v.y; reg[h * 4 + 2] = v.z; reg[h * 4 + 3] = v.w;
+        ok |= (k < K && r < R) ? (0xFu << (4 * h)) : 0u;
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) reg[h * 4 + i] = (k < K && r + i < R) ? p[i] : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+          reg[h * 4 + i] = X[(long long)kc * sk + min(r + i, R - 1)];
+          ok |= (k < K && r + i < R) ? (1u << (4 * h + i)) : 0u;
+        }
       }
     }
   }
+  return ok;
 }
 
-// Write the staged registers into the LDS slice T[k][r] (row stride LDT words).
+// Write the staged registers into the LDS slice T[k][r] (row stride LDT words); elements outside the operand as zeros.
 template <bool KC, int LDT>
-__device__ __forceinline__ void store_slice(const float (&reg)[8], float* __restrict__ T, int tid) {
+__device__ __forceinline__ void store_slice(const float (&reg)[8], unsigned ok, float* __restrict__ T, int tid) {
   if (KC) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int r = (tid >> 3) + 32 * h, k = (tid & 7) * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) T[(k + i) * LDT + r] = reg[h * 4 + i];
+      for (int i = 0; i < 4; ++i) T[(k + i) * LDT + r] = ((ok >> (4 * h + i)) & 1u) ? reg[h * 4 + i] : 0.0f;
     }
   } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = (tid >> 4) + 16 * h, r = (tid & 15) * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) T[k * LDT + r + i] = reg[h * 4 + i];
+      for (int i = 0; i < 4; ++i) T[k * LDT + r + i] = ((ok >> (4 * h + i)) & 1u) ? reg[h * 4 + i] : 0.0f;
     }
   }
 }
@@ -134,14 +148,15 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
   // PF-deep register pipeline of operand slices (PF = 1 everywhere: four slices in flight were measured on the spot path's
   // skinny problems -- 12.7 vs 12.6 us, 9.8 vs 9.6 us per launch, 212 registers against 80 -- and did not pay).
   float ra[PF][TM][8], rb[PF][TM][8];
+  unsigned oa[PF][TM], ob[PF][TM];
   const int nk = (kend - kbeg + BK - 1) / BK;
 #pragma unroll
   for (int u = 0; u < PF; ++u)
     if (u < nk) {
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + u * BK, p.M, kend, tid);
-        load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + u * BK, p.N, kend, tid);
+        oa[u][t] = load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + u * BK, p.M, kend, tid);
+        ob[u][t] = load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + u * BK, p.N, kend, tid);
       }
     }
 
@@ -156,15 +171,15 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
     if (kt >= nk) break;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      store_slice<AKC, LD>(ra[u][t], As + 64 * t, tid);
-      store_slice<BKC, LD>(rb[u][t], Bs + 64 * t, tid);
+      store_slice<AKC, LD>(ra[u][t], oa[u][t], As + 64 * t, tid);
+      store_slice<BKC, LD>(rb[u][t], ob[u][t], Bs + 64 * t, tid);
     }
     __syncthreads();
     if (kt + PF < nk) {
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + (kt + PF) * BK, p.M, kend, tid);
-        load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + (kt + PF) * BK, p.N, kend, tid);
+        oa[u][t] = load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + (kt + PF) * BK, p.M, kend, tid);
+        ob[u][t] = load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + (kt + PF) * BK, p.N, kend, tid);
       }
     }
     if (!BF16) {
@@ -323,6 +338,22 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
       float* __restrict__ C = p.C + (long long)bz * p.sCb;
       const float* __restrict__ R = p.resid ? p.resid + (long long)bz * p.sRb : nullptr;
       const float bias = p.bias ? p.bias[col] : 0.0f;
+      // The epilogue's operands (GELU' argument, residual, the C that is accumulated into) for all 16 rows of the lane, loaded
+      // up front from row-clamped addresses: inside the per-row bounds branch every one of them was followed by the compiler's
+      // vmcnt(0) -- up to 48 dependent round trips per tile, more than the product itself on the spot path's skinny problems.
+      float av[16], rv[16], cv[16];
+      if (p.flags & MCL_EPI_GELU_BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) av[r] = p.aux[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldaux + col];
+      }
+      if (R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = R[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col];
+      }
+      if (p.flags & MCL_EPI_ACCUM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cv[r] = C[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + col];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -330,9 +361,9 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
         float v = p.alpha * acc[ti][tj][r] + bias;
         if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
         if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
-        if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
-        if (R) v += R[(long long)row * p.ldr + col];
-        if (p.flags & MCL_EPI_ACCUM) v += C[(long long)row * p.ldc + col];
+        if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(av[r]);
+        if (R) v += rv[r];
+        if (p.flags & MCL_EPI_ACCUM) v += cv[r];
         C[(long long)row * p.ldc + col] = v;
       }
     }
@@ -388,15 +419,29 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmP p
     const int bz = (int)(q / MN);
     const long long e = q - (long long)bz * MN;
     const int row = (int)(e / p.N), col = (int)(e - (long long)row * p.N);
+    // (all of an element's loads issued together -- slices eight at a time from clamped indices, added in slice order -- and the
+    //  epilogue's operands before the first use: a load per loop trip or per branch is a round trip of its own)
+    float* C = p.C + (long long)bz * p.sCb + (long long)row * p.ldc + col;
+    float xa = 0.0f, xr = 0.0f, xc = 0.0f;
+    if (p.flags & MCL_EPI_GELU_BWD) xa = p.aux[(long long)row * p.ldaux + col];
+    if (p.resid) xr = p.resid[(long long)bz * p.sRb + (long long)row * p.ldr + col];
+    if (p.flags & MCL_EPI_ACCUM) xc = *C;
+    const float bias = p.bias ? p.bias[col] : 0.0f;
     float a = 0.0f;
-    for (int s = 0; s < p.ksplit; ++s) a += p.ws[((long long)s * p.batch + bz) * MN + e];
-    float v = p.alpha * a + (p.bias ? p.bias[col] : 0.0f);
+    for (int s0 = 0; s0 < p.ksplit; s0 += 8) {
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = p.ws[((long long)min(s0 + i, p.ksplit - 1) * p.batch + bz) * MN + e];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (s0 + i < p.ksplit) a += w[i];
+    }
+    float v = p.alpha * a + bias;
     if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
     if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
-    if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
-    if (p.resid) v += p.resid[(long long)bz * p.sRb + (long long)row * p.ldr + col];
-    float* C = p.C + (long long)bz * p.sCb + (long long)row * p.ldc + col;
-    if (p.flags & MCL_EPI_ACCUM) v += *C;
+    if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(xa);
+    if (p.resid) v += xr;
+    if (p.flags & MCL_EPI_ACCUM) v += xc;
     *C = v;
   }
 }
@@ -477,7 +522,10 @@ static int gemm_prepare(const mcl_gemm_args* caller_args, mcl_gemm_args* a, Gemm
   p.kchunk = ksplit > 1 ? (((a->K + ksplit - 1) / ksplit + BK - 1) / BK) * BK : a->K;
   // (the k-contiguous reading is preferred when a dimension of extent-1 stride is ambiguous)
   const long long lda = akc ? a->sAm : a->sAk, ldb = bkc ? a->sBn : a->sBk;
-  vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) && (a->sAb % 4 == 0) && (a->sBb % 4 == 0);
+  // (a 16-byte chunk must lie inside an operand or outside it as a whole: the extent along the contiguous dimension -- and the
+  //  start of every split-K slice, a multiple of BK -- a multiple of 4)
+  vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) && (a->sAb % 4 == 0) && (a->sBb % 4 == 0) &&
+        ((akc ? a->K : a->M) % 4 == 0) && ((bkc ? a->K : a->N) % 4 == 0);
   return MCL_OK;
 }
 
