@@ -31,42 +31,54 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // One BK-slice of a K-contiguous 256-row weight (row stride ld, k in [k0, k0 + 32) clipped to kend) -> 8 float4 per thread.
+// Loads are unconditional, from addresses clamped into the row (a load inside a bounds branch is followed by the compiler's
+// vmcnt(0): eight serial round trips per slice); the returned mask (4 bits per chunk) zeroes what lies past kend at the LDS store.
+// VEC: 16-byte loads (host: aligned bases / strides and D % 4 == 0, so a chunk is inside [0, kend) or outside as a whole).
 template <bool VEC>
-__device__ __forceinline__ void load_w_kc(float4 (&r)[8], const float* __restrict__ W, long long ld, int k0, int kend, int tid) {
+__device__ __forceinline__ unsigned load_w_kc(float4 (&r)[8], const float* __restrict__ W, long long ld, int k0, int kend, int tid) {
   const int k = k0 + (tid & 7) * 4;
+  unsigned ok = 0;
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
-    const float* q = W + (long long)((tid >> 3) + 32 * h) * ld + k;
-    if (VEC && k + 3 < kend) {
-      r[h] = *reinterpret_cast<const float4*>(q);
+    const float* q = W + (long long)((tid >> 3) + 32 * h) * ld;
+    if (VEC) {
+      r[h] = *reinterpret_cast<const float4*>(q + min(k, kend - 4));
+      ok |= (k < kend ? 0xFu : 0u) << (4 * h);
     } else {
-      r[h].x = k + 0 < kend ? q[0] : 0.0f;
-      r[h].y = k + 1 < kend ? q[1] : 0.0f;
-      r[h].z = k + 2 < kend ? q[2] : 0.0f;
-      r[h].w = k + 3 < kend ? q[3] : 0.0f;
+      r[h].x = q[min(k + 0, kend - 1)];
+      r[h].y = q[min(k + 1, kend - 1)];
+      r[h].z = q[min(k + 2, kend - 1)];
+      r[h].w = q[min(k + 3, kend - 1)];
+      ok |= ((k + 0 < kend ? 1u : 0u) | (k + 1 < kend ? 2u : 0u) | (k + 2 < kend ? 4u : 0u) | (k + 3 < kend ? 8u : 0u)) << (4 * h);
     }
   }
+  return ok;
 }
-__device__ __forceinline__ void store_w_kc(const float4 (&r)[8], float* __restrict__ Ws, int tid) {
+__device__ __forceinline__ float4 mask4(float4 v, unsigned m) {
+  return make_float4((m & 1u) ? v.x : 0.0f, (m & 2u) ? v.y : 0.0f, (m & 4u) ? v.z : 0.0f, (m & 8u) ? v.w : 0.0f);
+}
+__device__ __forceinline__ void store_w_kc(const float4 (&r)[8], unsigned ok, float* __restrict__ Ws, int tid) {
 #pragma unroll
-  for (int h = 0; h < 8; ++h) *reinterpret_cast<float4*>(Ws + ((tid >> 3) + 32 * h) * LDW + (tid & 7) * 4) = r[h];
+  for (int h = 0; h < 8; ++h)
+    *reinterpret_cast<float4*>(Ws + ((tid >> 3) + 32 * h) * LDW + (tid & 7) * 4) = mask4(r[h], (ok >> (4 * h)) & 0xFu);
 }
 
-// 16 rows x 32 k of a K-contiguous activation: threads 0..127 carry one float4 each
+// 16 rows x 32 k of a K-contiguous activation: threads 0..127 carry one float4 each (bits 0-3 of the mask: valid elements)
 template <bool VEC>
-__device__ __forceinline__ float4 load_x(const float* __restrict__ X, long long ld, int m0, int M, int k0, int kend, int tid) {
-  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  const int r = m0 + (tid >> 3), k = k0 + (tid & 7) * 4;
-  if (tid < 128 && r < M) {
-    const float* q = X + (long long)r * ld + k;
-    if (VEC && k + 3 < kend) {
-      v = *reinterpret_cast<const float4*>(q);
-    } else {
-      v.x = k + 0 < kend ? q[0] : 0.0f;
-      v.y = k + 1 < kend ? q[1] : 0.0f;
-      v.z = k + 2 < kend ? q[2] : 0.0f;
-      v.w = k + 3 < kend ? q[3] : 0.0f;
-    }
+__device__ __forceinline__ float4 load_x(const float* __restrict__ X, long long ld, int m0, int M, int k0, int kend, int tid,
+                                         unsigned& ok) {
+  const int r = m0 + ((tid & 127) >> 3), k = k0 + (tid & 7) * 4;
+  const float* q = X + (long long)min(r, M - 1) * ld;
+  float4 v;
+  if (VEC) {
+    v = *reinterpret_cast<const float4*>(q + min(k, kend - 4));
+    ok = (r < M && k < kend) ? 0xFu : 0u;
+  } else {
+    v.x = q[min(k + 0, kend - 1)];
+    v.y = q[min(k + 1, kend - 1)];
+    v.z = q[min(k + 2, kend - 1)];
+    v.w = q[min(k + 3, kend - 1)];
+    ok = r < M ? ((k + 0 < kend ? 1u : 0u) | (k + 1 < kend ? 2u : 0u) | (k + 2 < kend ? 4u : 0u) | (k + 3 < kend ? 8u : 0u)) : 0u;
   }
   return v;
 }
@@ -142,24 +154,25 @@ __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   float4 rw[PD][8], rx[PD];
+  unsigned ow[PD], ox[PD];
   const int nk = (kend - kbeg + BK - 1) / BK;
 #pragma unroll
   for (int u = 0; u < PD; ++u)
-    if (u < nk) {
-      load_w_kc<VEC>(rw[u], h.wp, h.ldwp, kbeg + u * BK, kend, tid);
-      rx[u] = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + u * BK, kend, tid);
+    if (u < nk) {                          // (workgroup-uniform: a scalar branch)
+      ow[u] = load_w_kc<VEC>(rw[u], h.wp, h.ldwp, kbeg + u * BK, kend, tid);
+      rx[u] = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + u * BK, kend, tid, ox[u]);
     }
   for (int kt0 = 0; kt0 < nk; kt0 += PD) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int kt = kt0 + u;
       if (kt < nk) {
-        store_w_kc(rw[u], Ws, tid);
-        if (tid < 128) *reinterpret_cast<float4*>(Xs + (tid >> 3) * LDW + (tid & 7) * 4) = rx[u];
+        store_w_kc(rw[u], ow[u], Ws, tid);
+        if (tid < 128) *reinterpret_cast<float4*>(Xs + (tid >> 3) * LDW + (tid & 7) * 4) = mask4(rx[u], ox[u]);
         __syncthreads();
         if (kt + PD < nk) {
-          load_w_kc<VEC>(rw[u], h.wp, h.ldwp, kbeg + (kt + PD) * BK, kend, tid);
-          rx[u] = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + (kt + PD) * BK, kend, tid);
+          ow[u] = load_w_kc<VEC>(rw[u], h.wp, h.ldwp, kbeg + (kt + PD) * BK, kend, tid);
+          rx[u] = load_x<VEC>(h.x, h.ldx, m0, h.M, kbeg + (kt + PD) * BK, kend, tid, ox[u]);
         }
         mma_slice_kc(acc, Xs, LDW, Ws, wave, lane);
         __syncthreads();
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
 
   // ---- the row block's last arriver.  The second layer's first PD weight slices: requested now.
 #pragma unroll
-  for (int u = 0; u < PD; ++u) load_w_kc<VEC>(rw[u], h.wf, h.ldwf, u * BK, P, tid);
+  for (int u = 0; u < PD; ++u) ow[u] = load_w_kc<VEC>(rw[u], h.wf, h.ldwf, u * BK, P, tid);
   // p = sum of the slices in slice order + bias
   {
     const u64* part = reinterpret_cast<const u64*>(h.ws + (long long)rb * h.ks * (RB * P));
@@ -240,9 +253,9 @@ __global__ __launch_bounds__(NT) void proj_head_fwd_kernel(const HeadF h) {
 #pragma unroll
     for (int u = 0; u < PD; ++u) {
       const int kt = kt0 + u;
-      store_w_kc(rw[u], Ws, tid);
+      store_w_kc(rw[u], ow[u], Ws, tid);
       __syncthreads();                     // (first pass: also publishes T0 / T1)
-      if (kt + PD < P / BK) load_w_kc<VEC>(rw[u], h.wf, h.ldwf, (kt + PD) * BK, P, tid);
+      if (kt + PD < P / BK) ow[u] = load_w_kc<VEC>(rw[u], h.wf, h.ldwf, (kt + PD) * BK, P, tid);
       mma_slice_kc(acc, T1 + kt * BK, LDT, Ws, wave, lane);
       __syncthreads();
     }
@@ -511,7 +524,7 @@ extern "C" int mcl_proj_head_fwd(const float* x, int64_t ldx, int32_t M, int32_t
   h.kchunk = (((D + ksplit - 1) / ksplit + BK - 1) / BK) * BK;
   h.ks = (D + h.kchunk - 1) / h.kchunk;            // (slices that would start past D are not launched)
   const int nrb = (M + RB - 1) / RB;
-  const bool vec = al16(x) && al16(wp) && al16(wf) && ldx % 4 == 0 && ldwp % 4 == 0 && ldwf % 4 == 0;
+  const bool vec = al16(x) && al16(wp) && al16(wf) && ldx % 4 == 0 && ldwp % 4 == 0 && ldwf % 4 == 0 && D % 4 == 0;
   const size_t lds = FWD_LDS_FLOATS * sizeof(float);
   static bool once = false;
   if (!once) {
