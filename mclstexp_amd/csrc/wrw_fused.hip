@@ -370,13 +370,21 @@ __global__ __launch_bounds__(256) void wrw_merge_kernel(const float* __restrict_
         acc8[u].x += v[u].x; acc8[u].y += v[u].y; acc8[u].z += v[u].z; acc8[u].w += v[u].w;
       }
     }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (zz + u * MZG < ks) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p + (long long)(zz + u * MZG) * stride);
-        acc8[u].x += v0.x; acc8[u].y += v0.y; acc8[u].z += v0.z; acc8[u].w += v0.w;
-      }
-    }
+    // the remaining < 8 rounds (ALL rounds for ks < 256): the loads unconditional, from a clamped slab index, 2 / 4 / 8 of them in
+    // flight by the workgroup-uniform round count -- a load inside the per-thread bounds branch is followed by the compiler's
+    // vmcnt(0), one dependent round trip per round in a 5 us kernel that runs 124 times per step
+    const int rounds = (ks - zz + zg + MZG - 1) / MZG;    // = ceil((ks - first slab of group 0) / MZG): uniform
+    float4 v[8];
+#define MERGE_TAIL(NU)                                                                                                   \
+  {                                                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < NU; ++u)                                                                       \
+        v[u] = *reinterpret_cast<const float4*>(p + (long long)min(zz + u * MZG, ks - 1) * stride);                      \
+    _Pragma("unroll") for (int u = 0; u < NU; ++u) if (zz + u * MZG < ks) {                                              \
+      acc8[u].x += v[u].x; acc8[u].y += v[u].y; acc8[u].z += v[u].z; acc8[u].w += v[u].w;                                \
+    }                                                                                                                    \
+  }
+    if (rounds <= 2) MERGE_TAIL(2) else if (rounds <= 4) MERGE_TAIL(4) else MERGE_TAIL(8)
+#undef MERGE_TAIL
   }
   float4 a;
   a.x = ((acc8[0].x + acc8[1].x) + (acc8[2].x + acc8[3].x)) + ((acc8[4].x + acc8[5].x) + (acc8[6].x + acc8[7].x));
