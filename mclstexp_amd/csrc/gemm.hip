@@ -145,8 +145,9 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  // PF-deep register pipeline of operand slices (PF = 1 everywhere: four slices in flight were measured on the spot path's
-  // skinny problems -- 12.7 vs 12.6 us, 9.8 vs 9.6 us per launch, 212 registers against 80 -- and did not pay).
+  // PF-deep register pipeline of operand slices (PF = 1 everywhere: two / four slices in flight were measured on the spot path's
+  // skinny problems, before and after the loads were made unconditional -- spot branch 0.800-0.822 / 0.790 ms against 0.772 at
+  // PF = 1, 136-212 registers against 80 -- and did not pay).
   float ra[PF][TM][8], rb[PF][TM][8];
   unsigned oa[PF][TM], ob[PF][TM];
   const int nk = (kend - kbeg + BK - 1) / BK;
