@@ -46,11 +46,14 @@ def run(M, D, fused, ks, reps=300):
     for _ in range(20):
         g.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        g.replay()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e6
+    best = float("inf")
+    for _ in range(3):          # best of three: single measurements of these 60-100 us graphs come out 2-4 x slow now and then
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+    return best
 
 
 def main():
