@@ -156,7 +156,9 @@ int mcl_embed_scatter_rows(const int32_t* owner_idx, const float* row_grad, int6
 int mcl_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                       float* mean, float* rstd, int32_t rows, int32_t cols, float eps, mcl_stream_t stream);
 /* dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ dx_add if non-NULL: the residual branch's gradient,
- * may alias dx), g = dy*gamma.  dgamma/dbeta (cols) are OVERWRITTEN with the column sums over rows. */
+ * may alias dx), g = dy*gamma.  dgamma/dbeta (cols) are OVERWRITTEN with the column sums over rows (accumulate_params != 0:
+ * added to).  ABI 9: dgamma == dbeta == NULL computes dx alone (the parameter gradients then belong to a grouped
+ * mcl_colred_group launch).                                                                              */
 int mcl_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, const float* dx_add, int64_t ldadd, float* dx,
                       int64_t lddx, float* dgamma, float* dbeta, int32_t accumulate_params, int32_t rows, int32_t cols,
