@@ -31,13 +31,22 @@ __global__ __launch_bounds__(256) void col_lse_kernel(const float* __restrict__ 
   const int c = blockIdx.x * 64 + lane;
   float m = -INFINITY, l = 0.0f;
   if (c < C) {
-    for (int r = grp; r < R; r += 4) {
-      const float v = S[(long long)r * ld + c];
-      if (v > m) {
-        l = l * expf(m - v) + 1.0f;  // exp(-inf)=0 on the first element
-        m = v;
-      } else {
-        l += expf(v - m);
+    // eight rows' loads in flight at a time (clamped row index, the surplus skipped), consumed in the same order: one load per
+    // trip of the data-dependent loop below is one memory round trip per trip -- 32 in series at B = 128, 11 of the kernel's 12 us
+    for (int r0 = grp; r0 < R; r0 += 32) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = S[(long long)min(r0 + 4 * u, R - 1) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (r0 + 4 * u >= R) continue;
+        const float v = v8[u];
+        if (v > m) {
+          l = l * expf(m - v) + 1.0f;  // exp(-inf)=0 on the first element
+          m = v;
+        } else {
+          l += expf(v - m);
+        }
       }
     }
   }

@@ -458,6 +458,9 @@ class mclSTExp_Attention(_ContrastiveBase):
             else:                                   # MCL_SPOT_AFTER_BLOCK beyond the last block: order after everything
                 side.wait_stream(main)
             with torch.cuda.stream(side):
+                pro = getattr(self, "_spot_lane_prologue", None)
+                if pro is not None:                 # (engine.TrainStep: the step's zero_grad, off the main chain)
+                    pro()
                 spot_embeddings = self._embed_spots(batch)
             image_embeddings = self.image_projection(image_features)
             main.wait_stream(side)
