@@ -833,8 +833,15 @@ def infonce_fwd_bwd(e_spot: Tensor, e_img: Tensor, temperature: float, want_logi
                                 1.0 / (2.0 * B * temperature), dS.data_ptr(), B, _stream()), "mcl_infonce_dlogits")
     d_es = torch.empty_like(es)
     d_ei = torch.empty_like(ei)
-    gemm_raw(B, P, B, 1, dS, B, 1, 0, ei, ei.stride(0), 1, 0, d_es, P, 0)          # dE_s = dS E_i
-    gemm_raw(B, P, B, 1, dS, 1, B, 0, es, es.stride(0), 1, 0, d_ei, P, 0)          # dE_i = dS^T E_s
+    if _compute_mode == COMPUTE_F32 and (not SPLIT_K or L.mcl_gemm_auto_ksplit(B, P, B, 1) == 1):
+        # both gradient products as one launch (on the step's critical chain between loss and backward); bit-identical
+        gemm_group([dict(M=B, N=P, K=B, A=dS.data_ptr(), sAm=B, sAk=1, B=ei.data_ptr(), sBk=ei.stride(0), sBn=1,
+                         C=d_es.data_ptr(), ldc=P),                                # dE_s = dS E_i
+                    dict(M=B, N=P, K=B, A=dS.data_ptr(), sAm=1, sAk=B, B=es.data_ptr(), sBk=es.stride(0), sBn=1,
+                         C=d_ei.data_ptr(), ldc=P)])                               # dE_i = dS^T E_s
+    else:
+        gemm_raw(B, P, B, 1, dS, B, 1, 0, ei, ei.stride(0), 1, 0, d_es, P, 0)          # dE_s = dS E_i
+        gemm_raw(B, P, B, 1, dS, 1, B, 0, es, es.stride(0), 1, 0, d_ei, P, 0)          # dE_i = dS^T E_s
     return loss, d_es, d_ei, (S if want_logits else None)
 
 
