@@ -900,15 +900,52 @@ namespace {
 constexpr int C0_OUT = 64, C0_K = 7, C0_KP = 24;        // output channels, kernel size, padded (kx, c) run
 // (a kernel row is 7 * 3 chunks of 8 + one zero chunk = 22 chunks -> 11 k-steps of 16)
 
-__global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
+// Input slab of the stem kernels, filled by LDS-DMA (round 6): row r of the slab holds input row iy = 2 oy0 - 3 + r as it lies in
+// memory, element d = 3 ix + c at position C0_P0 + d of a row of C0_PW(W) elements; positions before / after the data are zero
+// (left / right padding of the convolution: zeroed once per workgroup), a row outside the image is written as zeros by the DMA
+// itself (zero-size descriptor).  The window of output pixel ox starts at position C0_P0 - 9 + 6 ox = 7 + 6 ox: ODD -- so the
+// forward reads its 24-element k-runs from the even position 6 + 6 ox and carries the weights shifted by one (k-run element j'
+// holds weight j' - 1; j' = 0, 22, 23 are zero weights): 4-byte aligned A fragments from rows that were never touched by a VALU
+// instruction.  (Rounds 1-5 staged the rows through registers at element offset 9 with 2-byte LDS stores: 24 per thread and tile,
+// behind three loads that each waited for the previous one.)
+constexpr int C0_P0 = 16;
+__host__ __device__ inline int c0_pw(int W) { return ((C0_P0 + 3 * W + 24 + 7) / 8) * 8; }   // row pitch in elements (16-byte rows)
+typedef unsigned u32x4_d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void c0_dma16(u32x4_d rsrc, unsigned voff, unsigned dst) {     // 64 lanes x 16 B -> LDS dst + 16 lane
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(rsrc), "s"(dst)
+               : "memory");
+}
+__device__ __forceinline__ u32x4_d c0_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return u32x4_d{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+}
+// Rows r = wave, wave + 4, ... of the 9-row slab of tile (n, oy0): each row W * 6 bytes = cpr 16-byte chunks, 64 per instruction
+// (lanes past the row's last chunk are switched off: they must not write into the right padding).
+__device__ __forceinline__ void c0_dma_slab(const bf16_t* __restrict__ x, int n, int oy0, int H, int W, unsigned slab_lds, int PW,
+                                            int wave, int lane) {
+  const int cpr = (W * 6) >> 4;
+  for (int r = wave; r < 9; r += 4) {
+    const int iy = 2 * oy0 - 3 + r;
+    const bool inside = iy >= 0 && iy < H;
+    const u32x4_d rs = c0_rsrc(x + ((long long)(n * H + (inside ? iy : 0)) * W) * 3, inside ? (unsigned)(W * 6) : 0u);
+    const unsigned dst = slab_lds + (unsigned)(r * PW + C0_P0) * 2u;
+    for (int c0 = 0; c0 < cpr; c0 += 64)
+      if (c0 + lane < cpr) c0_dma16(rs, (unsigned)(c0 + lane) * 16u, dst + (unsigned)c0 * 16u);
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
                                                            const bf16_t* __restrict__ Wt, bf16_t* __restrict__ y,
                                                            float2* __restrict__ partial, int ntile) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int OH = H >> 1, OW = W >> 1;
-  const int PW = (W + 6) * 3 + 8;                        // slab row pitch in elements (even)
+  const int PW = c0_pw(W);                               // slab row pitch in elements
   const int npix = 2 * OW;                               // pixels per tile
   bf16_t* slab = reinterpret_cast<bf16_t*>(lds);         // [9][PW]
-  const int slab_bytes = (9 * PW * 2 + 15) & ~15;
+  const int slab_bytes = 9 * PW * 2;
   bf16_t* ot = reinterpret_cast<bf16_t*>(lds + slab_bytes);                  // [256][64] bf16
   float* red = reinterpret_cast<float*>(lds + slab_bytes + 256 * 128);       // [4 waves][64][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -924,34 +961,23 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
       const int co = nt * 32 + l31;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = j0 + i;
-        breg[nt][s][i] = (q < 21 && j < 21) ? (short)Wt[(co * C0_K + ky) * 21 + j] : (short)0;
+        const int j = j0 + i - 1;                         // (k-run element j' = j0 + i holds weight j' - 1: see C0_P0)
+        breg[nt][s][i] = (q < 21 && j >= 0 && j < 21) ? (short)Wt[(co * C0_K + ky) * 21 + j] : (short)0;
       }
     }
   const int nmt = (npix + 31) >> 5;
+  const unsigned slab_lds = (unsigned)(size_t)((__attribute__((address_space(3))) void*)(lds));
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // the slab's padding: zeroed once; the first tile's rows requested
+  for (int i = tid; i < slab_bytes / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  if ((int)blockIdx.x < ntile)
+    c0_dma_slab(x, (int)blockIdx.x / (OH >> 1), ((int)blockIdx.x % (OH >> 1)) * 2, H, W, slab_lds, PW, wave_u, lane);
 
   for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int n = tile / (OH >> 1), oy0 = (tile % (OH >> 1)) * 2;
-    __syncthreads();                                     // previous tile's output staging is done with LDS
-    for (int i = tid; i < slab_bytes / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    // 9 input rows iy = 2*oy0 - 3 + r, each W*3 bf16 = W*6/16 chunks of 16 B; data of pixel ix sits at element 9 + 3*ix
-    const int cpr = (W * 6) >> 4;
-    for (int c = tid; c < 9 * cpr; c += 256) {
-      const int r = c / cpr, cc = c % cpr;
-      const int iy = 2 * oy0 - 3 + r;
-      if (iy >= 0 && iy < H) {
-        const uint4 v = *reinterpret_cast<const uint4*>(x + ((long long)(n * H + iy) * W) * 3 + cc * 8);
-        bf16_t* d = slab + r * PW + 9 + cc * 8;          // odd element offset: 2-byte stores
-        const unsigned wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          d[2 * i] = (bf16_t)(wv[i] & 0xFFFFu);
-          d[2 * i + 1] = (bf16_t)(wv[i] >> 16);
-        }
-      }
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's rows of the tile have landed ...
+    __syncthreads();                                     // ... everybody's have; the previous tile's output staging is done with LDS
 
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     for (int mt = wave; mt < nmt; mt += 4) {
@@ -959,7 +985,7 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
       const bool mvalid = m < npix;
       if (!mvalid) m = npix - 1;
       const int rr = m / OW, ox = m - rr * OW;
-      const unsigned* arow = reinterpret_cast<const unsigned*>(slab + (2 * rr) * PW + 6 * ox);   // 4-byte aligned
+      const unsigned* arow = reinterpret_cast<const unsigned*>(slab + (2 * rr) * PW + 6 + 6 * ox);   // 4-byte aligned
       f32x16 acc[2];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -1000,6 +1026,12 @@ __global__ __launch_bounds__(256, 2) void conv0_fwd_kernel(const bf16_t* __restr
       }
     }
     __syncthreads();
+    // every wave is done with the slab: the next tile's rows are requested now and land while this tile's statistics and
+    // output rows go out
+    {
+      const int nx = tile + (int)gridDim.x;
+      if (nx < ntile) c0_dma_slab(x, nx / (OH >> 1), (nx % (OH >> 1)) * 2, H, W, slab_lds, PW, wave_u, lane);
+    }
     if (tid < 64) {
       float a = 0.f, b = 0.f;
 #pragma unroll
@@ -1172,8 +1204,8 @@ extern "C" int mcl_conv0_fwd(const void* x, int32_t N, int32_t H, int32_t W, con
     return MCL_EUNSUPPORTED;
   const int OH = H / 2, OW = W / 2;
   const int ntile = N * (OH / 2);
-  const int PW = (W + 6) * 3 + 8;
-  const size_t lds_bytes = (size_t)((9 * PW * 2 + 15) & ~15) + 256 * 128 + 4 * 64 * 2 * 4;
+  const int PW = c0_pw(W);
+  const size_t lds_bytes = (size_t)(9 * PW * 2) + 256 * 128 + 4 * 64 * 2 * 4;
   static mcl_device_once attr_once;
   if (auto attr_guard = attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_fwd_kernel),
