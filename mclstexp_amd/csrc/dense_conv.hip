@@ -951,20 +951,40 @@ __global__ __launch_bounds__(256, 3) void conv0_fwd_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
 
-  // weight fragments: B[k][n], lane supplies n = nt*32 + l31, k chunk q = 2*s + h -> (ky = q/3, j0 = 8*(q%3))
+  // weight fragments: B[k][n], lane supplies n = nt*32 + l31, k chunk q = 2*s + h -> (ky = q/3, j0 = 8*(q%3)).
+  // The 18.8 KB weight goes through LDS first (coalesced dword loads, all in flight; the output staging area is free until the first
+  // epilogue): read from global memory element by element, each of a lane's 176 two-byte loads sat behind a bounds branch and
+  // waited for the previous one (vmcnt(0) at every join) -- 27 us at the head of every workgroup, a quarter of the launch; and
+  // 150 unconditional two-byte loads in flight at once spill.
+  {
+    constexpr int WDW = (C0_OUT * C0_K * 21) / 2;         // 4704 dwords
+    unsigned* wl = reinterpret_cast<unsigned*>(ot);
+    const unsigned* w32 = reinterpret_cast<const unsigned*>(Wt);
+    unsigned wv[(WDW + 255) / 256];
+#pragma unroll
+    for (int k = 0; k < (WDW + 255) / 256; ++k) wv[k] = w32[min(tid + 256 * k, WDW - 1)];
+#pragma unroll
+    for (int k = 0; k < (WDW + 255) / 256; ++k) wl[min(tid + 256 * k, WDW - 1)] = wv[k];
+  }
+  __syncthreads();
   bf16x8 breg[2][11];
+  {
+    const bf16_t* wls = reinterpret_cast<const bf16_t*>(ot);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int s = 0; s < 11; ++s) {
-      const int q = 2 * s + h, ky = q / 3, j0 = (q % 3) * 8;
-      const int co = nt * 32 + l31;
+      for (int s = 0; s < 11; ++s) {
+        const int q = 2 * s + h, ky = q / 3, j0 = (q % 3) * 8;
+        const int co = nt * 32 + l31;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int j = j0 + i - 1;                         // (k-run element j' = j0 + i holds weight j' - 1: see C0_P0)
-        breg[nt][s][i] = (q < 21 && j >= 0 && j < 21) ? (short)Wt[(co * C0_K + ky) * 21 + j] : (short)0;
+        for (int i = 0; i < 8; ++i) {
+          const int j = j0 + i - 1;                       // (k-run element j' = j0 + i holds weight j' - 1: see C0_P0)
+          const bool ok = q < 21 && j >= 0 && j < 21;
+          const short w1 = (short)wls[ok ? (co * C0_K + ky) * 21 + j : 0];
+          breg[nt][s][i] = ok ? w1 : (short)0;
+        }
       }
-    }
+  }
   const int nmt = (npix + 31) >> 5;
   const unsigned slab_lds = (unsigned)(size_t)((__attribute__((address_space(3))) void*)(lds));
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
