@@ -231,18 +231,28 @@ class TrainStep:
         want_seg = (self.reducer is not None and n_seg > 1 and hasattr(m, "segment_backward")
                     and hasattr(self.opt, "flat_location"))
         m.segment_backward = tuple(range(n_blocks - n_seg + 2, n_blocks + 1)) if want_seg else ()
+        # (zero_grad rides on the spot lane inside graph A, as in the single-graph step: nothing touches .grad between the
+        #  previous step's optimizer and graph B)
+        zeroed = []
+
+        def _zero_on_spot_lane():
+            self.opt.zero_grad()
+            zeroed.append(True)
+        m._spot_lane_prologue = _zero_on_spot_lane
         try:
             with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
                 self.es, self.ei = m.embed(self.static_in)
         finally:
             m.segment_backward = ()
+            m._spot_lane_prologue = None
         cuts = list(getattr(m, "backward_cuts", None) or []) if want_seg else []
         m.backward_cuts = None
         self.d_es = torch.zeros_like(self.es)
         self.d_ei = torch.zeros_like(self.ei)
         self.gb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode="thread_local"):
-            self.opt.zero_grad()
+            if not zeroed:
+                self.opt.zero_grad()
             torch.autograd.backward((self.es, self.ei), (self.d_es, self.d_ei))
         self.seg_graphs, self.seg_ranges = [], []
         if cuts:
