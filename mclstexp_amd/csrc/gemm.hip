@@ -119,12 +119,73 @@ __device__ __forceinline__ void store_slice(const float (&reg)[8], unsigned ok, 
   }
 }
 
+// The same with the loads inside their bounds branches (the form of rounds 1-5), for launches with many workgroups per CU: there
+// other workgroups cover the serialised loads, and the clamps, masks and selects of the form above cost the VALU-bound big-tile
+// kernels 7-9 % (fp32 ViT-B/16 170.7 vs 156.1 ms/step).  Stage one (rows x BK) operand slice: X[r*sr + k*sk] with
+// r in [r0, r0+64) and k in [k0, k0+BK).  KC: contiguous along k (sk == 1) else along r (sr == 1).
+// Each thread carries 8 floats.  VEC: 16-byte loads allowed.
+template <bool KC, bool VEC>
+__device__ __forceinline__ void load_slice_branchy(float (&reg)[8], const float* __restrict__ X, long long sr, long long sk,
+                                           int r0, int k0, int R, int K, int tid) {
+  if (KC) {
+    // 64 rows x 32 k: 8 float4 per row -> thread t: row = t/8 + 32*h, kq = (t%8)*4
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = r0 + (tid >> 3) + 32 * h;
+      const int k = k0 + (tid & 7) * 4;
+      const float* p = X + (long long)r * sr + k;
+      if (VEC && r < R && k + 3 < K) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        reg[h * 4 + 0] = v.x; reg[h * 4 + 1] = v.y; reg[h * 4 + 2] = v.z; reg[h * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[h * 4 + i] = (r < R && k + i < K) ? p[i] : 0.0f;
+      }
+    }
+  } else {
+    // contiguous along r: 32 k-rows x 64 r: 16 float4 per k -> thread t: k = t/16 + 16*h, rq = (t%16)*4
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + (tid >> 4) + 16 * h;
+      const int r = r0 + (tid & 15) * 4;
+      const float* p = X + (long long)k * sk + r;
+      if (VEC && k < K && r + 3 < R) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        reg[h * 4 + 0] = v.x; reg[h * 4 + 1] = v.y; reg[h * 4 + 2] = v.z; reg[h * 4 + 3] = v.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[h * 4 + i] = (k < K && r + i < R) ? p[i] : 0.0f;
+      }
+    }
+  }
+}
+
+// Write the staged registers into the LDS slice T[k][r] (row stride LDT words).
+template <bool KC, int LDT>
+__device__ __forceinline__ void store_slice_plain(const float (&reg)[8], float* __restrict__ T, int tid) {
+  if (KC) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = (tid >> 3) + 32 * h, k = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T[(k + i) * LDT + r] = reg[h * 4 + i];
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = (tid >> 4) + 16 * h, r = (tid & 15) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) T[k * LDT + r + i] = reg[h * 4 + i];
+    }
+  }
+}
+
 // TM = 1: the 64 x 64 tile (each wave one 32 x 32 block).  TM = 2: a 128 x 128 tile for problems with many tiles (the fp32
 // "reference numerics" image encoders: M = 25 216 token rows, im2col rows of the generic convolutions) -- each wave a 64 x 64 block as
 // 2 x 2 MFMA tiles: two A and two B operand reads feed four products, and a tile's operand traffic per flop halves (the 64 x 64
 // form asks L2 for 16 KB per 262 kflop: ~10 TB/s with every CU busy).
 // (the body is a device function of the block coordinates: mcl_gemm_group runs several problems' tiles in one launch)
-template <bool AKC, bool BKC, bool VEC, bool BF16, int TM, int PF = 1>
+template <bool AKC, bool BKC, bool VEC, bool BF16, int TM, int PF = 1, bool CLAMP = true>
 __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const int by, const int bzz, float* __restrict__ As,
                                           float* __restrict__ Bs) {
   constexpr int BMT = BM * TM, BNT = BN * TM, LD = BMT + 1;
@@ -156,8 +217,13 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
     if (u < nk) {
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        oa[u][t] = load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + u * BK, p.M, kend, tid);
-        ob[u][t] = load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + u * BK, p.N, kend, tid);
+        if (CLAMP) {
+          oa[u][t] = load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + u * BK, p.M, kend, tid);
+          ob[u][t] = load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + u * BK, p.N, kend, tid);
+        } else {
+          load_slice_branchy<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + u * BK, p.M, kend, tid);
+          load_slice_branchy<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + u * BK, p.N, kend, tid);
+        }
       }
     }
 
@@ -172,15 +238,25 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
     if (kt >= nk) break;
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      store_slice<AKC, LD>(ra[u][t], oa[u][t], As + 64 * t, tid);
-      store_slice<BKC, LD>(rb[u][t], ob[u][t], Bs + 64 * t, tid);
+      if (CLAMP) {
+        store_slice<AKC, LD>(ra[u][t], oa[u][t], As + 64 * t, tid);
+        store_slice<BKC, LD>(rb[u][t], ob[u][t], Bs + 64 * t, tid);
+      } else {
+        store_slice_plain<AKC, LD>(ra[u][t], As + 64 * t, tid);
+        store_slice_plain<BKC, LD>(rb[u][t], Bs + 64 * t, tid);
+      }
     }
     __syncthreads();
     if (kt + PF < nk) {
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
-        oa[u][t] = load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + (kt + PF) * BK, p.M, kend, tid);
-        ob[u][t] = load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + (kt + PF) * BK, p.N, kend, tid);
+        if (CLAMP) {
+          oa[u][t] = load_slice<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + (kt + PF) * BK, p.M, kend, tid);
+          ob[u][t] = load_slice<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + (kt + PF) * BK, p.N, kend, tid);
+        } else {
+          load_slice_branchy<AKC, VEC>(ra[u][t], A, p.sAm, p.sAk, m0 + 64 * t, kbeg + (kt + PF) * BK, p.M, kend, tid);
+          load_slice_branchy<BKC, VEC>(rb[u][t], B, p.sBn, p.sBk, n0 + 64 * t, kbeg + (kt + PF) * BK, p.N, kend, tid);
+        }
       }
     }
     if (!BF16) {
@@ -266,7 +342,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
       }
     return;
   }
-  if (TM == 1 && p.ksplit > 1 && p.cnt) {
+  if (CLAMP && TM == 1 && p.ksplit > 1 && p.cnt) {
     // Split-K in ONE launch: the partial goes out with write-through stores, the workgroup drains them and takes a ticket on its
     // tile's counter; the LAST slice to arrive adds all slices in slice order (the order of gemm_splitk_epilogue_kernel: the
     // result is the same bit for bit, whoever is last) and runs the epilogue below.  Nobody waits for anybody; the counter is
@@ -318,7 +394,7 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
       }
     }
   }
-  const bool merged = TM == 1 && p.ksplit > 1 && p.cnt;
+  const bool merged = CLAMP && TM == 1 && p.ksplit > 1 && p.cnt;
   // epilogue: acc[i][j][r] -> row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31 of the wave's (i, j) 32x32 block
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti)
@@ -342,40 +418,56 @@ __device__ __forceinline__ void gemm_tile(const GemmP& p, const int bx, const in
       // The epilogue's operands (GELU' argument, residual, the C that is accumulated into) for all 16 rows of the lane, loaded
       // up front from row-clamped addresses: inside the per-row bounds branch every one of them was followed by the compiler's
       // vmcnt(0) -- up to 48 dependent round trips per tile, more than the product itself on the spot path's skinny problems.
-      float av[16], rv[16], cv[16];
-      if (p.flags & MCL_EPI_GELU_BWD) {
+      // (the skinny-launch instances only: 48 registers -- the many-tile instances keep their occupancy and the per-row form)
+      if (CLAMP) {
+        float av[16], rv[16], cv[16];
+        if (p.flags & MCL_EPI_GELU_BWD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) av[r] = p.aux[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldaux + col];
-      }
-      if (R) {
+          for (int r = 0; r < 16; ++r) av[r] = p.aux[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldaux + col];
+        }
+        if (R) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = R[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col];
-      }
-      if (p.flags & MCL_EPI_ACCUM) {
+          for (int r = 0; r < 16; ++r) rv[r] = R[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldr + col];
+        }
+        if (p.flags & MCL_EPI_ACCUM) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cv[r] = C[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + col];
-      }
+          for (int r = 0; r < 16; ++r) cv[r] = C[(long long)min(rbase + (r & 3) + 8 * (r >> 2), p.M - 1) * p.ldc + col];
+        }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row >= p.M) continue;
-        float v = p.alpha * acc[ti][tj][r] + bias;
-        if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
-        if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
-        if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(av[r]);
-        if (R) v += rv[r];
-        if (p.flags & MCL_EPI_ACCUM) v += cv[r];
-        C[(long long)row * p.ldc + col] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row >= p.M) continue;
+          float v = p.alpha * acc[ti][tj][r] + bias;
+          if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
+          if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
+          if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(av[r]);
+          if (R) v += rv[r];
+          if (p.flags & MCL_EPI_ACCUM) v += cv[r];
+          C[(long long)row * p.ldc + col] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row >= p.M) continue;
+          float v = p.alpha * acc[ti][tj][r] + bias;
+          if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
+          if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
+          if (p.flags & MCL_EPI_GELU_BWD) v *= gelu_erf_grad(p.aux[(long long)row * p.ldaux + col]);
+          if (R) v += R[(long long)row * p.ldr + col];
+          if (p.flags & MCL_EPI_ACCUM) v += C[(long long)row * p.ldc + col];
+          C[(long long)row * p.ldc + col] = v;
+        }
       }
     }
 }
 
-template <bool AKC, bool BKC, bool VEC, bool BF16, int TM, int PF = 1>
+template <bool AKC, bool BKC, bool VEC, bool BF16, int TM, int PF = 1, bool CLAMP = true>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmP p) {
   constexpr int LD = BM * TM + 1;
   __shared__ float As[BK * LD];
   __shared__ float Bs[BK * LD];
-  gemm_tile<AKC, BKC, VEC, BF16, TM, PF>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+  gemm_tile<AKC, BKC, VEC, BF16, TM, PF, CLAMP>(p, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
 // Up to four independent fp32 problems as ONE launch (mcl_gemm_group): the weight gradients and the data gradient of a layer's
@@ -429,14 +521,18 @@ __global__ __launch_bounds__(256) void gemm_splitk_epilogue_kernel(const GemmP p
     if (p.flags & MCL_EPI_ACCUM) xc = *C;
     const float bias = p.bias ? p.bias[col] : 0.0f;
     float a = 0.0f;
-    for (int s0 = 0; s0 < p.ksplit; s0 += 8) {
-      float w[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) w[i] = p.ws[((long long)min(s0 + i, p.ksplit - 1) * p.batch + bz) * MN + e];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (s0 + i < p.ksplit) a += w[i];
-    }
+    // (batches of 2 / 4 / 8 by the slice count: a clamped surplus load is a real load -- with two slices of a 9 MB weight
+    //  gradient each, eight-wide batches read four times the bytes)
+#define MCL_SK_BATCH(NB)                                                                                              \
+  for (int s0 = 0; s0 < p.ksplit; s0 += NB) {                                                                         \
+    float w[NB];                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                                    \
+        w[i] = p.ws[((long long)min(s0 + i, p.ksplit - 1) * p.batch + bz) * MN + e];                                  \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i) if (s0 + i < p.ksplit) a += w[i];                                  \
+  }
+    if (p.ksplit <= 2) MCL_SK_BATCH(2) else if (p.ksplit <= 4) MCL_SK_BATCH(4) else if (p.ksplit % 8 == 0 || p.ksplit > 16)
+      MCL_SK_BATCH(8) else MCL_SK_BATCH(4)
+#undef MCL_SK_BATCH
     float v = p.alpha * a + bias;
     if (p.pre_out) p.pre_out[(long long)row * p.ldp + col] = v;
     if (p.flags & MCL_EPI_GELU) v = gelu_erf(v);
@@ -460,17 +556,31 @@ bool mcl_gemm_wide_tiles(const GemmP& p) {
   return wide && ((p.ksplit == 1 && big_tiles >= 512) || (p.ksplit > 1 && tiles64 >= 128 && p.K >= 8192 && big_tiles * p.ksplit >= 256));
 }
 
+// fp32 launches of at most four 64 x 64-tile workgroups per CU: the clamped + masked operand loads
+bool gemm_skinny(const GemmP& p, bool bf16) {
+  if (bf16 || mcl_gemm_wide_tiles(p)) return false;
+  return (long long)((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.batch * p.ksplit <= 1024;
+}
+
 template <bool AKC, bool BKC, bool VEC>
 void launch2(const GemmP& p, int batch, bool bf16, hipStream_t st) {
   if (mcl_gemm_wide_tiles(p)) {
     dim3 grid((p.N + 2 * BN - 1) / (2 * BN), (p.M + 2 * BM - 1) / (2 * BM), batch * p.ksplit), block(NT);
-    if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 2>), grid, block, 0, st, p);
-    else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 2>), grid, block, 0, st, p);
+    if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 2, 1, false>), grid, block, 0, st, p);
+    else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 2, 1, false>), grid, block, 0, st, p);
     return;
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch * p.ksplit), block(NT);
-  if (bf16) hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 1>), grid, block, 0, st, p);
-  else      hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 1>), grid, block, 0, st, p);
+  // the unconditional (clamped + masked) operand loads for launches of at most four workgroups per CU -- the skinny problems of the
+  // spot path, whose few waves cannot cover serialised loads; the many-tile problems keep the cheaper branchy staging
+  const bool skinny = gemm_skinny(p, bf16);
+  if (bf16) {
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, true, 1, 1, false>), grid, block, 0, st, p);
+  } else if (skinny) {
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 1, 1, true>), grid, block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<AKC, BKC, VEC, false, 1, 1, false>), grid, block, 0, st, p);
+  }
 }
 
 template <bool AKC, bool BKC>
@@ -489,6 +599,12 @@ extern "C" uint32_t mcl_gemm_args_size(void) { return (uint32_t)sizeof(mcl_gemm_
 extern "C" uint32_t mcl_gemm_args_min_size(void) { return kGemmArgsMin; }
 
 // Argument check + the kernel-side descriptor of one problem.  `vec`: 16-byte operand loads allowed.
+// (the clamped staging needs a 16-byte chunk to lie inside an operand or outside it as a whole: the extent along the contiguous
+//  dimension -- and the start of every split-K slice, a multiple of BK -- a multiple of 4)
+static bool gemm_vec_strict(const mcl_gemm_args* a, bool akc, bool bkc) {
+  return ((akc ? a->K : a->M) % 4 == 0) && ((bkc ? a->K : a->N) % 4 == 0);
+}
+
 static int gemm_prepare(const mcl_gemm_args* caller_args, mcl_gemm_args* a, GemmP& p, bool& akc, bool& bkc, bool& vec) {
   if (!caller_args) return MCL_EINVAL;
   const uint32_t sz = caller_args->struct_size;
@@ -518,15 +634,12 @@ static int gemm_prepare(const mcl_gemm_args* caller_args, mcl_gemm_args* a, Gemm
   p.resid = a->resid; p.ldr = a->ldr; p.sRb = a->sRb;
   p.pre_out = a->pre_out; p.ldp = a->ldp; p.aux = a->aux; p.ldaux = a->ldaux;
   p.batch = a->batch; p.ksplit = ksplit; p.ws = a->workspace;
-  p.cnt = ksplit > 1 ? a->counters : nullptr;
+  p.cnt = ksplit > 1 ? a->counters : nullptr;       // (mcl_gemm drops it again for a launch that is not "skinny")
   p.flt_thr = a->flt_thr; p.flt_cnt = a->flt_cnt; p.flt_val = a->flt_val; p.flt_idx = a->flt_idx; p.flt_cap = a->flt_cap;
   p.kchunk = ksplit > 1 ? (((a->K + ksplit - 1) / ksplit + BK - 1) / BK) * BK : a->K;
   // (the k-contiguous reading is preferred when a dimension of extent-1 stride is ambiguous)
   const long long lda = akc ? a->sAm : a->sAk, ldb = bkc ? a->sBn : a->sBk;
-  // (a 16-byte chunk must lie inside an operand or outside it as a whole: the extent along the contiguous dimension -- and the
-  //  start of every split-K slice, a multiple of BK -- a multiple of 4)
-  vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) && (a->sAb % 4 == 0) && (a->sBb % 4 == 0) &&
-        ((akc ? a->K : a->M) % 4 == 0) && ((bkc ? a->K : a->N) % 4 == 0);
+  vec = aligned16(a->A) && aligned16(a->B) && (lda % 4 == 0) && (ldb % 4 == 0) && (a->sAb % 4 == 0) && (a->sBb % 4 == 0);
   return MCL_OK;
 }
 
@@ -549,7 +662,7 @@ extern "C" int mcl_gemm_group(const mcl_gemm_args* args, int32_t n, mcl_stream_t
     const int rc = gemm_prepare(ai, &local, g.p[i], akc, bkc, vec);
     if (rc != MCL_OK) return rc;
     if (local.compute != MCL_COMPUTE_F32 || local.batch != 1 || local.ksplit > 1 || local.flt_thr) return MCL_EUNSUPPORTED;
-    g.layout[i] = (akc ? 1 : 0) | (bkc ? 2 : 0) | (vec ? 4 : 0);
+    g.layout[i] = (akc ? 1 : 0) | (bkc ? 2 : 0) | (vec && gemm_vec_strict(&local, akc, bkc) ? 4 : 0);
     g.first[i] = tiles;
     tiles += ((local.M + BM - 1) / BM) * ((local.N + BN - 1) / BN);
   }
@@ -571,6 +684,8 @@ extern "C" int mcl_gemm(const mcl_gemm_args* caller_args, mcl_stream_t stream) {
   const bool AKC = akc, BKC = bkc;
   hipStream_t st = mcl_stream(stream);
   const bool bf16 = a->compute == MCL_COMPUTE_BF16;
+  if (gemm_skinny(p, bf16)) vec = vec && gemm_vec_strict(a, akc, bkc);
+  else p.cnt = nullptr;
   if (AKC && BKC) launch1<true, true>(p, a->batch, vec, bf16, st);
   else if (AKC && !BKC) launch1<true, false>(p, a->batch, vec, bf16, st);
   else if (!AKC && BKC) launch1<false, true>(p, a->batch, vec, bf16, st);

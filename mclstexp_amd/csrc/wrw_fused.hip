@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void wrw_merge_kernel(const float* __restrict_
       acc8[u].x += v[u].x; acc8[u].y += v[u].y; acc8[u].z += v[u].z; acc8[u].w += v[u].w;                                \
     }                                                                                                                    \
   }
-    if (rounds <= 2) MERGE_TAIL(2) else if (rounds <= 4) MERGE_TAIL(4) else MERGE_TAIL(8)
+    if (rounds <= 1) MERGE_TAIL(1) else if (rounds <= 2) MERGE_TAIL(2) else if (rounds <= 4) MERGE_TAIL(4) else MERGE_TAIL(8)
 #undef MERGE_TAIL
   }
   float4 a;
