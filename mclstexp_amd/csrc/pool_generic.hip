@@ -59,18 +59,24 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
       m[i] = -INFINITY;
       am[i] = 0;
     }
+    // the nine taps: loaded unconditionally from clamped coordinates, all in flight together (a load inside the bounds branch is
+    // followed by the compiler's vmcnt(0) at the join: nine dependent round trips per output); a tap outside the map is skipped
+    float tap[9][V];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = min(max(2 * oy - 1 + t / 3, 0), H - 1), ix = min(max(2 * ox - 1 + t % 3, 0), W - 1);
+      El<T>::load(x + ((((long long)n * H + iy) * W + ix) * CV + cv) * V, tap[t]);
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-          float v[V];
-          El<T>::load(x + ((((long long)n * H + iy) * W + ix) * CV + cv) * V, v);
 #pragma unroll
           for (int i = 0; i < V; ++i)
-            if (v[i] > m[i]) {
-              m[i] = v[i];
+            if (tap[ky * 3 + kx][i] > m[i]) {
+              m[i] = tap[ky * 3 + kx][i];
               am[i] = (unsigned char)(ky * 3 + kx);
             }
         }
