@@ -166,3 +166,27 @@ def test_gemm_group_equals_separate_launches(ops):
     bad[0]["workspace"] = g2.data_ptr()
     with pytest.raises(RuntimeError):
         ops.gemm_group(bad)
+
+
+def test_fused_head_stress_under_traffic(ops):
+    """The ticket hand-off (write-through partials, drain, relaxed ticket, last arriver) a few hundred times with fresh data while a
+    second stream keeps the memory system busy: every result equals the first-principles value within fp32 noise AND repeats bit for
+    bit on an immediate second call."""
+    M, D = 128, 1000
+    q = {k: v.to(DEV) for k, v in _head_params(D, seed=9).items()}
+    noise_stream = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device=DEV)
+    w64 = {k: v.double() for k, v in q.items()}
+    for it in range(200):
+        x = _rand(M, D, seed=1000 + it, scale=2.0).to(DEV)
+        with torch.cuda.stream(noise_stream):
+            big.mul_(1.0001)                                   # 256 MB of traffic beside the head kernels
+        e1 = ops.proj_head_fwd(x, q["wp"], q["bp"], q["wf"], q["bf"], q["g"], q["be"])[0]
+        e2 = ops.proj_head_fwd(x, q["wp"], q["bp"], q["wf"], q["bf"], q["g"], q["be"])[0]
+        assert torch.equal(e1, e2), f"iteration {it}: not reproducible"
+        if it % 20 == 0:
+            p = x.double() @ w64["wp"].t() + w64["bp"]
+            z = torch.nn.functional.gelu(p) @ w64["wf"].t() + w64["bf"] + p
+            ref = torch.nn.functional.layer_norm(z, (256,), w64["g"], w64["be"], 1e-5)
+            assert float((e1.double() - ref).abs().max()) < 2e-5, f"iteration {it}"
+    torch.cuda.synchronize()
