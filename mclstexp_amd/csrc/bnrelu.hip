@@ -119,12 +119,20 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
   float fa = 0.0f, fb = 0.0f;
   double da = 0.0, db = 0.0;
   int cnt = 0;
-  for (int i = lane; i < nblk; i += 64) {
-    const float2 v = p[i];
-    fa += v.x;
-    fb += v.y;
-    if (++cnt == 4) {  // keep fp32 chains short (<= 4 terms) before widening
-      da += (double)fa; db += (double)fb; fa = fb = 0.0f; cnt = 0;
+  // eight loads in flight per trip (clamped index; the surplus not added), consumed in the same order and grouping as the
+  // one-load-per-trip form: that form was a chain of nblk / 64 dependent round trips (8 us for the transitions' 1568 partials)
+  for (int i0 = lane; i0 < nblk; i0 += 8 * 64) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[min(i0 + 64 * u, nblk - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + 64 * u >= nblk) break;
+      fa += v[u].x;
+      fb += v[u].y;
+      if (++cnt == 4) {  // keep fp32 chains short (<= 4 terms) before widening
+        da += (double)fa; db += (double)fb; fa = fb = 0.0f; cnt = 0;
+      }
     }
   }
   da += (double)fa;
